@@ -1,0 +1,360 @@
+"""ctypes binding of oracle/_build/liboracle.so -- the CPU restatement used as the checker.
+
+Test infrastructure only: imported from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Never imported by the cellranger_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+NO_FEATURE = 0xFFFFFFFF
+MAX_LIB = 16
+
+
+def build_oracle(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs
+    ):
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+class DupInfo(C.Structure):
+    _fields_ = [
+        ("has_dupinfo", C.c_uint8),
+        ("is_corrected", C.c_uint8),
+        ("is_low_support", C.c_uint8),
+        ("is_umi_count", C.c_uint8),
+        ("processed_umi", C.c_uint32),
+        ("read_count", C.c_uint32),
+    ]
+
+
+DUPINFO_DTYPE = np.dtype(
+    [("has_dupinfo", "u1"), ("is_corrected", "u1"), ("is_low_support", "u1"), ("is_umi_count", "u1"),
+     ("processed_umi", "<u4"), ("read_count", "<u4")]
+)
+UMICOUNT_DTYPE = np.dtype(
+    [("feature_idx", "<u4"), ("umi", "<u4"), ("read_count", "<u4"), ("utype", "u1"), ("_pad", "V3")]
+)
+
+
+class Reads(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("cb_len", C.c_uint32),
+        ("umi_len", C.c_uint32),
+        ("cb", C.c_void_p),
+        ("cb_qual", C.c_void_p),
+        ("umi", C.c_void_p),
+        ("umi_qual", C.c_void_p),
+        ("feature", C.c_void_p),
+        ("lib", C.c_void_p),
+        ("utype", C.c_void_p),
+    ]
+
+
+class BcResult(C.Structure):
+    _fields_ = [("corrected_cb", C.c_void_p), ("bc_state", C.c_void_p)]
+
+
+class Matrix(C.Structure):
+    _fields_ = [
+        ("n_barcodes", C.c_uint64),
+        ("cb_len", C.c_uint32),
+        ("barcodes", C.c_void_p),
+        ("indptr", C.c_void_p),
+        ("nnz", C.c_uint64),
+        ("indices", C.c_void_p),
+        ("data", C.c_void_p),
+        ("n_umi_counts", C.c_uint64),
+        ("mol_bc_col", C.c_void_p),
+        ("mol_lib", C.c_void_p),
+        ("mol", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build_oracle()
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i64, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.c_double
+    L.oracle_whitelist_new.restype = vp
+    L.oracle_whitelist_new.argtypes = [C.c_char_p, u32, u32, C.c_char_p]
+    L.oracle_whitelist_free.argtypes = [vp]
+    L.oracle_whitelist_contains.argtypes = [vp, C.c_char_p, u32]
+    L.oracle_whitelist_check_and_update.argtypes = [vp, C.c_char_p, u32, C.c_char_p]
+    L.oracle_whitelist_match.argtypes = [vp, C.c_char_p, u32, C.c_char_p]
+    L.oracle_hist_new.restype = vp
+    L.oracle_hist_free.argtypes = [vp]
+    L.oracle_hist_observe_by.argtypes = [vp, C.c_char_p, u32, i64]
+    L.oracle_hist_get.restype = i64
+    L.oracle_hist_get.argtypes = [vp, C.c_char_p, u32]
+    L.oracle_hist_size.restype = u64
+    L.oracle_hist_size.argtypes = [vp]
+    L.oracle_hist_dump_sorted.argtypes = [vp, u32, vp, vp]
+    L.oracle_probability.restype = dbl
+    L.oracle_probability.argtypes = [C.c_uint8]
+    L.oracle_posterior_correct.argtypes = [vp, vp, C.c_char_p, vp, u32, dbl, dbl, C.c_char_p]
+    L.oracle_umi_is_valid.argtypes = [C.c_char_p, vp, u32]
+    L.oracle_encode_2bit_u32.restype = u32
+    L.oracle_encode_2bit_u32.argtypes = [C.c_char_p, u32]
+    L.oracle_mark_dups_group.restype = u64
+    L.oracle_mark_dups_group.argtypes = [vp, u32, vp, vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]
+    L.oracle_correct_umis.argtypes = [vp, u32, vp, vp, u64, vp]
+    L.oracle_barcode_stage.argtypes = [C.POINTER(Reads), vp, vp, vp, vp, dbl, dbl, C.c_int, C.POINTER(BcResult)]
+    L.oracle_count_stage.restype = C.POINTER(Matrix)
+    L.oracle_count_stage.argtypes = [C.POINTER(Reads), C.POINTER(BcResult), vp, vp, C.c_int, u32, C.c_int, vp]
+    L.oracle_matrix_free.argtypes = [C.POINTER(Matrix)]
+    L.oracle_write_mtx.restype = i64
+    L.oracle_write_mtx.argtypes = [C.POINTER(Matrix), u32, C.c_char_p, C.c_char_p]
+    L.oracle_correct_feature_barcode.restype = i64
+    L.oracle_correct_feature_barcode.argtypes = [C.c_char_p, u32, u32, vp, C.c_char_p, vp]
+    L.oracle_find_closest_feature.restype = i64
+    L.oracle_find_closest_feature.argtypes = [C.c_char_p, u32, u32, vp, C.c_char_p, vp]
+    L.oracle_compute_feature_dist.argtypes = [vp, vp, u32, vp]
+    _lib = L
+    return L
+
+
+DBL_MAX = float(np.finfo(np.float64).max)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def as_bytes_matrix(seqs, length=None):
+    """list of str/bytes (or an (n, len) uint8 array) -> contiguous (n, len) uint8 array."""
+    if isinstance(seqs, np.ndarray):
+        return np.ascontiguousarray(seqs, dtype=np.uint8)
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    if length is None:
+        length = len(bs[0]) if bs else 0
+    assert all(len(b) == length for b in bs)
+    return np.frombuffer(b"".join(bs), dtype=np.uint8).reshape(len(bs), length).copy()
+
+
+class Whitelist:
+    """barcode/src/whitelist.rs Whitelist::{Plain, Trans}."""
+
+    def __init__(self, keys, translated=None):
+        self.keys = as_bytes_matrix(keys)
+        self.n, self.len = self.keys.shape
+        self.translated = None if translated is None else as_bytes_matrix(translated, self.len)
+        self.h = lib().oracle_whitelist_new(
+            self.keys.tobytes(), self.n, self.len, None if self.translated is None else self.translated.tobytes()
+        )
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_whitelist_free(self.h)
+            self.h = None
+
+    def contains(self, seq):
+        s = seq.encode() if isinstance(seq, str) else bytes(seq)
+        return bool(lib().oracle_whitelist_contains(self.h, s, len(s)))
+
+    def check_and_update(self, seq):
+        s = seq.encode() if isinstance(seq, str) else bytes(seq)
+        out = C.create_string_buffer(len(s))
+        if lib().oracle_whitelist_check_and_update(self.h, s, len(s), out):
+            return out.raw
+        return None
+
+    def match_to_whitelist(self, seq):
+        s = seq.encode() if isinstance(seq, str) else bytes(seq)
+        out = C.create_string_buffer(len(s))
+        if lib().oracle_whitelist_match(self.h, s, len(s), out):
+            return out.raw
+        return None
+
+
+class Hist:
+    """metric SimpleHistogram<BcSegSeq>."""
+
+    def __init__(self, items=None):
+        self.h = lib().oracle_hist_new()
+        for k, v in (items or {}).items():
+            self.observe_by(k, v)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_hist_free(self.h)
+            self.h = None
+
+    def observe_by(self, seq, by=1):
+        s = seq.encode() if isinstance(seq, str) else bytes(seq)
+        lib().oracle_hist_observe_by(self.h, s, len(s), by)
+
+    def get(self, seq):
+        s = seq.encode() if isinstance(seq, str) else bytes(seq)
+        return lib().oracle_hist_get(self.h, s, len(s))
+
+    def __len__(self):
+        return lib().oracle_hist_size(self.h)
+
+    def dump_sorted(self, length):
+        n = len(self)
+        seqs = np.zeros((n, length), dtype=np.uint8)
+        cnt = np.zeros(n, dtype=np.int64)
+        if n:
+            lib().oracle_hist_dump_sorted(self.h, length, _ptr(seqs), _ptr(cnt))
+        return seqs, cnt
+
+
+def posterior_correct(wl, hist, seq, qual, max_expected_errors=DBL_MAX, threshold=0.975):
+    """Posterior::correct_barcode (corrector.rs:111-165). Returns corrected bytes or None."""
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    q = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
+    out = C.create_string_buffer(len(s))
+    ok = lib().oracle_posterior_correct(wl.h, hist.h if hist is not None else None, s, _ptr(q), len(s),
+                                        max_expected_errors, threshold, out)
+    return out.raw if ok else None
+
+
+def umi_is_valid(seq, qual):
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    q = np.ascontiguousarray(qual, dtype=np.uint8)
+    return bool(lib().oracle_umi_is_valid(s, _ptr(q), len(s)))
+
+
+def encode_2bit(seq):
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    return lib().oracle_encode_2bit_u32(s, len(s))
+
+
+def correct_umis(umis, genes, counts):
+    u = as_bytes_matrix(umis)
+    g = np.ascontiguousarray(genes, dtype=np.uint32)
+    c = np.ascontiguousarray(counts, dtype=np.uint64)
+    out = np.zeros(len(g), dtype=np.int64)
+    lib().oracle_correct_umis(_ptr(u), u.shape[1], _ptr(g), _ptr(c), len(g), _ptr(out))
+    return out
+
+
+def mark_dups_group(umis, umi_valid, feature, utype=None, qname=None, umi_correction=True, filter_umis=True):
+    u = as_bytes_matrix(umis)
+    n, ul = u.shape
+    v = np.ascontiguousarray(umi_valid, dtype=np.uint8)
+    f = np.ascontiguousarray(feature, dtype=np.uint32)
+    t = np.zeros(n, dtype=np.uint8) if utype is None else np.ascontiguousarray(utype, dtype=np.uint8)
+    q = np.arange(n, dtype=np.uint64) if qname is None else np.ascontiguousarray(qname, dtype=np.uint64)
+    dup = np.zeros(n, dtype=DUPINFO_DTYPE)
+    uc = np.zeros(n, dtype=UMICOUNT_DTYPE)
+    m = lib().oracle_mark_dups_group(_ptr(u), ul, _ptr(v), _ptr(f), _ptr(t), _ptr(q), n, int(umi_correction),
+                                     int(filter_umis), _ptr(dup), _ptr(uc))
+    return dup, uc[:m]
+
+
+class PipelineResult:
+    pass
+
+
+def run_pipeline(reads, whitelists, n_lib=1, multiplexing_lib_mask=0, n_threads=1,
+                 max_expected_errors=DBL_MAX, threshold=0.975, count=True, want_dupinfo=False):
+    """reads: dict with cb (n,L) u8, cb_qual (n,L) u8, optional umi/umi_qual/feature/lib/utype.
+    whitelists: list indexed by library id of tests.oracle_lib.Whitelist (or None)."""
+    cb = np.ascontiguousarray(reads["cb"], dtype=np.uint8)
+    n, L = cb.shape
+    cbq = np.ascontiguousarray(reads["cb_qual"], dtype=np.uint8)
+    umi = reads.get("umi")
+    R = Reads()
+    R.n, R.cb_len = n, L
+    R.cb, R.cb_qual = _ptr(cb), _ptr(cbq)
+    keep = [cb, cbq]
+    if umi is not None:
+        umi = np.ascontiguousarray(umi, dtype=np.uint8)
+        uq = np.ascontiguousarray(reads["umi_qual"], dtype=np.uint8)
+        feat = np.ascontiguousarray(reads["feature"], dtype=np.uint32)
+        R.umi_len = umi.shape[1]
+        R.umi, R.umi_qual, R.feature = _ptr(umi), _ptr(uq), _ptr(feat)
+        keep += [umi, uq, feat]
+    libarr = reads.get("lib")
+    if libarr is not None:
+        libarr = np.ascontiguousarray(libarr, dtype=np.uint8)
+        R.lib = _ptr(libarr)
+        keep.append(libarr)
+    ut = reads.get("utype")
+    if ut is not None:
+        ut = np.ascontiguousarray(ut, dtype=np.uint8)
+        R.utype = _ptr(ut)
+        keep.append(ut)
+
+    wl_arr = (C.c_void_p * MAX_LIB)()
+    for i, w in enumerate(whitelists):
+        wl_arr[i] = w.h if w is not None else None
+    valid = [Hist() for _ in range(MAX_LIB)]
+    corr = [Hist() for _ in range(MAX_LIB)]
+    v_arr = (C.c_void_p * MAX_LIB)(*[h.h for h in valid])
+    c_arr = (C.c_void_p * MAX_LIB)(*[h.h for h in corr])
+
+    out = PipelineResult()
+    out.corrected_cb = np.zeros((n, L), dtype=np.uint8)
+    out.bc_state = np.zeros(n, dtype=np.uint8)
+    B = BcResult()
+    B.corrected_cb, B.bc_state = _ptr(out.corrected_cb), _ptr(out.bc_state)
+    rc = lib().oracle_barcode_stage(C.byref(R), wl_arr, v_arr, c_arr, None, max_expected_errors, threshold,
+                                    n_threads, C.byref(B))
+    assert rc == 0
+    out.valid_hist, out.corrected_hist = valid, corr
+    if count and umi is not None:
+        dup = np.zeros(n, dtype=DUPINFO_DTYPE) if want_dupinfo else None
+        mp = lib().oracle_count_stage(C.byref(R), C.byref(B), v_arr, c_arr, n_lib, multiplexing_lib_mask,
+                                      n_threads, _ptr(dup))
+        m = mp.contents
+        V, nnz, nm = m.n_barcodes, m.nnz, m.n_umi_counts
+
+        def arr(p, dtype, count):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(p), dtype=dtype).copy()
+
+        out.barcodes = arr(m.barcodes, np.uint8, V * L).reshape(V, L)
+        out.indptr = arr(m.indptr, np.int64, V + 1)
+        out.indices = arr(m.indices, np.int32, nnz)
+        out.data = arr(m.data, np.int32, nnz)
+        out.mol_bc_col = arr(m.mol_bc_col, np.uint32, nm)
+        out.mol_lib = arr(m.mol_lib, np.uint8, nm)
+        out.mol = arr(m.mol, UMICOUNT_DTYPE, nm)
+        out.dupinfo = dup
+        out._matrix_ptr = None
+        lib().oracle_matrix_free(mp)
+    return out
+
+
+def correct_feature_barcode(feat_seqs, feat_dist, seq, qual):
+    fs = as_bytes_matrix(feat_seqs)
+    d = np.ascontiguousarray(feat_dist, dtype=np.float64)
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    q = np.frombuffer(qual.encode() if isinstance(qual, str) else bytes(qual), dtype=np.uint8).copy()
+    return lib().oracle_correct_feature_barcode(fs.tobytes(), fs.shape[0], fs.shape[1], _ptr(d), s, _ptr(q))
+
+
+def find_closest_feature(feat_seqs, feat_dist, seq, qual):
+    fs = as_bytes_matrix(feat_seqs)
+    d = None if feat_dist is None else np.ascontiguousarray(feat_dist, dtype=np.float64)
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    q = np.frombuffer(qual.encode() if isinstance(qual, str) else bytes(qual), dtype=np.uint8).copy()
+    return lib().oracle_find_closest_feature(fs.tobytes(), fs.shape[0], fs.shape[1], _ptr(d), s, _ptr(q))
+
+
+def compute_feature_dist(counts, feature_types):
+    c = np.ascontiguousarray(counts, dtype=np.int64)
+    t = np.ascontiguousarray(feature_types, dtype=np.uint32)
+    out = np.zeros(len(c), dtype=np.float64)
+    lib().oracle_compute_feature_dist(_ptr(c), _ptr(t), len(c), _ptr(out))
+    return out
