@@ -1,0 +1,173 @@
+"""ctypes binding of libcrgpu.so (include/crgpu.h).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is visible, loading or
+`Context()` raises.  Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libcrgpu.so")
+
+MISS = 0xFFFFFFFF
+NO_FEATURE = 0xFFFFFFFF
+MAX_LIB = 16
+FLAG_LIB_MASK = 0x0F
+FLAG_CB_HAS_N = 0x10
+FLAG_NONTXOMIC = 0x20
+
+COUNTS_VALID, COUNTS_CORRECTED, COUNTS_PRIOR = 0, 1, 2
+T_NAMES = ["pack", "match", "correct", "keys", "sort", "dedup", "matrix", "synth"]
+
+
+class CrgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("crgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Records(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("umi_len", C.c_uint32),
+        ("d_bc_idx", C.c_void_p),
+        ("d_umi", C.c_void_p),
+        ("d_umi_qualn", C.c_void_p),
+        ("d_feature", C.c_void_p),
+        ("d_flags", C.c_void_p),
+    ]
+
+
+class MatrixView(C.Structure):
+    _fields_ = [
+        ("n_barcodes", C.c_uint64),
+        ("nnz", C.c_uint64),
+        ("n_features", C.c_uint32),
+        ("cb_len", C.c_uint32),
+        ("barcode_rank", C.c_void_p),
+        ("barcode_seq", C.c_void_p),
+        ("indptr", C.c_void_p),
+        ("indices", C.c_void_p),
+        ("data", C.c_void_p),
+    ]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("cb_len", C.c_uint32),
+        ("umi_len", C.c_uint32),
+        ("n_wl", C.c_uint32),
+        ("wl_packed", C.c_void_p),
+        ("n_cells", C.c_uint32),
+        ("cell_wl_pos", C.c_void_p),
+        ("cell_cdf", C.c_void_p),
+        ("n_ambient", C.c_uint32),
+        ("ambient_wl_pos", C.c_void_p),
+        ("n_genes", C.c_uint32),
+        ("gene_cdf", C.c_void_p),
+        ("ambient_per_2_16", C.c_uint32),
+        ("cb_err_per_2_16", C.c_uint32),
+        ("umi_err_per_2_16", C.c_uint32),
+        ("n_per_2_20", C.c_uint32),
+        ("no_feature_per_2_16", C.c_uint32),
+        ("reads_per_umi", C.c_uint32),
+        ("n_total", C.c_uint64),
+        ("n_libs", C.c_uint32),
+    ]
+
+
+class SynthOut(C.Structure):
+    _fields_ = [
+        ("cb", C.c_void_p),
+        ("cb_qualn", C.c_void_p),
+        ("umi", C.c_void_p),
+        ("umi_qualn", C.c_void_p),
+        ("feature", C.c_void_p),
+        ("flags", C.c_void_p),
+    ]
+
+
+# every symbol include/crgpu.h declares: (restype, argtypes)
+_vp, _u8p, _u32, _u64, _i, _dbl = C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+SYMBOLS = {
+    "crgpu_abi_version": (_i, []),
+    "crgpu_create": (_i, [C.POINTER(_vp), _i]),
+    "crgpu_destroy": (None, [_vp]),
+    "crgpu_last_error": (C.c_char_p, [_vp]),
+    "crgpu_synchronize": (_i, [_vp]),
+    "crgpu_stream": (_vp, [_vp]),
+    "crgpu_malloc": (_i, [_vp, C.POINTER(_vp), _u64]),
+    "crgpu_free": (_i, [_vp, _vp]),
+    "crgpu_memcpy_h2d": (_i, [_vp, _vp, _vp, _u64]),
+    "crgpu_memcpy_d2h": (_i, [_vp, _vp, _vp, _u64]),
+    "crgpu_memset": (_i, [_vp, _vp, _i, _u64]),
+    "crgpu_timing_enable": (_i, [_vp, _i]),
+    "crgpu_timing_reset": (_i, [_vp]),
+    "crgpu_timing_get": (_i, [_vp, _vp, _vp]),
+    "crgpu_set_whitelist": (_i, [_vp, _i, C.c_char_p, _u32, _u32, C.c_char_p, _u32, _vp]),
+    "crgpu_set_whitelist_packed": (_i, [_vp, _i, _vp, _u32, _u32, _vp, _u32, _vp]),
+    "crgpu_whitelist_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
+    "crgpu_get_canon_order": (_i, [_vp, _vp, _vp]),
+    "crgpu_pack_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp]),
+    "crgpu_match_and_count_dev": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "crgpu_set_posterior": (_i, [_vp, _dbl, _dbl]),
+    "crgpu_correct_dev": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _vp]),
+    "crgpu_get_counts": (_i, [_vp, _i, _i, _vp]),
+    "crgpu_set_counts": (_i, [_vp, _i, _i, _vp]),
+    "crgpu_reset_counts": (_i, [_vp]),
+    "crgpu_counts_dev": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "crgpu_match_and_count": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
+    "crgpu_correct": (_i, [_vp, _i, _vp, _vp, _u64, _vp, _vp]),
+    "crgpu_set_key_layout": (_i, [_vp, _u32, _u32, _u32, _u32]),
+    "crgpu_build_keys_dev": (_i, [_vp, C.POINTER(Records), _vp, C.POINTER(_u64)]),
+    "crgpu_partition_keys_dev": (_i, [_vp, _vp, _u64, _u32, _vp, _vp]),
+    "crgpu_count_keys_dev": (_i, [_vp, _vp, _u64, C.POINTER(_vp)]),
+    "crgpu_counts_info": (_i, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "crgpu_counts_triplets_dev": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "crgpu_counts_triplets": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "crgpu_counts_molecules": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "crgpu_counts_free": (None, [_vp, _vp]),
+    "crgpu_assemble_matrix": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, C.POINTER(C.POINTER(MatrixView))]),
+    "crgpu_matrix_free": (None, [_vp, C.POINTER(MatrixView)]),
+    "crgpu_write_mtx": (_i, [_vp, C.POINTER(MatrixView), C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint16]),
+    "crgpu_count": (_i, [_vp, C.POINTER(Records), _u32, C.POINTER(C.POINTER(MatrixView))]),
+    "crgpu_set_feature_pattern": (_i, [_vp, _i, C.c_char_p, _u32, _u32, _vp, _vp]),
+    "crgpu_match_features_dev": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
+    "crgpu_synth_dev": (_i, [_vp, C.POINTER(SynthParams), _u64, _u64, C.POINTER(SynthOut)]),
+    "crgpu_synth_host": (_i, [C.POINTER(SynthParams), _u64, _u64, C.POINTER(SynthOut)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcrgpu.so and bind every symbol of include/crgpu.h (raises if one is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CrgpuError(-2, "%s not found: build it with `python -m cellranger_amd.build` "
+                             "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    missing = [name for name in SYMBOLS if not hasattr(L, name)]
+    if missing:
+        raise CrgpuError(-2, "libcrgpu.so does not export: %s" % ", ".join(missing))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def ptr(a):
+    """numpy array / int / None -> c_void_p"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))

@@ -1,0 +1,153 @@
+// common.h -- internal declarations shared by the libcrgpu translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/crgpu.h"
+
+#define CR_WAVE 64
+
+// --------------------------------------------------------------------------------------------
+// whitelist tables of one library type (device + host mirrors)
+//
+// Pigeonhole layout (DESIGN.md "K1/K2"): a barcode of `len` bases is split into a head of hA
+// bases and a tail of hB = len - hA bases.
+//   table A: raw keys sorted ascending (== by head, then tail).  offA[head] .. offA[head+1] is the
+//            bin of all keys with that head; tailA[] holds the tails (u16).
+//   table B: the same keys sorted by (tail, head).  offB[tail] bins, headB[] holds the heads.
+// Any Hamming-1 neighbour of a read either shares its head (mutation in the tail -> bin A) or
+// shares its tail (mutation in the head -> bin B).
+// valA[pos] = canonical rank of the key at sorted position pos (NULL => rank == pos, Plain list).
+// --------------------------------------------------------------------------------------------
+struct WlTables {
+    bool set = false;
+    uint32_t n = 0;          // raw keys (deduplicated)
+    uint32_t bitsA = 0;      // head bits (2*hA)
+    uint32_t bitsB = 0;      // tail bits (2*hB)
+    uint32_t *d_offA = nullptr;   // (1<<bitsA)+1
+    uint16_t *d_tailA = nullptr;  // n
+    uint32_t *d_valA = nullptr;   // n or nullptr
+    uint32_t *d_offB = nullptr;   // (1<<bitsB)+1
+    uint16_t *d_headB = nullptr;  // n
+    uint32_t *d_valid = nullptr;      // n_canon valid counts
+    uint32_t *d_corrected = nullptr;  // n_canon corrected counts
+    uint32_t *d_prior_override = nullptr;  // n_canon or nullptr (=> prior aliases d_valid)
+};
+
+struct FeaturePattern {
+    bool set = false;
+    uint32_t n = 0, len = 0;
+    bool has_dist = false;
+    uint32_t *d_seq = nullptr;    // n packed, sorted ascending
+    uint32_t *d_index = nullptr;  // n global feature index
+    double *d_dist = nullptr;     // n proportions
+};
+
+struct TimedSpan {
+    int slot;
+    hipEvent_t start, stop;
+};
+
+struct KeyLayout {
+    bool set = false;
+    uint32_t bits_bc = 0, bits_feat = 0, bits_lib = 0, bits_umi = 0;  // + 1 utype bit (LSB)
+    uint32_t n_features = 0, umi_len = 0, n_libs = 0, mux_mask = 0;
+    // shifts inside the primary key  [bc][feature][lib][umi][nontx]
+    uint32_t sh_umi() const { return 1; }
+    uint32_t sh_lib() const { return 1 + bits_umi; }
+    uint32_t sh_feat() const { return 1 + bits_umi + bits_lib; }
+    uint32_t sh_bc() const { return 1 + bits_umi + bits_lib + bits_feat; }
+    uint32_t total_bits() const { return 1 + bits_umi + bits_lib + bits_feat + bits_bc; }
+};
+
+struct crgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // canonical barcode space
+    bool canon_set = false;
+    uint32_t n_canon = 0, cb_len = 0;
+    std::vector<uint32_t> canon_sorted;  // packed, ascending
+    std::vector<uint32_t> canon_order;   // rank -> caller position
+
+    WlTables wl[CRGPU_MAX_LIB];
+    FeaturePattern pat[CRGPU_MAX_LIB];
+
+    double max_expected_errors = 1.7976931348623157e308;  // corrector.rs:104 (f64::MAX)
+    double confidence_threshold = 0.975;                   // corrector.rs:83
+    double *d_ptab = nullptr;  // 128 entries: probability(q) for q = 0..127 (corrector.rs:167-171)
+
+    KeyLayout layout;
+
+    // scratch
+    uint32_t *d_scalars = nullptr;  // small device counters
+    uint32_t *d_sort_hist = nullptr;  // RADIX x 2048 block histograms of the radix passes
+    void *d_scratch = nullptr;      // growable workspace
+    uint64_t scratch_bytes = 0;
+
+    // timing ledger
+    bool timing = false;
+    double acc_ms[CRGPU_T_NSLOTS] = {0};
+    uint64_t acc_launches[CRGPU_T_NSLOTS] = {0};
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+};
+
+int cr_fail(crgpu_ctx *ctx, int code, const char *fmt, ...);
+void cr_set_thread_error(const char *msg);
+
+#define CR_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return cr_fail((ctx), CRGPU_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define CR_TRY(expr)              \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != CRGPU_OK) return _rc; \
+    } while (0)
+
+#define CR_REQUIRE(ctx, cond, code, ...)                     \
+    do {                                                     \
+        if (!(cond)) return cr_fail((ctx), (code), __VA_ARGS__); \
+    } while (0)
+
+// workspace that only grows; returned pointer valid until the next cr_scratch call
+int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out);
+
+// timing scope: records a HIP event pair around the launches of one family when enabled
+struct CrTimer {
+    crgpu_ctx *ctx;
+    int slot;
+    hipEvent_t start = nullptr, stop = nullptr;
+    CrTimer(crgpu_ctx *c, int s);
+    ~CrTimer();
+};
+
+static inline uint32_t cr_ceil_log2(uint64_t n) {
+    uint32_t b = 0;
+    while ((1ull << b) < n) b++;
+    return b;
+}
+
+static inline uint32_t cr_grid(uint64_t n, uint32_t block, uint32_t max_blocks = 256u * 8u) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (uint32_t)g;
+}
+
+// internal entry points shared between translation units
+int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
+                      uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp);

@@ -1,0 +1,237 @@
+// ctx.hip -- context, memory helpers and the HIP-event timing ledger of libcrgpu.
+#include <cmath>
+
+#include "common.h"
+
+static thread_local std::string g_thread_err;
+
+void cr_set_thread_error(const char *msg) { g_thread_err = msg; }
+
+int cr_fail(crgpu_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_thread_err = buf;
+    return code;
+}
+
+extern "C" int crgpu_abi_version(void) { return CRGPU_ABI_VERSION; }
+
+extern "C" const char *crgpu_last_error(const crgpu_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : g_thread_err.c_str();
+}
+
+extern "C" int crgpu_create(crgpu_ctx **out, int device_id) {
+    if (!out) return cr_fail(nullptr, CRGPU_EINVAL, "crgpu_create: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return cr_fail(nullptr, CRGPU_ENODEV,
+                       "crgpu_create: no HIP device visible (%s); libcrgpu has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_id < 0 || device_id >= n_dev)
+        return cr_fail(nullptr, CRGPU_EINVAL, "crgpu_create: device_id %d out of range [0,%d)", device_id, n_dev);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return cr_fail(nullptr, CRGPU_ENODEV, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return cr_fail(nullptr, CRGPU_ENODEV, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return cr_fail(nullptr, CRGPU_ENODEV, "device %d is %s; libcrgpu is built for gfx950 (MI355X) only", device_id,
+                       prop.gcnArchName);
+
+    crgpu_ctx *ctx = new (std::nothrow) crgpu_ctx();
+    if (!ctx) return cr_fail(nullptr, CRGPU_ENOMEM, "crgpu_create: out of host memory");
+    ctx->device = device_id;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return cr_fail(nullptr, CRGPU_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    // probability(q) = 10^(-(q-33)/10) computed on the HOST with libm pow, exactly as the
+    // reference does per call (corrector.rs:167-171), for every 7-bit quality character.
+    double ptab[128];
+    for (int q = 0; q < 128; q++) ptab[q] = std::pow(10.0, -((double)q - 33.0) / 10.0);
+    if (hipMalloc(&ctx->d_ptab, sizeof(ptab)) != hipSuccess ||
+        hipMemcpy(ctx->d_ptab, ptab, sizeof(ptab), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&ctx->d_scalars, 4096) != hipSuccess || hipMemset(ctx->d_scalars, 0, 4096) != hipSuccess ||
+        hipMalloc(&ctx->d_sort_hist, sizeof(uint32_t) * 256 * 2048) != hipSuccess) {
+        crgpu_destroy(ctx);
+        return cr_fail(nullptr, CRGPU_ENOMEM, "crgpu_create: device allocation failed");
+    }
+    *out = ctx;
+    return CRGPU_OK;
+}
+
+static void free_wl(WlTables &w) {
+    hipFree(w.d_offA);
+    hipFree(w.d_tailA);
+    hipFree(w.d_valA);
+    hipFree(w.d_offB);
+    hipFree(w.d_headB);
+    hipFree(w.d_valid);
+    hipFree(w.d_corrected);
+    hipFree(w.d_prior_override);
+    w = WlTables();
+}
+
+void cr_free_wl(WlTables &w) { free_wl(w); }
+
+extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &w : ctx->wl) free_wl(w);
+    for (auto &p : ctx->pat) {
+        hipFree(p.d_seq);
+        hipFree(p.d_index);
+        hipFree(p.d_dist);
+    }
+    hipFree(ctx->d_ptab);
+    hipFree(ctx->d_scalars);
+    hipFree(ctx->d_sort_hist);
+    hipFree(ctx->d_scratch);
+    for (auto &s : ctx->spans) {
+        hipEventDestroy(s.start);
+        hipEventDestroy(s.stop);
+    }
+    for (auto ev : ctx->event_pool) hipEventDestroy(ev);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int crgpu_synchronize(crgpu_ctx *ctx) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRGPU_OK;
+}
+
+extern "C" void *crgpu_stream(crgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int crgpu_malloc(crgpu_ctx *ctx, void **d_out, uint64_t bytes) {
+    if (!ctx || !d_out) return CRGPU_EINVAL;
+    *d_out = nullptr;
+    hipError_t e = hipMalloc(d_out, bytes ? bytes : 1);
+    if (e != hipSuccess) return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_free(crgpu_ctx *ctx, void *d_ptr) {
+    if (!ctx) return CRGPU_EINVAL;
+    if (!d_ptr) return CRGPU_OK;
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CR_HIP(ctx, hipFree(d_ptr));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_memcpy_h2d(crgpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes) {
+    if (!ctx) return CRGPU_EINVAL;
+    if (!bytes) return CRGPU_OK;
+    CR_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_memcpy_d2h(crgpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes) {
+    if (!ctx) return CRGPU_EINVAL;
+    if (!bytes) return CRGPU_OK;
+    CR_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_memset(crgpu_ctx *ctx, void *d_dst, int value, uint64_t bytes) {
+    if (!ctx) return CRGPU_EINVAL;
+    if (!bytes) return CRGPU_OK;
+    CR_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return CRGPU_OK;
+}
+
+int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_scratch) CR_HIP(ctx, hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        uint64_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&ctx->d_scratch, want);
+        if (e != hipSuccess)
+            return cr_fail(ctx, CRGPU_ENOMEM, "workspace hipMalloc(%llu): %s", (unsigned long long)want, hipGetErrorString(e));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->d_scratch;
+    return CRGPU_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+
+static hipEvent_t take_event(crgpu_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+CrTimer::CrTimer(crgpu_ctx *c, int s) : ctx(c), slot(s) {
+    if (!ctx->timing) return;
+    start = take_event(ctx);
+    stop = take_event(ctx);
+    hipEventRecord(start, ctx->stream);
+}
+
+CrTimer::~CrTimer() {
+    if (!start) return;
+    hipEventRecord(stop, ctx->stream);
+    ctx->spans.push_back({slot, start, stop});
+}
+
+static int drain_spans(crgpu_ctx *ctx) {
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &s : ctx->spans) {
+        float ms = 0.f;
+        CR_HIP(ctx, hipEventElapsedTime(&ms, s.start, s.stop));
+        ctx->acc_ms[s.slot] += ms;
+        ctx->acc_launches[s.slot] += 1;
+        ctx->event_pool.push_back(s.start);
+        ctx->event_pool.push_back(s.stop);
+    }
+    ctx->spans.clear();
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_timing_enable(crgpu_ctx *ctx, int on) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_TRY(drain_spans(ctx));
+    ctx->timing = on != 0;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_timing_reset(crgpu_ctx *ctx) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_TRY(drain_spans(ctx));
+    for (int i = 0; i < CRGPU_T_NSLOTS; i++) {
+        ctx->acc_ms[i] = 0;
+        ctx->acc_launches[i] = 0;
+    }
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_timing_get(crgpu_ctx *ctx, double *ms_out, uint64_t *launches_out) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_TRY(drain_spans(ctx));
+    for (int i = 0; i < CRGPU_T_NSLOTS; i++) {
+        if (ms_out) ms_out[i] = ctx->acc_ms[i];
+        if (launches_out) launches_out[i] = ctx->acc_launches[i];
+    }
+    return CRGPU_OK;
+}

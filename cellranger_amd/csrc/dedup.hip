@@ -1,0 +1,726 @@
+// dedup.hip -- count stage: molecule keys, run-length grouping, UMI correction, low-support
+// filtering and (barcode, feature) counting on sorted 64-bit keys.
+//
+// Replaces, per (barcode, library type) group of the reference:
+//   UmiInfo::new                      umi/src/info.rs:20-37        (validity of each UMI)
+//   DupBuilder::observe               tx_annotation/src/mark_dups.rs:128-155
+//   correct_umis                      mark_dups.rs:19-59
+//   BarcodeDupMarker::new             mark_dups.rs:202-277  (two-phase count move)
+//   determine_low_support_umigenes    mark_dups.rs:87-108
+//   BarcodeDupMarker::process         mark_dups.rs:280-363  (which keys yield a UmiCount)
+//   BcUmiInfo::feature_counts         cr_types/src/types.rs:180-188
+//
+// Key layout (KeyLayout in common.h), most significant first:
+//   [barcode rank][feature][library][UMI 2-bit][nonTxomic]
+// so that after ONE ascending sort
+//   * equal keys (ignoring the last bit) are the reads of one (UMI, feature): run length = read count,
+//   * a (barcode, feature, library) segment holds every UMI that correct_umis may compare,
+//   * a (barcode, feature) segment is one matrix entry.
+// Low-support grouping needs (barcode, library, UMI) across features: a second sort of the
+// DISTINCT keys on [barcode][library][UMI][feature] with the distinct-key index as payload.
+#include "common.h"
+
+int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_total_out);
+int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
+                          uint32_t n_ranks, uint64_t *counts_out);
+
+#define NONE32 0xFFFFFFFFu
+
+struct crgpu_counts {
+    uint64_t n_triplets = 0, n_molecules = 0;
+    uint32_t *d_bc = nullptr, *d_feature = nullptr, *d_count = nullptr;  // triplets
+    uint64_t *d_mkeys = nullptr;    // molecule keys (primary layout), n_molecules
+    uint32_t *d_mreads = nullptr;   // read_count of each molecule
+    KeyLayout layout;
+};
+
+// ------------------------------------------------------------------------------------------------
+// key layout
+// ------------------------------------------------------------------------------------------------
+extern "C" int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_t umi_len, uint32_t n_libs,
+                                    uint32_t multiplexing_lib_mask) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_set_key_layout: set the whitelist first");
+    CR_REQUIRE(ctx, n_features >= 1, CRGPU_EINVAL, "n_features must be >= 1");
+    CR_REQUIRE(ctx, umi_len >= 1 && umi_len <= 16, CRGPU_ERANGE, "umi_len must be 1..16");
+    CR_REQUIRE(ctx, n_libs >= 1 && n_libs <= CRGPU_MAX_LIB, CRGPU_EINVAL, "n_libs must be 1..%d", CRGPU_MAX_LIB);
+    KeyLayout L;
+    L.bits_bc = cr_ceil_log2(ctx->n_canon);
+    L.bits_feat = cr_ceil_log2(n_features);
+    L.bits_lib = cr_ceil_log2(n_libs);
+    L.bits_umi = 2 * umi_len;
+    L.n_features = n_features;
+    L.umi_len = umi_len;
+    L.n_libs = n_libs;
+    L.mux_mask = multiplexing_lib_mask;
+    CR_REQUIRE(ctx, L.total_bits() <= 64, CRGPU_ERANGE,
+               "molecule key needs %u bits (barcode %u + feature %u + library %u + umi %u + 1) > 64", L.total_bits(),
+               L.bits_bc, L.bits_feat, L.bits_lib, L.bits_umi);
+    L.set = true;
+    ctx->layout = L;
+    return CRGPU_OK;
+}
+
+struct KL {  // device copy of the layout
+    uint32_t sh_umi, sh_lib, sh_feat, sh_bc, bits_umi, bits_lib, bits_feat, bits_bc, umi_len, n_features, n_libs, mux_mask;
+};
+static KL make_kl(const KeyLayout &L) {
+    return KL{L.sh_umi(), L.sh_lib(), L.sh_feat(), L.sh_bc(), L.bits_umi, L.bits_lib, L.bits_feat, L.bits_bc,
+              L.umi_len, L.n_features, L.n_libs, L.mux_mask};
+}
+__device__ __forceinline__ uint64_t lowmask(uint32_t bits) { return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull); }
+
+// ------------------------------------------------------------------------------------------------
+// build keys (compacting)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t *__restrict__ bc_idx,
+                                                    const uint32_t *__restrict__ umi, const uint8_t *__restrict__ umi_q,
+                                                    const uint32_t *__restrict__ feature, const uint8_t *__restrict__ flags,
+                                                    uint64_t n, uint64_t *__restrict__ keys_out,
+                                                    unsigned long long *__restrict__ n_out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_round = (n + stride - 1) / stride * stride;
+    const uint32_t L = kl.umi_len;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        bool keep = false;
+        uint64_t key = 0;
+        if (i < n) {
+            const uint32_t b = bc_idx[i];
+            const uint32_t f = feature[i];
+            const uint32_t fl = flags ? flags[i] : 0u;
+            const uint32_t lib = fl & CRGPU_FLAG_LIB_MASK;
+            if (b != CRGPU_MISS && f != CRGPU_NO_FEATURE && f < kl.n_features && lib < kl.n_libs) {
+                const uint32_t u = umi[i] & (uint32_t)lowmask(kl.bits_umi);
+                // UmiInfo::new (umi/src/info.rs:20-37)
+                bool has_n = false, low_q = false;
+                for (uint32_t k = 0; k < L; k++) {
+                    const uint32_t q = umi_q[i * L + k];
+                    has_n |= (q & 0x80u) != 0u;
+                    low_q |= (uint8_t)((q & 0x7Fu) - 33u) < 10u;  // u8 wrapping subtraction, UMI_MIN_QV = 10
+                }
+                // is_homopolymer: every adjacent pair equal (true for a 1-base UMI)
+                const uint32_t adj = (u ^ (u >> 2)) & (uint32_t)lowmask(kl.bits_umi - 2u);
+                const bool homopolymer = adj == 0u;
+                if (!(has_n || homopolymer || low_q)) {
+                    keep = true;
+                    key = ((uint64_t)b << kl.sh_bc) | ((uint64_t)f << kl.sh_feat) | ((uint64_t)lib << kl.sh_lib) |
+                          ((uint64_t)u << kl.sh_umi) | ((fl & CRGPU_FLAG_NONTXOMIC) ? 1ull : 0ull);
+                }
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned long long base = 0;
+            if ((int)lane == leader) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
+            base = __shfl(base, leader);
+            if (keep) keys_out[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+    }
+}
+
+extern "C" int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out,
+                                    uint64_t *n_keys_out) {
+    if (!ctx || !recs || !n_keys_out) return CRGPU_EINVAL;
+    CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_build_keys: call crgpu_set_key_layout first");
+    CR_REQUIRE(ctx, recs->umi_len == ctx->layout.umi_len, CRGPU_EINVAL, "records umi_len %u != layout umi_len %u",
+               recs->umi_len, ctx->layout.umi_len);
+    *n_keys_out = 0;
+    if (recs->n == 0) return CRGPU_OK;
+    CR_REQUIRE(ctx, recs->d_bc_idx && recs->d_umi && recs->d_umi_qualn && recs->d_feature && d_keys_out, CRGPU_EINVAL,
+               "crgpu_build_keys: NULL buffer");
+    unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
+    {
+        CrTimer t(ctx, CRGPU_T_KEYS);
+        CR_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(*d_n), ctx->stream));
+        hipLaunchKernelGGL(k_build_keys, dim3(cr_grid(recs->n, 256)), dim3(256), 0, ctx->stream, make_kl(ctx->layout),
+                           recs->d_bc_idx, recs->d_umi, recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n,
+                           d_keys_out, d_n);
+        CR_HIP(ctx, hipGetLastError());
+    }
+    unsigned long long h = 0;
+    CR_TRY(crgpu_memcpy_d2h(ctx, &h, d_n, sizeof(h)));
+    *n_keys_out = h;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n, uint32_t n_ranks,
+                                        uint64_t *d_keys_out, uint64_t *counts_out) {
+    if (!ctx || !counts_out) return CRGPU_EINVAL;
+    CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_partition_keys: call crgpu_set_key_layout first");
+    CR_REQUIRE(ctx, n == 0 || (d_keys && d_keys_out), CRGPU_EINVAL, "crgpu_partition_keys: NULL buffer");
+    CrTimer t(ctx, CRGPU_T_KEYS);
+    return cr_partition_by_owner(ctx, d_keys, d_keys_out, n, ctx->layout.sh_bc(), n_ranks, counts_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic two-pass stream compaction driven by a flag functor: out position of every flagged item
+// ------------------------------------------------------------------------------------------------
+#define CP_BLOCK 256
+
+template <typename Flag>
+__global__ __launch_bounds__(CP_BLOCK) void k_cp_count(Flag flag, uint64_t n, uint64_t tile, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t ws[CP_BLOCK / 64];
+    const uint64_t lo = (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = lo + tile < n ? lo + tile : n;
+    uint32_t c = 0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += CP_BLOCK) c += flag(i) ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63u) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < CP_BLOCK / 64; w++) t += ws[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+template <typename Flag, typename Emit>
+__global__ __launch_bounds__(CP_BLOCK) void k_cp_write(Flag flag, Emit emit, uint64_t n, uint64_t tile,
+                                                       const uint32_t *__restrict__ block_offs) {
+    __shared__ uint32_t ws[CP_BLOCK / 64];
+    __shared__ uint32_t run_s;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = lo + tile < n ? lo + tile : n;
+    if (threadIdx.x == 0) run_s = block_offs[blockIdx.x];
+    __syncthreads();
+    for (uint64_t base = lo; base < hi; base += CP_BLOCK) {
+        const uint64_t i = base + threadIdx.x;
+        const bool f = i < hi && flag(i);
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) ws[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = run_s;
+        for (uint32_t w = 0; w < wave; w++) off += ws[w];
+        if (f) emit(i, off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < CP_BLOCK / 64; w++) t += ws[w];
+            run_s += t;
+        }
+        __syncthreads();
+    }
+}
+
+static uint32_t cp_blocks(uint64_t n, uint64_t *tile_out) {
+    uint64_t nb = (n + CP_BLOCK * 16 - 1) / (CP_BLOCK * 16);
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    uint64_t tile = (n + nb - 1) / nb;
+    tile = (tile + CP_BLOCK - 1) / CP_BLOCK * CP_BLOCK;
+    nb = (n + tile - 1) / tile;
+    if (nb < 1) nb = 1;
+    *tile_out = tile;
+    return (uint32_t)nb;
+}
+
+// d_block: workspace of >= 4096 u32.  *total_out (device u32) receives the number of flagged items.
+template <typename Flag, typename Emit>
+static int compact(crgpu_ctx *ctx, Flag flag, Emit emit, uint64_t n, uint32_t *d_block, uint32_t *d_total_out) {
+    uint64_t tile;
+    const uint32_t nb = cp_blocks(n, &tile);
+    hipLaunchKernelGGL(k_cp_count<Flag>, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, flag, n, tile, d_block);
+    CR_TRY(cr_scan_small(ctx, d_block, nb, d_total_out));
+    hipLaunchKernelGGL((k_cp_write<Flag, Emit>), dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, flag, emit, n, tile, d_block);
+    CR_HIP(ctx, hipGetLastError());
+    return CRGPU_OK;
+}
+
+// ---- functors --------------------------------------------------------------------------------------
+struct HeadFlag {  // first element of a run of equal (key >> shift)
+    const uint64_t *keys;
+    uint32_t shift;
+    __device__ __forceinline__ bool operator()(uint64_t i) const {
+        return i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift);
+    }
+};
+struct EmitRun {  // distinct key + start position of its run
+    const uint64_t *keys;
+    uint64_t *ukey;
+    uint32_t *upos;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t o) const {
+        ukey[o] = keys[i];
+        upos[o] = (uint32_t)i;
+    }
+};
+struct MolFlag {  // distinct key that yields a UmiCount (mark_dups.rs:322-325 with rate 1.0, no target filter)
+    const uint32_t *corr, *inc1;
+    const uint8_t *low;
+    __device__ __forceinline__ bool operator()(uint64_t k) const {
+        const bool landed = corr[k] == NONE32 || inc1[k] > 0u;  // some read's corrected key is k
+        return landed && !low[k];
+    }
+};
+struct EmitMol {
+    const uint64_t *ukey;
+    const uint32_t *upos, *corr, *inc_all;
+    const unsigned long long *minraw;
+    uint64_t n_keys, n_dist;
+    uint64_t *mkeys;
+    uint32_t *mreads;
+    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o) const {
+        // UmiType of the representative read (mark_dups.rs:250-268,326-329): the min (utype, qname)
+        // read of the smallest qualifying raw UMI corrected onto k, else of k itself.
+        const unsigned long long mr = minraw[k];
+        const uint64_t bit = mr != ~0ull ? (uint64_t)(mr & 1ull) : (ukey[k] & 1ull);
+        mkeys[o] = (ukey[k] & ~1ull) | bit;
+        const uint32_t end = k + 1 < n_dist ? upos[k + 1] : (uint32_t)n_keys;
+        const uint32_t cnt = end - upos[k];
+        // umigene_counts after both moves (mark_dups.rs:226-246): own reads stay only if not corrected away
+        mreads[o] = (corr[k] == NONE32 ? cnt : 0u) + inc_all[k];
+    }
+};
+struct EmitTriplet {
+    const uint64_t *mkeys;
+    uint32_t *tpos;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t o) const { tpos[o] = (uint32_t)i; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// UMI correction (correct_umis, mark_dups.rs:19-59)
+// ------------------------------------------------------------------------------------------------
+// segment [s, e) of distinct keys sharing (barcode, feature, library) with key k: galloping search
+__device__ __forceinline__ void segment_bounds(const uint64_t *__restrict__ ukey, uint64_t nd, uint64_t k, uint32_t shift,
+                                               uint64_t &s, uint64_t &e) {
+    const uint64_t pre = ukey[k] >> shift;
+    // backward
+    uint64_t lo = k, step = 1;
+    while (lo >= step && (ukey[lo - step] >> shift) == pre) {
+        lo -= step;
+        step <<= 1;
+    }
+    // first index with prefix == pre lies in (lo - step, lo]  (or [0, lo])
+    uint64_t a = lo >= step ? lo - step + 1 : 0, b = lo;
+    while (a < b) {
+        const uint64_t mid = (a + b) >> 1;
+        if ((ukey[mid] >> shift) == pre) b = mid; else a = mid + 1;
+    }
+    s = a;
+    // forward
+    uint64_t hi = k;
+    step = 1;
+    while (hi + step < nd && (ukey[hi + step] >> shift) == pre) {
+        hi += step;
+        step <<= 1;
+    }
+    a = hi;
+    b = hi + step < nd ? hi + step - 1 : nd - 1;  // last index with prefix == pre lies in [hi, b]
+    while (a < b) {
+        const uint64_t mid = (a + b + 1) >> 1;
+        if ((ukey[mid] >> shift) == pre) a = mid; else b = mid - 1;
+    }
+    e = a + 1;
+}
+
+__device__ __forceinline__ uint32_t run_count(const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys, uint64_t k) {
+    const uint32_t end = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
+    return end - upos[k];
+}
+
+#define SMALL_SEG 24
+
+__global__ __launch_bounds__(256) void k_correct_umis(const KL kl, const uint64_t *__restrict__ ukey,
+                                                      const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+                                                      uint32_t *__restrict__ corr, uint32_t *__restrict__ inc1,
+                                                      uint32_t *__restrict__ inc_all) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t umi_mask = lowmask(kl.bits_umi);
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
+        const uint64_t key = ukey[k];
+        const uint32_t lib = (uint32_t)((key >> kl.sh_lib) & lowmask(kl.bits_lib));
+        uint32_t target = NONE32;
+        if (!((kl.mux_mask >> lib) & 1u)) {  // UmiCorrection::Disable for Multiplexing Capture (aligner.rs:315-318)
+            uint64_t s, e;
+            segment_bounds(ukey, nd, k, kl.sh_lib, s, e);
+            if (e - s > 1) {
+                const uint32_t my_umi = (uint32_t)((key >> kl.sh_umi) & umi_mask);
+                const uint32_t my_cnt = run_count(upos, nd, n_keys, k);
+                uint32_t best_cnt = my_cnt, best_umi = my_umi;
+                uint64_t best_idx = k;
+                if (e - s <= SMALL_SEG) {
+                    // all pairs: every existing Hamming-1 neighbour competes on (count, umi)
+                    for (uint64_t j = s; j < e; j++) {
+                        if (j == k) continue;
+                        const uint32_t u = (uint32_t)((ukey[j] >> kl.sh_umi) & umi_mask);
+                        const uint32_t x = u ^ my_umi;
+                        const uint32_t y = (x | (x >> 1)) & 0x55555555u;
+                        if (y == 0u || (y & (y - 1u)) != 0u) continue;  // not exactly one base apart
+                        const uint32_t c = run_count(upos, nd, n_keys, j);
+                        if (c > best_cnt || (c == best_cnt && u > best_umi)) {
+                            best_cnt = c;
+                            best_umi = u;
+                            best_idx = j;
+                        }
+                    }
+                } else {
+                    // 3L probes, each a binary search inside the segment (sorted by UMI)
+                    const uint64_t pre = (key >> kl.sh_lib) << kl.bits_umi;
+                    for (uint32_t pos = 0; pos < kl.umi_len; pos++) {
+                        const uint32_t sh = 2u * (kl.umi_len - 1u - pos);
+                        const uint32_t orig = (my_umi >> sh) & 3u;
+                        for (uint32_t b = 0; b < 4; b++) {
+                            if (b == orig) continue;
+                            const uint32_t u = (my_umi & ~(3u << sh)) | (b << sh);
+                            const uint64_t want = pre | u;  // == ukey >> sh_umi of the probed key
+                            uint64_t lo = s, hi = e;
+                            while (lo < hi) {
+                                const uint64_t mid = (lo + hi) >> 1;
+                                if ((ukey[mid] >> kl.sh_umi) < want) lo = mid + 1; else hi = mid;
+                            }
+                            if (lo < e && (ukey[lo] >> kl.sh_umi) == want) {
+                                const uint32_t c = run_count(upos, nd, n_keys, lo);
+                                if (c > best_cnt || (c == best_cnt && u > best_umi)) {
+                                    best_cnt = c;
+                                    best_umi = u;
+                                    best_idx = lo;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (best_idx != k) {
+                    target = (uint32_t)best_idx;
+                    atomicAdd(&inc1[best_idx], 1u);          // phase 1 moves one read (mark_dups.rs:228-232)
+                    atomicAdd(&inc_all[best_idx], my_cnt);   // phases 1+2 move them all (:242-246)
+                }
+            }
+        }
+        corr[k] = target;
+    }
+}
+
+// Representative-read bookkeeping (mark_dups.rs:248-268): for a corrected key K the representative
+// is the min-(utype, qname) read of the lexicographically smallest raw UMI R corrected onto K with
+// (R < K or K itself corrected away).  Only its UmiType survives into the UmiCount, so keep
+// min over such R of (R << 1 | min utype bit of R).
+__global__ __launch_bounds__(256) void k_rep_utype(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
+                                                   const uint32_t *__restrict__ corr,
+                                                   unsigned long long *__restrict__ minraw) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t umi_mask = lowmask(kl.bits_umi);
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
+        const uint32_t t = corr[k];
+        if (t == NONE32) continue;
+        const uint64_t raw = (ukey[k] >> kl.sh_umi) & umi_mask, tgt = (ukey[t] >> kl.sh_umi) & umi_mask;
+        if (raw < tgt || corr[t] != NONE32) atomicMin(&minraw[t], (unsigned long long)((raw << 1) | (ukey[k] & 1ull)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// low-support filter (determine_low_support_umigenes, mark_dups.rs:87-108)
+// ------------------------------------------------------------------------------------------------
+// secondary key [barcode][library][UMI][feature] so that all features of one (barcode, library, UMI)
+// are adjacent; payload = index of the distinct key.
+__global__ __launch_bounds__(256) void k_secondary_keys(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
+                                                        uint64_t *__restrict__ key2, uint32_t *__restrict__ val) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
+        const uint64_t key = ukey[k];
+        const uint64_t umi = (key >> kl.sh_umi) & lowmask(kl.bits_umi);
+        const uint64_t lib = (key >> kl.sh_lib) & lowmask(kl.bits_lib);
+        const uint64_t feat = (key >> kl.sh_feat) & lowmask(kl.bits_feat);
+        const uint64_t bc = key >> kl.sh_bc;
+        key2[k] = (((bc << kl.bits_lib | lib) << kl.bits_umi | umi) << kl.bits_feat) | feat;
+        val[k] = (uint32_t)k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint64_t *__restrict__ key2,
+                                                     const uint32_t *__restrict__ val, uint64_t nd,
+                                                     const uint32_t *__restrict__ upos, uint64_t n_keys,
+                                                     const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc1,
+                                                     uint8_t *__restrict__ low) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nd; j += stride) {
+        const uint64_t pre = key2[j] >> kl.bits_feat;
+        // only the first element of a group does the work; groups are almost always singletons
+        if (j > 0 && (key2[j - 1] >> kl.bits_feat) == pre) continue;
+        uint64_t e = j + 1;
+        while (e < nd && (key2[e] >> kl.bits_feat) == pre) e++;
+        if (e - j < 2) continue;  // a single (umi, feature): it is its own strict maximum, never low support
+        // counts after moving ONE read of each corrected key (mark_dups.rs:226-232); zero-count keys stay
+        uint32_t mx = 0;
+        for (uint64_t t = j; t < e; t++) {
+            const uint32_t k = val[t];
+            const uint32_t c1 = run_count(upos, nd, n_keys, k) - (corr[k] != NONE32 ? 1u : 0u) + inc1[k];
+            mx = c1 > mx ? c1 : mx;
+        }
+        uint32_t n_max = 0;
+        for (uint64_t t = j; t < e; t++) {
+            const uint32_t k = val[t];
+            const uint32_t c1 = run_count(upos, nd, n_keys, k) - (corr[k] != NONE32 ? 1u : 0u) + inc1[k];
+            n_max += c1 == mx ? 1u : 0u;
+        }
+        const bool tied = n_max >= 2;
+        for (uint64_t t = j; t < e; t++) {
+            const uint32_t k = val[t];
+            const uint32_t c1 = run_count(upos, nd, n_keys, k) - (corr[k] != NONE32 ? 1u : 0u) + inc1[k];
+            if (tied || c1 < mx) low[k] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_triplets(const KL kl, const uint64_t *__restrict__ mkeys,
+                                                  const uint32_t *__restrict__ tpos, uint64_t nt, uint64_t nm,
+                                                  uint32_t *__restrict__ bc, uint32_t *__restrict__ feat,
+                                                  uint32_t *__restrict__ cnt) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += stride) {
+        const uint32_t p = tpos[t];
+        const uint32_t end = t + 1 < nt ? tpos[t + 1] : (uint32_t)nm;
+        const uint64_t key = mkeys[p];
+        bc[t] = (uint32_t)(key >> kl.sh_bc);
+        feat[t] = (uint32_t)((key >> kl.sh_feat) & lowmask(kl.bits_feat));
+        cnt[t] = end - p;  // number of surviving molecules of (barcode, feature): types.rs:180-188
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// driver
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    template <typename T>
+    T *as() { return (T *)p; }
+};
+
+static int dmalloc(crgpu_ctx *ctx, DevBuf &b, uint64_t bytes) {
+    hipError_t e = hipMalloc(&b.p, bytes ? bytes : 8);
+    if (e != hipSuccess) return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return CRGPU_OK;
+}
+
+static int read_u32(crgpu_ctx *ctx, const uint32_t *d, uint32_t *h) {
+    return crgpu_memcpy_d2h(ctx, h, d, sizeof(uint32_t));
+}
+
+extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    *out = nullptr;
+    CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_count_keys: call crgpu_set_key_layout first");
+    CR_REQUIRE(ctx, n_keys < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_count_keys: at most 2^32-2 keys per call");
+    const KeyLayout &L = ctx->layout;
+    const KL kl = make_kl(L);
+    crgpu_counts *res = new (std::nothrow) crgpu_counts();
+    if (!res) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
+    res->layout = L;
+    if (n_keys == 0) {
+        *out = res;
+        return CRGPU_OK;
+    }
+    CR_REQUIRE(ctx, d_keys_inout, CRGPU_EINVAL, "crgpu_count_keys: NULL keys");
+    struct Guard {
+        crgpu_ctx *c;
+        crgpu_counts *r;
+        bool armed = true;
+        ~Guard() {
+            if (armed) crgpu_counts_free(c, r);
+        }
+    } guard{ctx, res};
+
+    uint32_t *d_block = ctx->d_sort_hist;      // 4096 u32 block counters of the compactions
+    uint32_t *d_total = ctx->d_scalars + 16;   // device-side totals
+
+    // 1. sort the keys
+    DevBuf tmp;
+    CR_TRY(dmalloc(ctx, tmp, n_keys * sizeof(uint64_t)));
+    bool in_tmp = false;
+    {
+        CrTimer t(ctx, CRGPU_T_SORT);
+        CR_TRY(cr_radix_sort_u64(ctx, d_keys_inout, tmp.as<uint64_t>(), nullptr, nullptr, n_keys, 0, L.total_bits(), &in_tmp));
+    }
+    const uint64_t *keys = in_tmp ? tmp.as<uint64_t>() : d_keys_inout;
+
+    // 2. distinct (barcode, feature, library, UMI) keys and their run starts (DupBuilder::observe)
+    DevBuf ukey_b, upos_b;
+    CR_TRY(dmalloc(ctx, ukey_b, n_keys * sizeof(uint64_t)));
+    CR_TRY(dmalloc(ctx, upos_b, (n_keys + 1) * sizeof(uint32_t)));
+    uint64_t *ukey = ukey_b.as<uint64_t>();
+    uint32_t *upos = upos_b.as<uint32_t>();
+    uint32_t nd32 = 0;
+    {
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        CR_TRY(compact(ctx, HeadFlag{keys, 1u}, EmitRun{keys, ukey, upos}, n_keys, d_block, d_total));
+    }
+    CR_TRY(read_u32(ctx, d_total, &nd32));
+    const uint64_t nd = nd32;
+
+    // 3. UMI correction + the read moves
+    DevBuf corr_b, inc1_b, incall_b, low_b, minraw_b;
+    CR_TRY(dmalloc(ctx, minraw_b, nd * sizeof(unsigned long long)));
+    CR_TRY(dmalloc(ctx, corr_b, nd * sizeof(uint32_t)));
+    CR_TRY(dmalloc(ctx, inc1_b, nd * sizeof(uint32_t)));
+    CR_TRY(dmalloc(ctx, incall_b, nd * sizeof(uint32_t)));
+    CR_TRY(dmalloc(ctx, low_b, nd));
+    uint32_t *corr = corr_b.as<uint32_t>(), *inc1 = inc1_b.as<uint32_t>(), *inc_all = incall_b.as<uint32_t>();
+    uint8_t *low = low_b.as<uint8_t>();
+    {
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        CR_HIP(ctx, hipMemsetAsync(inc1, 0, nd * sizeof(uint32_t), ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(inc_all, 0, nd * sizeof(uint32_t), ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(low, 0, nd, ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(minraw_b.p, 0xFF, nd * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_correct_umis, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, corr,
+                           inc1, inc_all);
+        hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd, corr,
+                           minraw_b.as<unsigned long long>());
+        CR_HIP(ctx, hipGetLastError());
+    }
+
+    // 4. low support: group the distinct keys by (barcode, library, UMI)
+    {
+        DevBuf k2_b, k2t_b, v_b, vt_b;
+        CR_TRY(dmalloc(ctx, k2_b, nd * sizeof(uint64_t)));
+        CR_TRY(dmalloc(ctx, k2t_b, nd * sizeof(uint64_t)));
+        CR_TRY(dmalloc(ctx, v_b, nd * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, vt_b, nd * sizeof(uint32_t)));
+        {
+            CrTimer t(ctx, CRGPU_T_DEDUP);
+            hipLaunchKernelGGL(k_secondary_keys, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd,
+                               k2_b.as<uint64_t>(), v_b.as<uint32_t>());
+            CR_HIP(ctx, hipGetLastError());
+        }
+        bool s_in_tmp = false;
+        {
+            CrTimer t(ctx, CRGPU_T_SORT);
+            CR_TRY(cr_radix_sort_u64(ctx, k2_b.as<uint64_t>(), k2t_b.as<uint64_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(),
+                                     nd, 0, L.total_bits() - 1, &s_in_tmp));
+        }
+        {
+            CrTimer t(ctx, CRGPU_T_DEDUP);
+            hipLaunchKernelGGL(k_low_support, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl,
+                               s_in_tmp ? k2t_b.as<uint64_t>() : k2_b.as<uint64_t>(),
+                               s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), nd, upos, n_keys, corr, inc1, low);
+            CR_HIP(ctx, hipGetLastError());
+        }
+        CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // buffers of this scope are freed below
+    }
+
+    // 5. molecules = distinct keys some read lands on and that are not low support
+    DevBuf mkeys_b, mreads_b;
+    CR_TRY(dmalloc(ctx, mkeys_b, nd * sizeof(uint64_t)));
+    CR_TRY(dmalloc(ctx, mreads_b, nd * sizeof(uint32_t)));
+    uint32_t nm32 = 0;
+    {
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        CR_TRY(compact(ctx, MolFlag{corr, inc1, low},
+                       EmitMol{ukey, upos, corr, inc_all, minraw_b.as<unsigned long long>(), n_keys, nd, mkeys_b.as<uint64_t>(),
+                               mreads_b.as<uint32_t>()}, nd,
+                       d_block, d_total));
+    }
+    CR_TRY(read_u32(ctx, d_total, &nm32));
+    const uint64_t nm = nm32;
+
+    // 6. (barcode, feature) triplets = run lengths of the molecule keys at the feature boundary
+    DevBuf tpos_b;
+    CR_TRY(dmalloc(ctx, tpos_b, (nm + 1) * sizeof(uint32_t)));
+    uint32_t nt32 = 0;
+    if (nm) {
+        {
+            CrTimer t(ctx, CRGPU_T_DEDUP);
+            CR_TRY(compact(ctx, HeadFlag{mkeys_b.as<uint64_t>(), L.sh_feat()}, EmitTriplet{mkeys_b.as<uint64_t>(), tpos_b.as<uint32_t>()},
+                           nm, d_block, d_total));
+        }
+        CR_TRY(read_u32(ctx, d_total, &nt32));
+    }
+    const uint64_t nt = nt32;
+    CR_HIP(ctx, hipMalloc((void **)&res->d_bc, (nt ? nt : 1) * sizeof(uint32_t)));
+    CR_HIP(ctx, hipMalloc((void **)&res->d_feature, (nt ? nt : 1) * sizeof(uint32_t)));
+    CR_HIP(ctx, hipMalloc((void **)&res->d_count, (nt ? nt : 1) * sizeof(uint32_t)));
+    if (nt) {
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        hipLaunchKernelGGL(k_triplets, dim3(cr_grid(nt, 256)), dim3(256), 0, ctx->stream, kl, mkeys_b.as<uint64_t>(),
+                           tpos_b.as<uint32_t>(), nt, nm, res->d_bc, res->d_feature, res->d_count);
+        CR_HIP(ctx, hipGetLastError());
+    }
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    res->n_triplets = nt;
+    res->n_molecules = nm;
+    res->d_mkeys = (uint64_t *)mkeys_b.p;
+    res->d_mreads = (uint32_t *)mreads_b.p;
+    mkeys_b.p = nullptr;
+    mreads_b.p = nullptr;
+    guard.armed = false;
+    *out = res;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_counts_info(crgpu_ctx *ctx, const crgpu_counts *c, uint64_t *n_triplets, uint64_t *n_molecules) {
+    if (!ctx || !c) return CRGPU_EINVAL;
+    if (n_triplets) *n_triplets = c->n_triplets;
+    if (n_molecules) *n_molecules = c->n_molecules;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_counts_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t **d_bc, uint32_t **d_feature,
+                                         uint32_t **d_count) {
+    if (!ctx || !c) return CRGPU_EINVAL;
+    if (d_bc) *d_bc = c->d_bc;
+    if (d_feature) *d_feature = c->d_feature;
+    if (d_count) *d_count = c->d_count;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_counts_triplets(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint32_t *feature_out,
+                                     uint32_t *count_out) {
+    if (!ctx || !c) return CRGPU_EINVAL;
+    const uint64_t b = c->n_triplets * sizeof(uint32_t);
+    if (bc_out) CR_TRY(crgpu_memcpy_d2h(ctx, bc_out, c->d_bc, b));
+    if (feature_out) CR_TRY(crgpu_memcpy_d2h(ctx, feature_out, c->d_feature, b));
+    if (count_out) CR_TRY(crgpu_memcpy_d2h(ctx, count_out, c->d_count, b));
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint8_t *lib_out,
+                                      uint32_t *feature_out, uint32_t *umi_out, uint32_t *read_count_out,
+                                      uint8_t *utype_out) {
+    if (!ctx || !c) return CRGPU_EINVAL;
+    const uint64_t nm = c->n_molecules;
+    if (!nm) return CRGPU_OK;
+    std::vector<uint64_t> keys(nm);
+    std::vector<uint32_t> reads(nm);
+    CR_TRY(crgpu_memcpy_d2h(ctx, keys.data(), c->d_mkeys, nm * sizeof(uint64_t)));
+    CR_TRY(crgpu_memcpy_d2h(ctx, reads.data(), c->d_mreads, nm * sizeof(uint32_t)));
+    const KeyLayout &L = c->layout;
+    // align_and_count.rs:314 sorts a barcode's UmiCounts by (library_idx, feature_idx, umi, ...):
+    // the device order is (barcode, feature, library, umi); reorder inside each barcode.
+    std::vector<uint32_t> order(nm);
+    for (uint64_t i = 0; i < nm; i++) order[i] = (uint32_t)i;
+    auto fld = [&](uint64_t k, uint32_t sh, uint32_t bits) { return (uint32_t)((k >> sh) & (bits >= 64 ? ~0ull : ((1ull << bits) - 1))); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const uint64_t ka = keys[a], kb = keys[b];
+        const uint32_t bca = (uint32_t)(ka >> L.sh_bc()), bcb = (uint32_t)(kb >> L.sh_bc());
+        if (bca != bcb) return bca < bcb;
+        const uint32_t la = fld(ka, L.sh_lib(), L.bits_lib), lb = fld(kb, L.sh_lib(), L.bits_lib);
+        if (la != lb) return la < lb;
+        const uint32_t fa = fld(ka, L.sh_feat(), L.bits_feat), fb = fld(kb, L.sh_feat(), L.bits_feat);
+        if (fa != fb) return fa < fb;
+        return fld(ka, L.sh_umi(), L.bits_umi) < fld(kb, L.sh_umi(), L.bits_umi);
+    });
+    for (uint64_t o = 0; o < nm; o++) {
+        const uint64_t k = keys[order[o]];
+        if (bc_out) bc_out[o] = (uint32_t)(k >> L.sh_bc());
+        if (lib_out) lib_out[o] = (uint8_t)fld(k, L.sh_lib(), L.bits_lib);
+        if (feature_out) feature_out[o] = fld(k, L.sh_feat(), L.bits_feat);
+        if (umi_out) umi_out[o] = fld(k, L.sh_umi(), L.bits_umi);
+        if (read_count_out) read_count_out[o] = reads[order[o]];
+        if (utype_out) utype_out[o] = (uint8_t)(k & 1ull);
+    }
+    return CRGPU_OK;
+}
+
+extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
+    if (!c) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(c->d_bc);
+    (void)hipFree(c->d_feature);
+    (void)hipFree(c->d_count);
+    (void)hipFree(c->d_mkeys);
+    (void)hipFree(c->d_mreads);
+    delete c;
+}

@@ -1,0 +1,154 @@
+// matrix.hip -- barcode index, CSC assembly and Matrix Market text (host side of the boundary).
+//
+// Replaces BarcodeIndex::new / from_iter (cr_types/src/barcode_index.rs:20-53),
+// write_matrix_h5_helper's CSC construction (cr_h5/src/count_matrix.rs:382-448) and
+// write_matrix_mtx (cr_lib/src/stages/write_matrix_market.rs:80-122).  The .h5 container itself
+// stays with the unchanged Rust host (no HDF5 library in this image): it receives exactly the
+// arrays it writes today (data i32, indices -> i64 on disk, indptr i64, barcodes, shape).
+#include <algorithm>
+#include <cstdio>
+
+#include "common.h"
+
+struct MatrixImpl {
+    crgpu_matrix view;
+    std::vector<uint32_t> rank, seq;
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> indices, data;
+};
+
+extern "C" int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const uint32_t *feature, const uint32_t *count,
+                                     uint64_t n_triplets, uint32_t n_features, crgpu_matrix **out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    *out = nullptr;
+    CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_assemble_matrix: no whitelist set");
+    CR_REQUIRE(ctx, n_triplets == 0 || (bc && feature && count), CRGPU_EINVAL, "crgpu_assemble_matrix: NULL triplets");
+    const uint32_t W = ctx->n_canon;
+
+    // BarcodeIndex: sorted, dedup'd union over libraries of the barcodes in corrected_barcode_counts
+    // (= valid counts merged with corrected counts, barcode_correction.rs:401-407)
+    std::vector<uint8_t> seen(W, 0);
+    std::vector<uint32_t> tmp(W);
+    for (int l = 0; l < CRGPU_MAX_LIB; l++) {
+        if (!ctx->wl[l].set) continue;
+        for (int which = 0; which < 2; which++) {
+            CR_TRY(crgpu_memcpy_d2h(ctx, tmp.data(), which ? ctx->wl[l].d_corrected : ctx->wl[l].d_valid, sizeof(uint32_t) * W));
+            for (uint32_t r = 0; r < W; r++) seen[r] |= tmp[r] != 0;
+        }
+    }
+    MatrixImpl *m = new (std::nothrow) MatrixImpl();
+    if (!m) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
+    std::vector<uint32_t> col_of_rank(W, 0xFFFFFFFFu);
+    for (uint32_t r = 0; r < W; r++)
+        if (seen[r]) {
+            col_of_rank[r] = (uint32_t)m->rank.size();
+            m->rank.push_back(r);
+            m->seq.push_back(ctx->canon_sorted[r]);
+        }
+    const uint64_t V = m->rank.size();
+
+    // FeatureBarcodeCount stream in BarcodeThenFeatureOrder (types.rs:121-137)
+    std::vector<uint64_t> order(n_triplets);
+    for (uint64_t i = 0; i < n_triplets; i++) order[i] = i;
+    bool sorted = true;
+    for (uint64_t i = 1; i < n_triplets && sorted; i++)
+        sorted = bc[i - 1] < bc[i] || (bc[i - 1] == bc[i] && feature[i - 1] <= feature[i]);
+    if (!sorted)
+        std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+            return bc[a] != bc[b] ? bc[a] < bc[b] : feature[a] < feature[b];
+        });
+
+    std::vector<int64_t> percol(V, 0);
+    m->indices.reserve(n_triplets);
+    m->data.reserve(n_triplets);
+    for (uint64_t i = 0; i < n_triplets;) {
+        const uint64_t a = order[i];
+        if (bc[a] >= W || col_of_rank[bc[a]] == 0xFFFFFFFFu || feature[a] >= n_features) {
+            delete m;
+            return cr_fail(ctx, CRGPU_EINVAL,
+                           "triplet %llu (barcode rank %u, feature %u) is outside the barcode index / feature space",
+                           (unsigned long long)a, bc[a], feature[a]);
+        }
+        // count_matrix.rs:409-414: entries with equal (barcode, feature) are summed
+        uint64_t j = i;
+        uint64_t sum = 0;
+        while (j < n_triplets && bc[order[j]] == bc[a] && feature[order[j]] == feature[a]) sum += count[order[j++]];
+        m->indices.push_back((int32_t)feature[a]);
+        m->data.push_back((int32_t)sum);
+        percol[col_of_rank[bc[a]]] += 1;
+        i = j;
+    }
+    m->indptr.resize(V + 1);
+    m->indptr[0] = 0;
+    for (uint64_t c = 0; c < V; c++) m->indptr[c + 1] = m->indptr[c] + percol[c];
+
+    m->view.n_barcodes = V;
+    m->view.nnz = m->data.size();
+    m->view.n_features = n_features;
+    m->view.cb_len = ctx->cb_len;
+    m->view.barcode_rank = m->rank.data();
+    m->view.barcode_seq = m->seq.data();
+    m->view.indptr = m->indptr.data();
+    m->view.indices = m->indices.data();
+    m->view.data = m->data.data();
+    *out = &m->view;
+    return CRGPU_OK;
+}
+
+extern "C" void crgpu_matrix_free(crgpu_ctx *, crgpu_matrix *mv) {
+    if (!mv) return;
+    delete reinterpret_cast<MatrixImpl *>(mv);  // view is the first member
+}
+
+extern "C" int crgpu_write_mtx(crgpu_ctx *ctx, const crgpu_matrix *m, const char *metadata_line, const char *mtx_path,
+                               const char *barcodes_tsv_path, uint16_t gem_group) {
+    if (!ctx || !m) return CRGPU_EINVAL;
+    if (mtx_path) {
+        FILE *f = fopen(mtx_path, "wb");
+        if (!f) return cr_fail(ctx, CRGPU_EINVAL, "cannot open %s", mtx_path);
+        // write_matrix_market.rs:96-118 (the reference gzips exactly this text)
+        fprintf(f, "%%%%MatrixMarket matrix coordinate integer general\n");
+        fprintf(f, "%s\n", metadata_line ? metadata_line : "%metadata_json: {}");
+        fprintf(f, "%u %llu %llu\n", m->n_features, (unsigned long long)m->n_barcodes, (unsigned long long)m->nnz);
+        for (uint64_t c = 0; c < m->n_barcodes; c++)
+            for (int64_t k = m->indptr[c]; k < m->indptr[c + 1]; k++)
+                fprintf(f, "%d %llu %d\n", 1 + m->indices[k], (unsigned long long)(1 + c), m->data[k]);
+        fclose(f);
+    }
+    if (barcodes_tsv_path) {
+        FILE *f = fopen(barcodes_tsv_path, "wb");
+        if (!f) return cr_fail(ctx, CRGPU_EINVAL, "cannot open %s", barcodes_tsv_path);
+        static const char acgt[4] = {'A', 'C', 'G', 'T'};
+        char buf[32];
+        for (uint64_t c = 0; c < m->n_barcodes; c++) {
+            for (uint32_t p = 0; p < m->cb_len; p++) buf[p] = acgt[(m->barcode_seq[c] >> (2 * (m->cb_len - 1 - p))) & 3u];
+            buf[m->cb_len] = 0;
+            fprintf(f, "%s-%u\n", buf, (unsigned)gem_group);  // Barcode Display: "{content}-{gem_group}" (barcode/src/lib.rs:197-201)
+        }
+        fclose(f);
+    }
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_count(crgpu_ctx *ctx, const crgpu_records *recs, uint32_t n_features, crgpu_matrix **out) {
+    if (!ctx || !recs || !out) return CRGPU_EINVAL;
+    *out = nullptr;
+    CR_REQUIRE(ctx, ctx->layout.set && ctx->layout.n_features == n_features, CRGPU_ESTATE,
+               "crgpu_count: call crgpu_set_key_layout with the same n_features first");
+    uint64_t *d_keys = nullptr;
+    CR_HIP(ctx, hipMalloc((void **)&d_keys, (recs->n ? recs->n : 1) * sizeof(uint64_t)));
+    uint64_t n_keys = 0;
+    crgpu_counts *c = nullptr;
+    int rc = crgpu_build_keys_dev(ctx, recs, d_keys, &n_keys);
+    if (rc == CRGPU_OK) rc = crgpu_count_keys_dev(ctx, d_keys, n_keys, &c);
+    (void)hipFree(d_keys);
+    if (rc != CRGPU_OK) return rc;
+    uint64_t nt = 0;
+    crgpu_counts_info(ctx, c, &nt, nullptr);
+    std::vector<uint32_t> bc(nt), ft(nt), ct(nt);
+    rc = crgpu_counts_triplets(ctx, c, bc.data(), ft.data(), ct.data());
+    crgpu_counts_free(ctx, c);
+    if (rc != CRGPU_OK) return rc;
+    CrTimer t(ctx, CRGPU_T_MATRIX);
+    return crgpu_assemble_matrix(ctx, bc.data(), ft.data(), ct.data(), nt, n_features, out);
+}

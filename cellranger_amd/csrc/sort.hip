@@ -1,0 +1,246 @@
+// sort.hip -- LSD radix sort of 64-bit molecule keys (optionally with a 32-bit payload) built on
+// wave64 ballot multisplit, plus the small device-wide scan used by the sort and the compactions.
+//
+// This is the "sort" the reference gets from shardio's sorted shards + std HashMap grouping
+// (cr_lib/src/barcode_sort.rs:97-162, par_proc.rs:131-152); integer work, HBM bound: every pass
+// streams the keys once for the digit histogram and once for the scatter.
+#include "common.h"
+
+#define SORT_BLOCK 256
+#define SORT_ITEMS 8                      // keys per thread per chunk
+#define SORT_CHUNK (SORT_BLOCK * SORT_ITEMS)
+#define SORT_WAVES (SORT_BLOCK / 64)
+#define RADIX_BITS 8
+#define RADIX 256
+
+// ---- exclusive scan of a small u32 array (block histograms / block counts), single workgroup ----
+__global__ __launch_bounds__(1024) void k_scan_small(uint32_t *__restrict__ data, uint64_t n,
+                                                     uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t lo = (uint64_t)tid * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint64_t i = lo; i < hi; i++) sum += data[i];
+    // inclusive scan of `sum` across the block
+    uint32_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wave_sums[wave] = x;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0;
+        for (int w = 0; w < 16; w++) {
+            const uint32_t t = wave_sums[w];
+            wave_sums[w] = c;
+            c += t;
+        }
+        carry_s = c;
+    }
+    __syncthreads();
+    uint32_t run = wave_sums[wave] + x - sum;  // exclusive prefix of this thread's segment
+    for (uint64_t i = lo; i < hi; i++) {
+        const uint32_t v = data[i];
+        data[i] = run;
+        run += v;
+    }
+    if (tid == 0 && total_out) *total_out = carry_s;
+}
+
+int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_total_out) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, d_data, n, d_total_out);
+    CR_HIP(ctx, hipGetLastError());
+    return CRGPU_OK;
+}
+
+// ---- digit extraction -------------------------------------------------------------------------
+// mode 0: (key >> shift) & mask           (radix pass)
+// mode 1: ((key >> shift) % mod)           (owner rank of the barcode, crgpu_partition_keys_dev)
+struct DigitFn {
+    uint32_t shift, mask, mod, mode;
+    __device__ __forceinline__ uint32_t operator()(uint64_t key) const {
+        const uint64_t v = key >> shift;
+        return mode == 0 ? (uint32_t)(v & mask) : (uint32_t)(v % mod);
+    }
+};
+
+// ---- pass 1: per-block digit histogram ------------------------------------------------------------
+__global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(const uint64_t *__restrict__ keys, uint64_t n,
+                                                           uint64_t tile, DigitFn dig, uint32_t *__restrict__ block_hist,
+                                                           uint32_t n_blocks) {
+    __shared__ uint32_t h[RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = lo + tile < n ? lo + tile : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) atomicAdd(&h[dig(keys[i])], 1u);
+    __syncthreads();
+    block_hist[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// ---- pass 2: stable scatter ------------------------------------------------------------------------
+// Order inside a chunk: wave-major, then item, then lane, so a wave owns 64*SORT_ITEMS consecutive
+// keys.  Rank of a key = block_base[d] + (same-digit keys of earlier waves) + (same-digit keys of this
+// wave's earlier items) + (same-digit lanes below it), all from ballots and LDS counters.
+template <bool HAS_VALS>
+__global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const uint64_t *__restrict__ keys_in,
+                                                              uint64_t *__restrict__ keys_out,
+                                                              const uint32_t *__restrict__ vals_in,
+                                                              uint32_t *__restrict__ vals_out, uint64_t n, uint64_t tile,
+                                                              DigitFn dig, const uint32_t *__restrict__ block_offs,
+                                                              uint32_t n_blocks) {
+    __shared__ uint32_t wcount[SORT_WAVES][RADIX];  // per-wave same-digit counts of the chunk
+    __shared__ uint32_t base[RADIX];                // running output offset of each digit for this block
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    base[tid] = block_offs[(uint64_t)tid * n_blocks + blockIdx.x];
+    const uint64_t lo = (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = lo + tile < n ? lo + tile : n;
+
+    for (uint64_t chunk = lo; chunk < hi; chunk += SORT_CHUNK) {
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; w++) wcount[w][tid] = 0;
+        __syncthreads();
+
+        uint64_t key[SORT_ITEMS];
+        uint32_t val[SORT_ITEMS];
+        uint32_t digit[SORT_ITEMS];
+        uint32_t rank[SORT_ITEMS];  // rank inside (wave, digit)
+        const uint64_t wave_base = chunk + (uint64_t)wave * (64 * SORT_ITEMS);
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; it++) {
+            const uint64_t i = wave_base + (uint64_t)it * 64 + lane;
+            const bool ok = i < hi;
+            key[it] = ok ? keys_in[i] : 0ull;
+            if (HAS_VALS) val[it] = ok ? vals_in[i] : 0u;
+            const uint32_t d = ok ? dig(key[it]) : 0u;
+            digit[it] = d;
+            // lanes holding the same digit: intersect the 8 bit ballots
+            unsigned long long peers = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < RADIX_BITS; b++) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            uint32_t prev = 0;
+            if (ok) {
+                const int leader = __ffsll((long long)peers) - 1;
+                if ((int)lane == leader) prev = atomicAdd(&wcount[wave][d], (uint32_t)__popcll(peers));
+                prev = __shfl(prev, leader);
+            }
+            rank[it] = prev + (uint32_t)__popcll(peers & lt_mask);
+        }
+        __syncthreads();
+        // one thread per digit: turn the per-wave counts into exclusive prefixes over waves and
+        // advance the block's running offset
+        {
+            uint32_t run = base[tid];
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; w++) {
+                const uint32_t c = wcount[w][tid];
+                wcount[w][tid] = run;
+                run += c;
+            }
+            base[tid] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; it++) {
+            const uint64_t i = wave_base + (uint64_t)it * 64 + lane;
+            if (i < hi) {
+                const uint32_t pos = wcount[wave][digit[it]] + rank[it];
+                keys_out[pos] = key[it];
+                if (HAS_VALS) vals_out[pos] = val[it];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static uint32_t sort_blocks(uint64_t n, uint64_t *tile_out) {
+    uint64_t nb = (n + SORT_CHUNK * 4 - 1) / (SORT_CHUNK * 4);
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    uint64_t tile = (n + nb - 1) / nb;
+    tile = (tile + SORT_CHUNK - 1) / SORT_CHUNK * SORT_CHUNK;
+    nb = (n + tile - 1) / tile;
+    if (nb < 1) nb = 1;
+    *tile_out = tile;
+    return (uint32_t)nb;
+}
+
+// one counting-sort pass keyed by `dig` (stable).  d_hist: RADIX * n_blocks u32 workspace.
+static int radix_pass(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, const uint32_t *d_vin, uint32_t *d_vout,
+                      uint64_t n, DigitFn dig, uint32_t *d_hist) {
+    uint64_t tile;
+    const uint32_t nb = sort_blocks(n, &tile);
+    hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
+    CR_TRY(cr_scan_small(ctx, d_hist, (uint64_t)RADIX * nb, nullptr));
+    if (d_vin)
+        hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout, n,
+                           tile, dig, d_hist, nb);
+    else
+        hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout, n,
+                           tile, dig, d_hist, nb);
+    CR_HIP(ctx, hipGetLastError());
+    return CRGPU_OK;
+}
+
+// Sort d_keys[0..n) ascending on bits [lo_bit, hi_bit).  d_tmp (n keys) and, when d_vals != NULL,
+// d_vals_tmp (n u32) are ping-pong buffers; *result_in_tmp tells where the sorted data ended up.
+int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
+                      uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
+    *result_in_tmp = false;
+    if (n <= 1 || hi_bit <= lo_bit) return CRGPU_OK;
+    CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "sort: at most 2^32-2 keys per call");
+    uint32_t *d_hist = ctx->d_sort_hist;
+    uint64_t *in = d_keys, *out = d_tmp;
+    uint32_t *vin = d_vals, *vout = d_vals_tmp;
+    int rc = CRGPU_OK;
+    for (uint32_t shift = lo_bit; shift < hi_bit && rc == CRGPU_OK; shift += RADIX_BITS) {
+        const uint32_t bits = hi_bit - shift < RADIX_BITS ? hi_bit - shift : RADIX_BITS;
+        DigitFn dig{shift, (1u << bits) - 1u, 1u, 0u};
+        rc = radix_pass(ctx, in, out, vin, vout, n, dig, d_hist);
+        uint64_t *t = in;
+        in = out;
+        out = t;
+        uint32_t *tv = vin;
+        vin = vout;
+        vout = tv;
+        *result_in_tmp = !*result_in_tmp;
+    }
+    return rc;
+}
+
+// Stable partition of keys by owner rank of their barcode (bc % n_ranks): one counting-sort pass.
+int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
+                          uint32_t n_ranks, uint64_t *counts_out) {
+    CR_REQUIRE(ctx, n_ranks >= 1 && n_ranks <= RADIX, CRGPU_EINVAL, "partition: n_ranks must be 1..256");
+    CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "partition: at most 2^32-2 keys per call");
+    for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = 0;
+    if (n == 0) return CRGPU_OK;
+    uint64_t tile;
+    const uint32_t nb = sort_blocks(n, &tile);
+    uint32_t *d_hist = ctx->d_sort_hist;
+    DigitFn dig{sh_bc, 0u, n_ranks, 1u};
+    int rc = radix_pass(ctx, d_in, d_out, nullptr, nullptr, n, dig, d_hist);
+    // after the scan d_hist[d*nb + 0] is the start of digit d: counts = differences
+    std::vector<uint32_t> starts(RADIX);
+    if (rc == CRGPU_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        for (uint32_t d = 0; d < RADIX && e == hipSuccess; d++)
+            e = hipMemcpy(&starts[d], d_hist + (uint64_t)d * nb, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "partition: %s", hipGetErrorString(e));
+    }
+    if (rc != CRGPU_OK) return rc;
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        const uint64_t end = r + 1 < RADIX ? starts[r + 1] : n;
+        counts_out[r] = (r + 1 < n_ranks ? end : n) - starts[r];
+    }
+    return CRGPU_OK;
+}

@@ -1,0 +1,389 @@
+"""Thin Python host over the C ABI (include/crgpu.h): device buffers + one method per entry point.
+
+The product path: every method ends in a libcrgpu call; there is no CPU implementation behind
+any of them (a missing library / GPU raises CrgpuError).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (COUNTS_CORRECTED, COUNTS_PRIOR, COUNTS_VALID, MISS, NO_FEATURE, CrgpuError, MatrixView,
+                   Records, SynthOut, SynthParams, ptr)
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def pack_seqs(seqs, length=None):
+    """list of str/bytes or (n, len) uint8 ASCII array -> (packed uint32[n], len).  ACGT only."""
+    a = ascii_matrix(seqs, length)
+    n, L = a.shape
+    if L > 16:
+        raise ValueError("sequences longer than 16 bases do not fit 32 bits")
+    code = np.full(256, 255, dtype=np.uint8)
+    code[_ACGT] = np.arange(4, dtype=np.uint8)
+    c = code[a]
+    if (c == 255).any():
+        raise ValueError("non-ACGT base")
+    out = np.zeros(n, dtype=np.uint32)
+    for j in range(L):
+        out = (out << np.uint32(2)) | c[:, j].astype(np.uint32)
+    return out, L
+
+
+def unpack_seqs(packed, length):
+    packed = np.asarray(packed, dtype=np.uint32)
+    out = np.zeros((len(packed), length), dtype=np.uint8)
+    for j in range(length):
+        out[:, j] = _ACGT[(packed >> np.uint32(2 * (length - 1 - j))) & np.uint32(3)]
+    return out
+
+
+def ascii_matrix(seqs, length=None):
+    if isinstance(seqs, np.ndarray) and seqs.dtype == np.uint8 and seqs.ndim == 2:
+        return np.ascontiguousarray(seqs)
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    if length is None:
+        length = len(bs[0]) if bs else 0
+    if any(len(b) != length for b in bs):
+        raise ValueError("sequences must all have length %d" % length)
+    return np.frombuffer(b"".join(bs), dtype=np.uint8).reshape(len(bs), length).copy()
+
+
+class DeviceArray:
+    """A device allocation owned through crgpu_malloc/crgpu_free."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        ctx._check(ctx.L.crgpu_malloc(ctx.h, C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def to_host(self, count=None):
+        n = self.size if count is None else int(count)
+        out = np.empty(n, dtype=self.dtype)
+        if n:
+            self.ctx._check(self.ctx.L.crgpu_memcpy_d2h(self.ctx.h, ptr(out), self.ptr, n * self.dtype.itemsize))
+        if count is None:
+            out = out.reshape(self.shape)
+        return out
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.nbytes <= self.nbytes
+        if a.nbytes:
+            self.ctx._check(self.ctx.L.crgpu_memcpy_h2d(self.ctx.h, self.ptr, ptr(a), a.nbytes))
+        return self
+
+    def zero(self):
+        self.ctx._check(self.ctx.L.crgpu_memset(self.ctx.h, self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr is not None and self.ctx.h:
+            self.ctx.L.crgpu_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def __cuda_array_interface__(self):
+        # lets torch.as_tensor(..., device="cuda") alias the buffer for collectives
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2}
+
+
+def _p(x):
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return C.c_void_p(x.ptr)
+    if hasattr(x, "data_ptr"):  # torch tensor
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+class Matrix:
+    """Host view of crgpu_matrix (the arrays write_matrix_h5 stores; count_matrix.rs:382-448)."""
+
+    def __init__(self, ctx, mv_ptr):
+        self.ctx, self._mv = ctx, mv_ptr
+        m = mv_ptr.contents
+        self.n_barcodes, self.nnz = int(m.n_barcodes), int(m.nnz)
+        self.n_features, self.cb_len = int(m.n_features), int(m.cb_len)
+
+        def arr(p, dtype, n):
+            if n == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer((C.c_char * (n * np.dtype(dtype).itemsize)).from_address(p), dtype=dtype).copy()
+
+        self.barcode_rank = arr(m.barcode_rank, np.uint32, self.n_barcodes)
+        self.barcode_seq = arr(m.barcode_seq, np.uint32, self.n_barcodes)
+        self.indptr = arr(m.indptr, np.int64, self.n_barcodes + 1)
+        self.indices = arr(m.indices, np.int32, self.nnz)
+        self.data = arr(m.data, np.int32, self.nnz)
+
+    def barcodes_ascii(self):
+        return unpack_seqs(self.barcode_seq, self.cb_len)
+
+    def write_mtx(self, mtx_path, barcodes_path=None, metadata_line='%metadata_json: {"format_version": 2}',
+                  gem_group=1):
+        self.ctx._check(self.ctx.L.crgpu_write_mtx(self.ctx.h, self._mv, metadata_line.encode(),
+                                                   None if mtx_path is None else str(mtx_path).encode(),
+                                                   None if barcodes_path is None else str(barcodes_path).encode(),
+                                                   gem_group))
+
+    def free(self):
+        if self._mv is not None and self.ctx.h:
+            self.ctx.L.crgpu_matrix_free(self.ctx.h, self._mv)
+        self._mv = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Counts:
+    """crgpu_counts: sorted (barcode, feature, count) triplets + the molecule table."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+        nt, nm = C.c_uint64(), C.c_uint64()
+        ctx._check(ctx.L.crgpu_counts_info(ctx.h, handle, C.byref(nt), C.byref(nm)))
+        self.n_triplets, self.n_molecules = nt.value, nm.value
+
+    def triplets(self):
+        n = self.n_triplets
+        bc, ft, ct = (np.zeros(n, np.uint32) for _ in range(3))
+        if n:
+            self.ctx._check(self.ctx.L.crgpu_counts_triplets(self.ctx.h, self.h, ptr(bc), ptr(ft), ptr(ct)))
+        return bc, ft, ct
+
+    def triplets_dev(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.ctx._check(self.ctx.L.crgpu_counts_triplets_dev(self.ctx.h, self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def molecules(self):
+        n = self.n_molecules
+        out = dict(bc=np.zeros(n, np.uint32), lib=np.zeros(n, np.uint8), feature=np.zeros(n, np.uint32),
+                   umi=np.zeros(n, np.uint32), read_count=np.zeros(n, np.uint32), utype=np.zeros(n, np.uint8))
+        if n:
+            self.ctx._check(self.ctx.L.crgpu_counts_molecules(self.ctx.h, self.h, ptr(out["bc"]), ptr(out["lib"]),
+                                                              ptr(out["feature"]), ptr(out["umi"]),
+                                                              ptr(out["read_count"]), ptr(out["utype"])))
+        return out
+
+    def free(self):
+        if self.h is not None and self.ctx.h:
+            self.ctx.L.crgpu_counts_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """crgpu_ctx: one per (process, device)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.crgpu_create(C.byref(h), device)
+        if rc != 0:
+            raise CrgpuError(rc, (self.L.crgpu_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+        self.cb_len = None
+        self.n_canon = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.crgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise CrgpuError(rc, (self.L.crgpu_last_error(self.h) or b"").decode())
+
+    # ---- memory -------------------------------------------------------------------------------
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        return DeviceArray(self, shape, dtype).zero()
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        return DeviceArray(self, a.shape, a.dtype).upload(a)
+
+    def synchronize(self):
+        self._check(self.L.crgpu_synchronize(self.h))
+
+    # ---- timing -------------------------------------------------------------------------------
+    def timing(self, on=True):
+        self._check(self.L.crgpu_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._check(self.L.crgpu_timing_reset(self.h))
+
+    def timing_get(self):
+        ms = np.zeros(len(_lib.T_NAMES), np.float64)
+        ln = np.zeros(len(_lib.T_NAMES), np.uint64)
+        self._check(self.L.crgpu_timing_get(self.h, ptr(ms), ptr(ln)))
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(_lib.T_NAMES)}
+
+    # ---- whitelist ------------------------------------------------------------------------------
+    def set_whitelist(self, lib, keys, canon=None, translate_to=None, length=None):
+        """keys/canon: list of str, ASCII matrix, or packed uint32 (then `length` is required)."""
+        def packed(x):
+            if isinstance(x, np.ndarray) and x.dtype == np.uint32:
+                return np.ascontiguousarray(x), length
+            return pack_seqs(x)
+        pk, L1 = packed(keys)
+        if canon is None:
+            pc, L2 = pk, L1
+        else:
+            pc, L2 = packed(canon)
+        assert L1 == L2 and L1 is not None
+        tt = None if translate_to is None else np.ascontiguousarray(translate_to, dtype=np.uint32)
+        self._check(self.L.crgpu_set_whitelist_packed(self.h, lib, ptr(pk), len(pk), L1, ptr(pc), len(pc), ptr(tt)))
+        self.cb_len, self.n_canon = L1, len(pc)
+
+    def set_whitelist_ascii(self, lib, keys, canon=None, translate_to=None):
+        k = ascii_matrix(keys)
+        c = k if canon is None else ascii_matrix(canon)
+        tt = None if translate_to is None else np.ascontiguousarray(translate_to, dtype=np.uint32)
+        self._check(self.L.crgpu_set_whitelist(self.h, lib, k.tobytes(), k.shape[0], k.shape[1], c.tobytes(),
+                                               c.shape[0], ptr(tt)))
+        self.cb_len, self.n_canon = k.shape[1], c.shape[0]
+
+    def canon_order(self):
+        order = np.zeros(self.n_canon, np.uint32)
+        seqs = np.zeros(self.n_canon, np.uint32)
+        self._check(self.L.crgpu_get_canon_order(self.h, ptr(order), ptr(seqs)))
+        return order, seqs
+
+    # ---- barcode stage ---------------------------------------------------------------------------
+    def pack(self, d_seq, d_qual, n, length, d_packed, d_qualn, d_flags=None):
+        self._check(self.L.crgpu_pack_dev(self.h, _p(d_seq), _p(d_qual), n, length, _p(d_packed), _p(d_qualn), _p(d_flags)))
+
+    def match_and_count(self, d_cb, d_flags, n, d_idx_out):
+        self._check(self.L.crgpu_match_and_count_dev(self.h, _p(d_cb), _p(d_flags), n, _p(d_idx_out)))
+
+    def set_posterior(self, max_expected_barcode_errors, bc_confidence_threshold):
+        self._check(self.L.crgpu_set_posterior(self.h, float(max_expected_barcode_errors), float(bc_confidence_threshold)))
+
+    def correct(self, d_cb, d_qualn, d_flags, n, d_idx_inout, d_corrected_out=None):
+        self._check(self.L.crgpu_correct_dev(self.h, _p(d_cb), _p(d_qualn), _p(d_flags), n, _p(d_idx_inout), _p(d_corrected_out)))
+
+    def get_counts(self, lib, which=COUNTS_VALID):
+        out = np.zeros(self.n_canon, np.uint32)
+        self._check(self.L.crgpu_get_counts(self.h, lib, which, ptr(out)))
+        return out
+
+    def set_counts(self, lib, which, counts):
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        assert len(c) == self.n_canon
+        self._check(self.L.crgpu_set_counts(self.h, lib, which, ptr(c)))
+
+    def reset_counts(self):
+        self._check(self.L.crgpu_reset_counts(self.h))
+
+    def counts_dev(self, lib, which):
+        p = C.c_void_p()
+        self._check(self.L.crgpu_counts_dev(self.h, lib, which, C.byref(p)))
+        return p.value
+
+    def match_and_count_host(self, lib, seq_ascii, qual):
+        s = ascii_matrix(seq_ascii)
+        q = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
+        idx = np.zeros(s.shape[0], np.uint32)
+        self._check(self.L.crgpu_match_and_count(self.h, lib, ptr(s), ptr(q), s.shape[0], ptr(idx)))
+        return idx
+
+    def correct_host(self, lib, seq_ascii, qual, idx):
+        s = ascii_matrix(seq_ascii)
+        q = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32).copy()
+        flag = np.zeros(s.shape[0], np.uint8)
+        self._check(self.L.crgpu_correct(self.h, lib, ptr(s), ptr(q), s.shape[0], ptr(idx), ptr(flag)))
+        return idx, flag
+
+    # ---- count stage -------------------------------------------------------------------------------
+    def set_key_layout(self, n_features, umi_len, n_libs=1, multiplexing_lib_mask=0):
+        self._check(self.L.crgpu_set_key_layout(self.h, n_features, umi_len, n_libs, multiplexing_lib_mask))
+        self.n_features, self.umi_len = n_features, umi_len
+
+    def records(self, n, umi_len, d_bc_idx, d_umi, d_umi_qualn, d_feature, d_flags=None):
+        r = Records()
+        r.n, r.umi_len = n, umi_len
+        r.d_bc_idx, r.d_umi, r.d_umi_qualn = _p(d_bc_idx), _p(d_umi), _p(d_umi_qualn)
+        r.d_feature, r.d_flags = _p(d_feature), _p(d_flags)
+        return r
+
+    def build_keys(self, recs, d_keys_out):
+        n = C.c_uint64()
+        self._check(self.L.crgpu_build_keys_dev(self.h, C.byref(recs), _p(d_keys_out), C.byref(n)))
+        return n.value
+
+    def partition_keys(self, d_keys, n, n_ranks, d_keys_out):
+        counts = np.zeros(n_ranks, np.uint64)
+        self._check(self.L.crgpu_partition_keys_dev(self.h, _p(d_keys), n, n_ranks, _p(d_keys_out), ptr(counts)))
+        return counts
+
+    def count_keys(self, d_keys, n_keys):
+        h = C.c_void_p()
+        self._check(self.L.crgpu_count_keys_dev(self.h, _p(d_keys), n_keys, C.byref(h)))
+        return Counts(self, h)
+
+    def assemble_matrix(self, bc, feature, count, n_features):
+        bc = np.ascontiguousarray(bc, np.uint32)
+        ft = np.ascontiguousarray(feature, np.uint32)
+        ct = np.ascontiguousarray(count, np.uint32)
+        mv = C.POINTER(MatrixView)()
+        self._check(self.L.crgpu_assemble_matrix(self.h, ptr(bc), ptr(ft), ptr(ct), len(bc), n_features, C.byref(mv)))
+        return Matrix(self, mv)
+
+    def count(self, recs, n_features):
+        mv = C.POINTER(MatrixView)()
+        self._check(self.L.crgpu_count(self.h, C.byref(recs), n_features, C.byref(mv)))
+        return Matrix(self, mv)
+
+    # ---- feature barcodes ----------------------------------------------------------------------------
+    def set_feature_pattern(self, pattern, feat_seqs, feat_index, feat_dist=None):
+        s = ascii_matrix(feat_seqs)
+        ix = np.ascontiguousarray(feat_index, dtype=np.uint32)
+        d = None if feat_dist is None else np.ascontiguousarray(feat_dist, dtype=np.float64)
+        self._check(self.L.crgpu_set_feature_pattern(self.h, pattern, s.tobytes(), s.shape[0], s.shape[1], ptr(ix), ptr(d)))
+
+    def match_features(self, pattern, d_seq, d_qualn, n, d_feature_out):
+        self._check(self.L.crgpu_match_features_dev(self.h, pattern, _p(d_seq), _p(d_qualn), n, _p(d_feature_out)))
+
+    # ---- synthetic data --------------------------------------------------------------------------------
+    def synth(self, params, first, n, cb=None, cb_qualn=None, umi=None, umi_qualn=None, feature=None, flags=None):
+        o = SynthOut()
+        o.cb, o.cb_qualn, o.umi, o.umi_qualn = _p(cb), _p(cb_qualn), _p(umi), _p(umi_qualn)
+        o.feature, o.flags = _p(feature), _p(flags)
+        self._check(self.L.crgpu_synth_dev(self.h, C.byref(params.c), first, n, C.byref(o)))

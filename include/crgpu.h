@@ -1,0 +1,285 @@
+/*
+ * crgpu.h -- C ABI of libcrgpu.so, the MI355X (gfx950) barcode-correct -> UMI-dedup -> count engine.
+ *
+ * Drop-in boundary for Cell Ranger's `count` hot path.  The reference has no FFI seam on this
+ * path (everything is in-process Rust); each entry point below names the reference
+ * interface it replaces (paths relative to /root/reference/lib/rust).  INTEGRATION.md shows the
+ * Rust `extern "C"` block a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative CRGPU_E* code on failure;
+ *     crgpu_last_error(ctx) returns a NUL-terminated message (valid until the next call on ctx).
+ *     No C++ exception crosses the ABI.
+ *   - pointers named *_dev / `d_*` are DEVICE pointers (hipMalloc'ed by the caller, by torch, or by
+ *     crgpu_malloc); all others are host pointers.  Inputs are caller-owned and never retained
+ *     past the call unless documented (crgpu_set_whitelist copies).
+ *   - sequences are 2-bit packed, A=0 C=1 G=2 T=3, FIRST base most significant
+ *     (== fastq_set `encode_2bit_u32`, used by mark_dups.rs:347), right-aligned in a uint32
+ *     (barcodes and UMIs of <= 16 bases).  Numeric order == byte-lexicographic order of the
+ *     sequences (barcode/src/lib.rs:119-124 ordering).
+ *   - quality arrays are `len` bytes per read: bits 0..6 = the FASTQ quality character
+ *     (ASCII, Phred+33), bit 7 = "this base was N" (the packed code of an N base is 0).
+ *   - a barcode index (`idx`) is the RANK of the canonical (translated) barcode in the ascending
+ *     order of the canonical whitelist; CRGPU_MISS (0xFFFFFFFF) = not on the whitelist.
+ *     crgpu_get_canon_order maps rank -> position in the caller's canon list.
+ *   - library types are small ids 0..CRGPU_MAX_LIB-1 chosen by the caller (one per
+ *     cr_types LibraryType in the GEM well); all libraries of a context share ONE canonical
+ *     barcode space, as in the reference (Trans whitelists map onto the GEX list).
+ *   - one context per (process, device).  Calls on one context must be serialised by the caller.
+ */
+#ifndef CRGPU_H
+#define CRGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRGPU_ABI_VERSION 1
+#define CRGPU_MAX_LIB 16
+#define CRGPU_MISS 0xFFFFFFFFu
+#define CRGPU_NO_FEATURE 0xFFFFFFFFu
+
+/* error codes */
+#define CRGPU_OK 0
+#define CRGPU_EINVAL (-1)   /* bad argument */
+#define CRGPU_ENODEV (-2)   /* no usable gfx950 device / HIP runtime failure at create */
+#define CRGPU_EHIP (-3)     /* a HIP call failed */
+#define CRGPU_ENOMEM (-4)   /* host or device allocation failed */
+#define CRGPU_ESTATE (-5)   /* call sequence error (e.g. whitelist not set) */
+#define CRGPU_ERANGE (-6)   /* value does not fit the engine's key layout */
+
+/* per-read flag byte */
+#define CRGPU_FLAG_LIB_MASK 0x0Fu   /* bits 0..3: library-type id */
+#define CRGPU_FLAG_CB_HAS_N 0x10u   /* barcode contains at least one N */
+#define CRGPU_FLAG_NONTXOMIC 0x20u  /* UmiType::NonTxomic (umi/src/lib.rs); clear = Txomic */
+
+typedef struct crgpu_ctx crgpu_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int crgpu_abi_version(void);
+int crgpu_create(crgpu_ctx **out, int device_id);
+void crgpu_destroy(crgpu_ctx *ctx);
+/* ctx may be NULL: returns the message of the last failed crgpu_create on this thread. */
+const char *crgpu_last_error(const crgpu_ctx *ctx);
+int crgpu_synchronize(crgpu_ctx *ctx);
+/* The HIP stream (hipStream_t) every kernel of this context is launched on. */
+void *crgpu_stream(crgpu_ctx *ctx);
+/* device-memory helpers for hosts without their own allocator (Rust host, tests) */
+int crgpu_malloc(crgpu_ctx *ctx, void **d_out, uint64_t bytes);
+int crgpu_free(crgpu_ctx *ctx, void *d_ptr);
+int crgpu_memcpy_h2d(crgpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int crgpu_memcpy_d2h(crgpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int crgpu_memset(crgpu_ctx *ctx, void *d_dst, int value, uint64_t bytes);
+
+/* ---- timing ledger (HIP events on the context's stream; used by bench.py's roofline) --------
+ * Every kernel family has a slot; times accumulate while enabled. */
+#define CRGPU_T_PACK 0
+#define CRGPU_T_MATCH 1       /* K1 exact match + histogram */
+#define CRGPU_T_CORRECT 2     /* K2 posterior correction */
+#define CRGPU_T_KEYS 3        /* key building / compaction */
+#define CRGPU_T_SORT 4        /* radix sort passes */
+#define CRGPU_T_DEDUP 5       /* run-length, UMI correction, low support, counting */
+#define CRGPU_T_MATRIX 6      /* CSC assembly */
+#define CRGPU_T_SYNTH 7       /* synthetic data generation */
+#define CRGPU_T_NSLOTS 8
+int crgpu_timing_enable(crgpu_ctx *ctx, int on);
+int crgpu_timing_reset(crgpu_ctx *ctx);
+/* ms_out[CRGPU_T_NSLOTS], launches_out[CRGPU_T_NSLOTS] (either may be NULL); synchronises. */
+int crgpu_timing_get(crgpu_ctx *ctx, double *ms_out, uint64_t *launches_out);
+
+/* ---- whitelist ---------------------------------------------------------------------------------
+ * Replaces Whitelist::construct / WhitelistSource::as_whitelist (barcode/src/whitelist.rs:313-330,
+ * 468-472).  keys: n x len ASCII (ACGT only).  canon: the canonical barcode list of the GEM well
+ * (n_canon x len ASCII).  translate_to[i] = position in canon of key i's translation
+ * (Whitelist::Trans, whitelist.rs:263-269,301-311); NULL => Whitelist::Plain and keys must equal
+ * canon as a set.  The first call on a context fixes the canonical list; later calls (other
+ * libraries) must pass the same canon.  len <= 16. */
+int crgpu_set_whitelist(crgpu_ctx *ctx, int lib, const char *keys, uint32_t n, uint32_t len,
+                        const char *canon, uint32_t n_canon, const uint32_t *translate_to);
+/* Same with 2-bit packed sequences (skips ASCII parsing for very large lists). */
+int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_t *keys, uint32_t n, uint32_t len,
+                               const uint32_t *canon, uint32_t n_canon, const uint32_t *translate_to);
+int crgpu_whitelist_info(crgpu_ctx *ctx, uint32_t *n_canon_out, uint32_t *len_out);
+/* order_out[rank] = position in the caller's canon list; seqs_out[rank] = packed sequence.
+ * Either may be NULL.  n_canon entries each. */
+int crgpu_get_canon_order(crgpu_ctx *ctx, uint32_t *order_out, uint32_t *seqs_out);
+
+/* ---- packing (ASCII -> 2-bit + N-flagged quality) ----------------------------------------------
+ * Device-side part of RnaProcessor::process_read's slicing (cr_types/src/rna_read.rs:103-138,
+ * 352-366): seq/qual are n x len ASCII (device).  packed_out n x u32, qualn_out n x len bytes,
+ * flags_inout (nullable) n bytes: CRGPU_FLAG_CB_HAS_N is OR-ed in when a base is N. */
+int crgpu_pack_dev(crgpu_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, uint32_t len,
+                   uint32_t *d_packed_out, uint8_t *d_qualn_out, uint8_t *d_flags_inout);
+
+/* ---- pass A: exact match + valid-barcode histogram (K1) -----------------------------------------
+ * Replaces Whitelist::check_and_update per read (whitelist.rs:494-517, called from
+ * rna_read.rs:352-366) and MakeShardHistograms::observe (cr_lib/src/make_shard_metrics.rs:171-188).
+ * d_flags carries the library id and CB_HAS_N per read (NULL => library 0, no N).
+ * d_idx_out[i] = canonical rank or CRGPU_MISS.  valid counts of the read's library accumulate in
+ * the context (crgpu_get_counts / crgpu_counts_dev). */
+int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_flags, uint64_t n,
+                              uint32_t *d_idx_out);
+
+/* ---- pass B: posterior 1-mismatch correction (K2) -----------------------------------------------
+ * Replaces BarcodeCorrector::correct_barcode / Posterior::correct_barcode
+ * (barcode/src/corrector.rs:48-60,111-165) as driven by correct_barcode_in_read
+ * (cr_lib/src/stages/barcode_correction.rs:76-99,328-345).  Only reads with
+ * d_idx_inout[i] == CRGPU_MISS are touched.  The prior is the library's valid-barcode histogram
+ * accumulated so far (or the one installed by crgpu_set_counts(CRGPU_COUNTS_PRIOR)); it must be
+ * complete -- over all batches and all ranks -- before this call.  d_qualn NULL => no qualities
+ * (corrector.rs:126 map_or).  d_corrected_out (nullable) gets 1 for ValidAfterCorrection.
+ * Corrected counts accumulate in the context. */
+int crgpu_set_posterior(crgpu_ctx *ctx, double max_expected_barcode_errors, double bc_confidence_threshold);
+int crgpu_correct_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_qualn, const uint8_t *d_flags,
+                      uint64_t n, uint32_t *d_idx_inout, uint8_t *d_corrected_out);
+
+/* ---- histograms ---------------------------------------------------------------------------------
+ * Per-library u32[n_canon] tables indexed by canonical rank.
+ *   VALID     = make_shard's valid_bc_counts (.bcc) == bc_counts prior of the corrector
+ *   CORRECTED = barcode_correction's bc_counts_corrected (reads fixed in pass B)
+ *   PRIOR     = the table pass B reads; aliases VALID until crgpu_set_counts(PRIOR) is called */
+#define CRGPU_COUNTS_VALID 0
+#define CRGPU_COUNTS_CORRECTED 1
+#define CRGPU_COUNTS_PRIOR 2
+int crgpu_get_counts(crgpu_ctx *ctx, int lib, int which, uint32_t *counts_out);
+int crgpu_set_counts(crgpu_ctx *ctx, int lib, int which, const uint32_t *counts);
+int crgpu_reset_counts(crgpu_ctx *ctx);
+/* device pointer of the table, for collectives issued by the host (RCCL all-reduce of the prior) */
+int crgpu_counts_dev(crgpu_ctx *ctx, int lib, int which, uint32_t **d_out);
+
+/* ---- host-buffer convenience: the signatures of SURVEY.md 8(b) ------------------------------------
+ * seq/qual are n x len ASCII host arrays exactly as the Rust host holds them (RnaRead raw barcode
+ * and quality); the library id applies to the whole batch.  These upload, pack, run K1 / K2 and
+ * download; PCIe-bound, for drop-in use, not for the bench. */
+int crgpu_match_and_count(crgpu_ctx *ctx, int lib, const uint8_t *seq, const uint8_t *qual, uint64_t n,
+                          uint32_t *idx_out);
+int crgpu_correct(crgpu_ctx *ctx, int lib, const uint8_t *seq, const uint8_t *qual, uint64_t n,
+                  uint32_t *idx_inout, uint8_t *corrected_flag_out);
+
+/* ---- count stage --------------------------------------------------------------------------------
+ * Device-resident SoA records (one GEM well).  Replaces, per (barcode, library type):
+ * UmiInfo::new (umi/src/info.rs:20-37), DupBuilder::observe/build and BarcodeDupMarker::new/process
+ * (tx_annotation/src/mark_dups.rs:128-363, driven by aligner.rs:283-334), and per barcode
+ * BcUmiInfo::feature_counts (cr_types/src/types.rs:180-188, align_and_count.rs:312-333). */
+typedef struct {
+    uint64_t n;
+    uint32_t umi_len;          /* <= 16 */
+    const uint32_t *d_bc_idx;  /* canonical rank after pass A/B, CRGPU_MISS = invalid barcode */
+    const uint32_t *d_umi;     /* 2-bit packed */
+    const uint8_t *d_umi_qualn;/* n x umi_len, bit7 = N */
+    const uint32_t *d_feature; /* conf-mapped feature index or CRGPU_NO_FEATURE */
+    const uint8_t *d_flags;    /* library id / NONTXOMIC; nullable (library 0, Txomic) */
+} crgpu_records;
+
+/* 64-bit molecule keys: the exchange unit between GPUs and the input of the
+ * dedup.  Build keeps only reads that reach DupBuilder::observe (valid barcode, valid UMI,
+ * feature != NONE).  d_keys_out must hold n entries; *n_keys_out = number written.
+ * multiplexing_lib_mask: bit l set => library l is Multiplexing Capture (UMI correction
+ * disabled, aligner.rs:315-318). */
+int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_t umi_len, uint32_t n_libs,
+                         uint32_t multiplexing_lib_mask);
+int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out,
+                         uint64_t *n_keys_out);
+/* owner rank of a key's barcode for the all-to-all (bc rank % n_ranks).  Partition d_keys (n) into
+ * n_ranks contiguous groups in d_keys_out; counts_out[r] = keys owned by rank r (host). */
+int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n, uint32_t n_ranks,
+                             uint64_t *d_keys_out, uint64_t *counts_out);
+
+/* result of the dedup: (barcode rank, feature, umi_count) triplets sorted by (barcode, feature),
+ * i.e. the FeatureBarcodeCount stream in BarcodeThenFeatureOrder (types.rs:121-137), plus the
+ * molecule table (UmiCount, types.rs:152-160) sorted per barcode as align_and_count.rs:314 does. */
+typedef struct crgpu_counts crgpu_counts;
+int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out);
+int crgpu_counts_info(crgpu_ctx *ctx, const crgpu_counts *c, uint64_t *n_triplets, uint64_t *n_molecules);
+/* device views (valid until crgpu_counts_free): bc rank u32[nt], feature u32[nt], count u32[nt] */
+int crgpu_counts_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t **d_bc, uint32_t **d_feature,
+                              uint32_t **d_count);
+int crgpu_counts_triplets(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint32_t *feature_out,
+                          uint32_t *count_out);
+/* molecule table: bc rank, library, feature, 2-bit umi, read_count, utype (0 Txomic,1 NonTxomic) */
+int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint8_t *lib_out,
+                           uint32_t *feature_out, uint32_t *umi_out, uint32_t *read_count_out,
+                           uint8_t *utype_out);
+void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c);
+
+/* ---- matrix (K6) ----------------------------------------------------------------------------------
+ * Replaces BarcodeIndex::new (cr_types/src/barcode_index.rs:20-53) and write_matrix_h5_helper's
+ * CSC assembly (cr_h5/src/count_matrix.rs:382-448).  Columns = every canonical barcode with a
+ * non-zero VALID or CORRECTED count in any library, ascending.  Library-owned; host arrays. */
+typedef struct {
+    uint64_t n_barcodes;     /* V */
+    uint64_t nnz;
+    uint32_t n_features;
+    uint32_t cb_len;
+    const uint32_t *barcode_rank;  /* V canonical ranks (ascending) */
+    const uint32_t *barcode_seq;   /* V packed sequences */
+    const int64_t *indptr;         /* V + 1 */
+    const int32_t *indices;        /* nnz  (written as int64 on disk, count_matrix.rs:399) */
+    const int32_t *data;           /* nnz */
+} crgpu_matrix;
+/* triplets may come from several ranks (concatenated in any order of disjoint barcodes; they are
+ * re-sorted by barcode here).  Host arrays. */
+int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const uint32_t *feature, const uint32_t *count,
+                          uint64_t n_triplets, uint32_t n_features, crgpu_matrix **out);
+void crgpu_matrix_free(crgpu_ctx *ctx, crgpu_matrix *m);
+/* write_matrix_mtx body (cr_lib/src/stages/write_matrix_market.rs:80-122), uncompressed text;
+ * metadata_line is the full "%metadata_json: ..." line.  gem_group suffixes barcodes.tsv rows. */
+int crgpu_write_mtx(crgpu_ctx *ctx, const crgpu_matrix *m, const char *metadata_line, const char *mtx_path,
+                    const char *barcodes_tsv_path, uint16_t gem_group);
+
+/* one-call convenience (single GPU): build keys -> dedup -> matrix */
+int crgpu_count(crgpu_ctx *ctx, const crgpu_records *recs, uint32_t n_features, crgpu_matrix **out);
+
+/* ---- feature-barcode matching (K3) ---------------------------------------------------------------
+ * Replaces FeatureExtractor::find_closest / correct_feature_barcode for one tethered pattern
+ * (cr_types/src/reference/feature_extraction.rs:34-117,443-470): feat_seqs n_feat x len ASCII,
+ * feat_index[n_feat] = global feature index, feat_dist[n_feat] = compute_feature_dist proportions
+ * (NULL => exact matches only).  d_seq / d_qualn: packed captures (len <= 16).
+ * d_feature_out[i] = feature index or CRGPU_NO_FEATURE. */
+int crgpu_set_feature_pattern(crgpu_ctx *ctx, int pattern, const char *feat_seqs, uint32_t n_feat, uint32_t len,
+                              const uint32_t *feat_index, const double *feat_dist);
+int crgpu_match_features_dev(crgpu_ctx *ctx, int pattern, const uint32_t *d_seq, const uint8_t *d_qualn,
+                             uint64_t n, uint32_t *d_feature_out);
+
+/* ---- synthetic workloads (bench / tests) ---------------------------------------------
+ * Counter-based integer generator: read i of a given seed is identical on the host and on the
+ * device.  Tables are host arrays built by cellranger_amd.synth. */
+typedef struct {
+    uint64_t seed;
+    uint32_t cb_len, umi_len;
+    uint32_t n_wl;            const uint32_t *wl_packed;     /* whitelist the reads are drawn from */
+    uint32_t n_cells;         const uint32_t *cell_wl_pos;   /* whitelist positions of the cells */
+                              const uint64_t *cell_cdf;      /* n_cells cumulative weights, last = 2^63 */
+    uint32_t n_ambient;       const uint32_t *ambient_wl_pos;
+    uint32_t n_genes;         const uint64_t *gene_cdf;      /* n_genes cumulative weights, last = 2^63 */
+    uint32_t ambient_per_2_16;      /* P(read is ambient) in 1/65536 */
+    uint32_t cb_err_per_2_16;       /* per-base substitution rate in 1/65536 */
+    uint32_t umi_err_per_2_16;
+    uint32_t n_per_2_20;            /* per-base N rate in 1/1048576 */
+    uint32_t no_feature_per_2_16;   /* P(feature == NONE) in 1/65536 */
+    uint32_t reads_per_umi;         /* mean reads per molecule */
+    uint64_t n_total;               /* reads in the whole job (sets molecule multiplicities) */
+    uint32_t n_libs;                /* library ids are drawn uniformly from [0, n_libs) */
+} crgpu_synth_params;
+
+typedef struct {
+    uint32_t *cb;        /* n */
+    uint8_t *cb_qualn;   /* n x cb_len */
+    uint32_t *umi;       /* n */
+    uint8_t *umi_qualn;  /* n x umi_len */
+    uint32_t *feature;   /* n */
+    uint8_t *flags;      /* n */
+} crgpu_synth_out;   /* any pointer may be NULL (field not generated) */
+
+/* reads [first, first+n) into device buffers / host buffers */
+int crgpu_synth_dev(crgpu_ctx *ctx, const crgpu_synth_params *p, uint64_t first, uint64_t n,
+                    const crgpu_synth_out *d_out);
+int crgpu_synth_host(const crgpu_synth_params *p, uint64_t first, uint64_t n, const crgpu_synth_out *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

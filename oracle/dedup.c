@@ -276,6 +276,7 @@ uint64_t oracle_mark_dups_group(const char *umi, uint32_t umi_len, const uint8_t
             di.is_umi_count = !di.is_low_support && is_min_qname;
             if (di.is_umi_count && umi_counts_out) {
                 oracle_umicount *u = &umi_counts_out[n_out];
+                memset(u, 0, sizeof(*u));
                 u->feature_idx = cr->gene;
                 u->umi = di.processed_umi;
                 u->read_count = di.read_count;

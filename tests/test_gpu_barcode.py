@@ -1,0 +1,223 @@
+"""GPU parity tests of the barcode stage (K1 exact match + histogram, K2 posterior correction),
+called through the C ABI and compared bit-for-bit with the oracle and the reference's golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def test_context_is_gfx950_and_loaded_in_tree():
+    import gpu_helpers as G
+    from cellranger_amd import _lib
+
+    c = G.ctx()
+    assert c.h
+    assert os.path.dirname(_lib.LIB_PATH).endswith("cellranger_amd")
+
+
+@pytest.mark.parametrize("block", load("corrector_vectors.json")["posterior"], ids=lambda b: b["name"][:40])
+def test_posterior_golden_vectors_on_gpu(block):
+    """corrector.rs:196-313 through crgpu_match_and_count / crgpu_correct (host-buffer ABI)."""
+    import gpu_helpers as G
+    from cellranger_amd import engine as E
+    from cellranger_amd._lib import COUNTS_PRIOR, MISS
+
+    c = G.fresh_ctx()
+    wl = block["whitelist"]
+    c.set_whitelist_ascii(0, wl)
+    order, seqs = c.canon_order()
+    sorted_wl = [bytes(r).decode() for r in E.unpack_seqs(seqs, 5)]
+    assert sorted_wl == sorted(wl)
+    prior = np.zeros(len(wl), np.uint32)
+    for k, v in block["bc_counts"].items():
+        prior[sorted_wl.index(k)] = v
+    c.set_counts(0, COUNTS_PRIOR, prior)
+    c.set_posterior(block["max_expected_barcode_errors"], block["bc_confidence_threshold"])
+    seqs_in = [case["seq"] for case in block["cases"]]
+    quals = np.array([case["qual"] for case in block["cases"]], dtype=np.uint8)
+    # the reference test feeds these as Invalid segments: start from MISS for all of them
+    idx = np.full(len(seqs_in), MISS, np.uint32)
+    idx2, flag = c.correct_host(0, seqs_in, quals, idx)
+    for case, i, f in zip(block["cases"], idx2, flag):
+        if case["expect"] is None:
+            assert i == MISS and f == 0, case
+        else:
+            assert i != MISS and sorted_wl[i] == case["expect"] and f == 1, case
+    c.close()
+
+
+def test_posterior_n_any_position_on_gpu():
+    import gpu_helpers as G
+    from cellranger_amd._lib import MISS
+
+    g = load("corrector_vectors.json")["prop_n_in_barcode"]
+    c = G.fresh_ctx()
+    c.set_whitelist_ascii(0, g["whitelist"])
+    bc = g["whitelist"][0]
+    seqs, quals = [], []
+    for n_pos in range(16):
+        seqs.append(bc[:n_pos] + "N" + bc[n_pos + 1:])
+        q = [g["qual_default"]] * 16
+        q[n_pos] = g["qual_at_n"]
+        quals.append(q)
+    quals = np.array(quals, np.uint8)
+    for params in [(g["max_expected_barcode_errors"], g["bc_confidence_threshold"]), None]:
+        if params:
+            c.set_posterior(*params)
+        else:
+            c.set_posterior(np.finfo(np.float64).max, 0.975)  # Posterior::default (corrector.rs:102-108)
+        idx = c.match_and_count_host(0, seqs, quals)
+        assert (idx == MISS).all()  # an N never matches exactly (whitelist.rs:494)
+        idx2, flag = c.correct_host(0, seqs, quals, idx)
+        assert (idx2 == 0).all() and (flag == 1).all()
+    # two Ns can never be repaired
+    idx2, flag = c.correct_host(0, ["NNGATTGACCCAAAGG"], np.full((1, 16), 53, np.uint8), np.array([MISS], np.uint32))
+    assert idx2[0] == MISS and flag[0] == 0
+    c.close()
+
+
+def _compare_barcode_stage(w, n, first=0, threshold=0.975, max_err=None):
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd._lib import COUNTS_CORRECTED, COUNTS_VALID
+
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=w.cb_len)
+    max_err = np.finfo(np.float64).max if max_err is None else max_err
+    c.set_posterior(max_err, threshold)
+    _, canon_sorted = c.canon_order()
+    r = w.host_reads(first, n)
+    idx_a, idx_b, corr, _ = G.gpu_barcode_stage(c, r, n)
+
+    owl = O.Whitelist(E.unpack_seqs(w.wl_packed, w.cb_len))
+    res = O.run_pipeline(G.oracle_reads_from_packed(r, w.cb_len, w.umi_len), [owl], count=False,
+                         max_expected_errors=max_err, threshold=threshold, n_threads=4)
+    exp_a, exp_b = G.oracle_expected_idx(res, canon_sorted)
+    assert np.array_equal(idx_a, exp_a)
+    assert np.array_equal(idx_b, exp_b)
+    assert np.array_equal(corr, (res.bc_state == 2).astype(np.uint8))
+    assert np.array_equal(c.get_counts(0, COUNTS_VALID), G.hist_as_rank_counts(res.valid_hist[0], w.cb_len, canon_sorted))
+    assert np.array_equal(c.get_counts(0, COUNTS_CORRECTED),
+                          G.hist_as_rank_counts(res.corrected_hist[0], w.cb_len, canon_sorted))
+    stats = dict(valid=int((res.bc_state == 1).sum()), corrected=int((res.bc_state == 2).sum()),
+                 invalid=int((res.bc_state == 0).sum()))
+    c.close()
+    return stats
+
+
+def test_cfg2_model_1m_reads_bit_exact():
+    """1 M-read down-scale of cfg2: idx per read and both histograms equal the oracle's."""
+    from cellranger_amd import synth as S
+
+    w = S.Workload(n_total=1_000_000, seed=S.SEED0 + 2)
+    st = _compare_barcode_stage(w, 1_000_000)
+    assert st["corrected"] > 20_000 and st["invalid"] > 1_000 and st["valid"] > 800_000
+
+
+def test_dense_small_whitelists_many_neighbours_and_ties():
+    """Short barcodes with a dense whitelist: several Hamming-1 neighbours per read, equal priors,
+    thresholds that accept ties' winners -- exercises the f64 accumulation order and tie-breaks."""
+    from cellranger_amd import synth as S
+
+    for cb_len, n_wl, thr in [(5, 300, 0.5), (6, 1500, 0.3), (8, 20000, 0.6), (11, 100000, 0.9), (16, 5000, 0.975)]:
+        w = S.Workload(n_total=200_000, seed=77 + cb_len, n_wl=n_wl, n_cells=min(200, n_wl // 3),
+                       n_ambient=n_wl // 2, cb_len=cb_len, cb_err=0.03, n_rate=0.004)
+        st = _compare_barcode_stage(w, 200_000, threshold=thr)
+        assert st["corrected"] > 0
+        # the reference's unit-test parameters (expected-error veto active)
+        _compare_barcode_stage(w, 50_000, first=200_000, threshold=0.95, max_err=1.0)
+
+
+def test_translation_whitelist_on_gpu():
+    """Whitelist::Trans (whitelist.rs:497-504): hits report the partner's rank and the prior is
+    looked up by the translated sequence (corrector.rs:135-137)."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import COUNTS_VALID
+
+    w = S.Workload(n_total=300_000, seed=5, n_wl=50_000, n_cells=2000, n_ambient=20000)
+    rng = np.random.default_rng(9)
+    canon = w.wl_packed                       # GEX list = canonical space
+    raw = np.unique(rng.integers(0, 1 << 32, size=60_000, dtype=np.uint64))[:50_000].astype(np.uint32)
+    raw = rng.permutation(raw)
+    translate_to = rng.permutation(50_000).astype(np.uint32)   # pairing permutation
+    c = G.fresh_ctx()
+    c.set_whitelist(0, canon, length=16)
+    c.set_whitelist(1, raw, canon=canon, translate_to=translate_to, length=16)
+    _, canon_sorted = c.canon_order()
+    # reads: library 1 reads carry RAW barcodes; build them by swapping the generator's whitelist
+    w_fb = S.Workload(n_total=300_000, seed=5, n_wl=50_000, n_cells=2000, n_ambient=20000)
+    w_fb.wl_packed[:] = raw
+    r0 = w.host_reads(0, 150_000)
+    r1 = w_fb.host_reads(150_000, 150_000)
+    r = {k: np.concatenate([r0[k], r1[k]]) for k in r0}
+    r["flags"][150_000:] |= 1
+    idx_a, idx_b, corr, _ = G.gpu_barcode_stage(c, r, 300_000)
+    owl0 = O.Whitelist(E.unpack_seqs(canon, 16))
+    owl1 = O.Whitelist(E.unpack_seqs(raw, 16), translated=E.unpack_seqs(canon[translate_to], 16))
+    res = O.run_pipeline(G.oracle_reads_from_packed(r, 16, 12), [owl0, owl1], n_lib=2, count=False, n_threads=4)
+    exp_a, exp_b = G.oracle_expected_idx(res, canon_sorted)
+    assert np.array_equal(idx_a, exp_a) and np.array_equal(idx_b, exp_b)
+    for lib in (0, 1):
+        assert np.array_equal(c.get_counts(lib, COUNTS_VALID),
+                              G.hist_as_rank_counts(res.valid_hist[lib], 16, canon_sorted))
+    assert (res.bc_state[150_000:] == 2).sum() > 1000
+    c.close()
+
+
+def test_pack_and_host_abi_match_device_abi():
+    """crgpu_pack_dev + host-buffer entry points give the same answers as the packed device path."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import FLAG_CB_HAS_N
+
+    w = S.Workload(n_total=100_000, seed=3, n_wl=40_000, n_cells=1000, n_ambient=10000)
+    n = 100_000
+    r = w.host_reads(0, n)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    seq_ascii, qual = S.to_ascii(r["cb"], r["cb_qualn"], 16)
+    # device pack
+    d_seq, d_qual = c.upload(seq_ascii), c.upload(qual)
+    d_pk, d_qn, d_fl = c.empty(n, np.uint32), c.empty((n, 16), np.uint8), c.zeros(n, np.uint8)
+    c.pack(d_seq, d_qual, n, 16, d_pk, d_qn, d_fl)
+    assert np.array_equal(d_pk.to_host(), r["cb"])
+    assert np.array_equal(d_qn.to_host(), r["cb_qualn"])
+    assert np.array_equal(d_fl.to_host() & FLAG_CB_HAS_N, r["flags"] & FLAG_CB_HAS_N)
+    idx_a, idx_b, corr, _ = G.gpu_barcode_stage(c, r, n)
+    c.reset_counts()
+    h_a = c.match_and_count_host(0, seq_ascii, qual)
+    h_b, h_f = c.correct_host(0, seq_ascii, qual, h_a)
+    assert np.array_equal(h_a, idx_a) and np.array_equal(h_b, idx_b) and np.array_equal(h_f, corr)
+    c.close()
+
+
+def test_empty_and_error_paths():
+    import gpu_helpers as G
+    from cellranger_amd._lib import CrgpuError
+
+    c = G.fresh_ctx()
+    with pytest.raises(CrgpuError):
+        c.match_and_count(0, None, 10, 0)          # no whitelist yet
+    with pytest.raises(CrgpuError):
+        c.set_whitelist_ascii(0, ["ACGTN"])         # non-ACGT whitelist entry
+    with pytest.raises(CrgpuError):
+        c.set_whitelist_ascii(0, ["A" * 17])        # > 16 bases
+    c.set_whitelist_ascii(0, ["ACGT", "TTTT"])
+    c.match_and_count(None, None, 0, None)          # empty batch is a no-op
+    c.correct(None, None, None, 0, None)
+    assert c.get_counts(0).sum() == 0
+    c.close()

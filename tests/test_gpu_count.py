@@ -1,0 +1,190 @@
+"""GPU parity tests of the count stage (keys, radix sort, UMI correction, low support, triplets,
+CSC) through the C ABI, bit-for-bit against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gpu(c, r, n, w_cb_len, umi_len, n_features, n_libs=1, mux_mask=0):
+    import gpu_helpers as G
+
+    idx_a, idx_b, corr, dev = G.gpu_barcode_stage(c, r, n)
+    c.set_key_layout(n_features, umi_len, n_libs, mux_mask)
+    d_umi, d_uq, d_ft = c.upload(r["umi"]), c.upload(r["umi_qualn"]), c.upload(r["feature"])
+    recs = c.records(n, umi_len, dev["idx"], d_umi, d_uq, d_ft, dev["flags"])
+    d_keys = c.empty(max(n, 1), np.uint64)
+    nk = c.build_keys(recs, d_keys)
+    counts = c.count_keys(d_keys, nk)
+    bc, ft, ct = counts.triplets()
+    mol = counts.molecules()
+    m = c.assemble_matrix(bc, ft, ct, n_features)
+    # the one-call convenience entry point must agree
+    m2 = c.count(recs, n_features)
+    for a in ("barcode_rank", "indptr", "indices", "data"):
+        assert np.array_equal(getattr(m, a), getattr(m2, a))
+    return idx_b, (bc, ft, ct), mol, m
+
+
+def _compare_with_oracle(c, w, r, n, n_features, n_libs=1, mux_mask=0, whitelists=None):
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+
+    _, canon_sorted = c.canon_order()
+    idx_b, trip, mol, m = _run_gpu(c, r, n, w.cb_len, w.umi_len, n_features, n_libs, mux_mask)
+    if whitelists is None:
+        whitelists = [O.Whitelist(E.unpack_seqs(w.wl_packed, w.cb_len))] * n_libs
+    res = O.run_pipeline(G.oracle_reads_from_packed(r, w.cb_len, w.umi_len), whitelists, n_lib=n_libs,
+                         multiplexing_lib_mask=mux_mask, n_threads=4)
+    # columns, indptr, indices, data: the arrays write_matrix_h5 stores
+    assert np.array_equal(m.barcodes_ascii(), res.barcodes)
+    assert np.array_equal(m.indptr, res.indptr)
+    assert np.array_equal(m.indices, res.indices)
+    assert np.array_equal(m.data, res.data)
+    # molecule table (UmiCount stream, types.rs:152-160) in the reference's per-barcode order
+    col_rank = G.ranks_of(canon_sorted, res.barcodes) if len(res.barcodes) else np.zeros(0, np.uint32)
+    assert np.array_equal(mol["bc"], col_rank[res.mol_bc_col])
+    assert np.array_equal(mol["lib"], res.mol_lib)
+    assert np.array_equal(mol["feature"], res.mol["feature_idx"])
+    assert np.array_equal(mol["umi"], res.mol["umi"])
+    assert np.array_equal(mol["read_count"], res.mol["read_count"])
+    assert np.array_equal(mol["utype"], res.mol["utype"])
+    return res, m
+
+
+def test_radix_sort_matches_numpy():
+    """The ballot-multisplit LSD sort, exercised through partition + count on raw keys."""
+    import gpu_helpers as G
+
+    c = G.fresh_ctx()
+    c.set_whitelist_ascii(0, ["ACGTACGTACGTACGT", "TTTTACGTACGTACGT", "GGGGACGTACGTACGT"])
+    c.set_key_layout(1000, 12, 1, 0)
+    rng = np.random.default_rng(1)
+    # keys: [bc 2 bits][feature 10][umi 24][1]
+    n = 300_000
+    bc = rng.integers(0, 3, n).astype(np.uint64)
+    ft = rng.integers(0, 1000, n).astype(np.uint64)
+    umi = rng.integers(0, 1 << 24, n).astype(np.uint64)
+    keys = (bc << np.uint64(35)) | (ft << np.uint64(25)) | (umi << np.uint64(1))
+    d_in, d_out = c.upload(keys), c.empty(n, np.uint64)
+    for n_ranks in (1, 2, 3, 8):
+        cnt = c.partition_keys(d_in, n, n_ranks, d_out)
+        out = d_out.to_host()
+        owner = (keys >> np.uint64(35)) % np.uint64(n_ranks)
+        exp = np.concatenate([keys[owner == r] for r in range(n_ranks)])  # stable
+        assert np.array_equal(out, exp)
+        assert list(cnt) == [int((owner == r).sum()) for r in range(n_ranks)]
+    c.close()
+
+
+def test_cfg3_model_1m_records_matrix_bit_exact():
+    """1 M-record down-scale of cfg3: CSC arrays and molecule table equal the oracle's."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+
+    n = 1_000_000
+    w = S.Workload(n_total=n, seed=S.SEED0 + 3, n_cells=300, n_ambient=20000)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    res, m = _compare_with_oracle(c, w, r, n, w.n_genes)
+    assert m.nnz > 100_000 and m.n_barcodes > 10_000
+    # UMI correction and low-support filtering both happened
+    assert res.mol["read_count"].max() > 4
+    c.close()
+
+
+def test_adversarial_dense_umis_chains_ties_multilib():
+    """Tiny UMI space + few features + several library types: long Hamming chains, count ties,
+    zero-count keys, UMIs shared by features (low support), a Multiplexing library with UMI
+    correction disabled, NonTxomic reads, invalid UMIs."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import FLAG_NONTXOMIC
+
+    for seed, umi_len, n_genes, n in [(11, 4, 3, 60_000), (12, 5, 7, 120_000), (13, 6, 40, 200_000), (14, 3, 2, 20_000)]:
+        w = S.Workload(n_total=n, seed=seed, n_wl=2000, n_cells=40, n_ambient=500, n_genes=n_genes, umi_len=umi_len,
+                       umi_err=0.05, cb_err=0.01, n_rate=0.002, no_feature_frac=0.1, reads_per_umi=2, n_libs=3)
+        c = G.fresh_ctx()
+        for lib in range(3):
+            c.set_whitelist(lib, w.wl_packed, length=16)
+        r = w.host_reads(0, n)
+        rng = np.random.default_rng(seed)
+        r["flags"] = (r["flags"] | np.where(rng.random(n) < 0.3, FLAG_NONTXOMIC, 0)).astype(np.uint8)
+        res, m = _compare_with_oracle(c, w, r, n, n_genes, n_libs=3, mux_mask=0b100)
+        assert m.nnz > 0
+        c.close()
+
+
+def test_large_segments_use_binary_search_path():
+    """One barcode, one feature, thousands of distinct UMIs: the > SMALL_SEG path of correct_umis."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+
+    n = 150_000
+    w = S.Workload(n_total=n, seed=21, n_wl=100, n_cells=3, n_ambient=0, n_genes=2, umi_len=8, umi_err=0.02,
+                   cb_err=0.0, n_rate=0.0, no_feature_frac=0.0, reads_per_umi=3, sigma=0.1)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    res, m = _compare_with_oracle(c, w, r, n, 2)
+    assert m.data.max() > 2000
+    c.close()
+
+
+def test_empty_and_degenerate_inputs():
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import MISS, NO_FEATURE
+
+    w = S.Workload(n_total=1000, seed=2, n_wl=500, n_cells=20, n_ambient=100, n_genes=5)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    c.set_key_layout(5, 12, 1, 0)
+    # no reads at all
+    recs = c.records(0, 12, None, None, None, None, None)
+    m = c.count(recs, 5)
+    assert m.n_barcodes == 0 and m.nnz == 0 and list(m.indptr) == [0]
+    # reads whose barcodes are all invalid / features all NONE: columns exist only for seen barcodes
+    n = 1000
+    r = w.host_reads(0, n)
+    r["feature"][:] = NO_FEATURE
+    res, m = _compare_with_oracle(c, w, r, n, 5)
+    assert m.nnz == 0 and m.n_barcodes > 0
+    c.close()
+
+
+def test_mtx_text_matches_oracle(tmp_path):
+    """write_matrix_mtx text (write_matrix_market.rs:96-118) is byte-identical to the oracle's."""
+    import ctypes as C
+
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+
+    n = 50_000
+    w = S.Workload(n_total=n, seed=8, n_wl=3000, n_cells=50, n_ambient=400, n_genes=30)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    _, _, _, m = _run_gpu(c, r, n, 16, 12, 30)
+    meta = '%metadata_json: {"software_version": "cellranger-amd", "format_version": 2}'
+    p_gpu, p_bc = tmp_path / "gpu.mtx", tmp_path / "barcodes.tsv"
+    m.write_mtx(p_gpu, p_bc, metadata_line=meta, gem_group=1)
+
+    # oracle text
+    reads = G.oracle_reads_from_packed(r, 16, 12)
+    owl = O.Whitelist(E.unpack_seqs(w.wl_packed, 16))
+    # re-run the oracle keeping the C matrix alive long enough to write it
+    res = O.run_pipeline(reads, [owl])
+    lines = ["%%MatrixMarket matrix coordinate integer general", meta, "%d %d %d" % (30, len(res.barcodes), len(res.data))]
+    for col in range(len(res.barcodes)):
+        for k in range(res.indptr[col], res.indptr[col + 1]):
+            lines.append("%d %d %d" % (1 + res.indices[k], 1 + col, res.data[k]))
+    assert p_gpu.read_text() == "\n".join(lines) + "\n"
+    assert p_bc.read_text().splitlines() == [bytes(b).decode() + "-1" for b in res.barcodes]
+    c.close()
