@@ -19,7 +19,7 @@ FLAG_CB_HAS_N = 0x10
 FLAG_NONTXOMIC = 0x20
 
 COUNTS_VALID, COUNTS_CORRECTED, COUNTS_PRIOR = 0, 1, 2
-T_NAMES = ["pack", "match", "correct", "keys", "sort", "dedup", "matrix", "synth"]
+T_NAMES = ["pack", "match", "correct", "keys", "sort_scatter", "dedup", "matrix", "synth", "sort_hist", "scan"]
 
 
 class CrgpuError(RuntimeError):
@@ -51,6 +51,17 @@ class MatrixView(C.Structure):
         ("indptr", C.c_void_p),
         ("indices", C.c_void_p),
         ("data", C.c_void_p),
+    ]
+
+
+class MatrixDevView(C.Structure):
+    _fields_ = [
+        ("n_barcodes", C.c_uint64),
+        ("nnz", C.c_uint64),
+        ("d_barcode_rank", C.c_void_p),
+        ("d_indptr", C.c_void_p),
+        ("d_indices", C.c_void_p),
+        ("d_data", C.c_void_p),
     ]
 
 
@@ -106,7 +117,7 @@ SYMBOLS = {
     "crgpu_memset": (_i, [_vp, _vp, _i, _u64]),
     "crgpu_timing_enable": (_i, [_vp, _i]),
     "crgpu_timing_reset": (_i, [_vp]),
-    "crgpu_timing_get": (_i, [_vp, _vp, _vp]),
+    "crgpu_timing_get": (_i, [_vp, _vp, _vp, _vp]),
     "crgpu_set_whitelist": (_i, [_vp, _i, C.c_char_p, _u32, _u32, C.c_char_p, _u32, _vp]),
     "crgpu_set_whitelist_packed": (_i, [_vp, _i, _vp, _u32, _u32, _vp, _u32, _vp]),
     "crgpu_whitelist_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
@@ -133,6 +144,9 @@ SYMBOLS = {
     "crgpu_assemble_matrix": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_matrix_free": (None, [_vp, C.POINTER(MatrixView)]),
     "crgpu_write_mtx": (_i, [_vp, C.POINTER(MatrixView), C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint16]),
+    "crgpu_assemble_matrix_dev": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(MatrixDevView))]),
+    "crgpu_matrix_dev_free": (None, [_vp, C.POINTER(MatrixDevView)]),
+    "crgpu_matrix_dev_download": (_i, [_vp, C.POINTER(MatrixDevView), _vp, _vp, _vp, _vp]),
     "crgpu_count": (_i, [_vp, C.POINTER(Records), _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_set_feature_pattern": (_i, [_vp, _i, C.c_char_p, _u32, _u32, _vp, _vp]),
     "crgpu_match_features_dev": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),

@@ -83,7 +83,7 @@ extern "C" int crgpu_pack_dev(crgpu_ctx *ctx, const uint8_t *d_seq, const uint8_
     if (len == 16)
         CR_REQUIRE(ctx, ((uintptr_t)d_seq | (uintptr_t)d_qual | (uintptr_t)d_qualn_out) % 16 == 0, CRGPU_EINVAL,
                    "crgpu_pack_dev: 16-base buffers must be 16-byte aligned");
-    CrTimer t(ctx, CRGPU_T_PACK);
+    CrTimer t(ctx, CRGPU_T_PACK, n);
     hipLaunchKernelGGL(k_pack, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_seq, d_qual, n, len, d_packed_out,
                        d_qualn_out, d_flags_inout);
     CR_HIP(ctx, hipGetLastError());
@@ -130,7 +130,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     CR_REQUIRE(ctx, d_cb && d_idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
     WlViewSet vs;
     CR_TRY(cr_make_views(ctx, vs.v));
-    CrTimer t(ctx, CRGPU_T_MATCH);
+    CrTimer t(ctx, CRGPU_T_MATCH, n);
     const dim3 grid(cr_grid(n, 256)), block(256);
     if (uniform_lib0(ctx))
         hipLaunchKernelGGL(k_match<true>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, n, d_idx_out);
@@ -309,7 +309,7 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
     CR_TRY(cr_scratch(ctx, n * sizeof(uint32_t), &ws));
     uint32_t *miss_list = (uint32_t *)ws;
     uint32_t *n_miss = ctx->d_scalars;
-    CrTimer t(ctx, CRGPU_T_CORRECT);
+    CrTimer t(ctx, CRGPU_T_CORRECT, n);
     CR_HIP(ctx, hipMemsetAsync(n_miss, 0, sizeof(uint32_t), ctx->stream));
     if (d_corrected_out) CR_HIP(ctx, hipMemsetAsync(d_corrected_out, 0, n, ctx->stream));
     hipLaunchKernelGGL(k_collect_miss, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_idx_inout, n, miss_list, n_miss);

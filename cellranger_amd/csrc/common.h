@@ -53,6 +53,7 @@ struct FeaturePattern {
 struct TimedSpan {
     int slot;
     hipEvent_t start, stop;
+    uint64_t units;
 };
 
 struct KeyLayout {
@@ -97,6 +98,7 @@ struct crgpu_ctx {
     bool timing = false;
     double acc_ms[CRGPU_T_NSLOTS] = {0};
     uint64_t acc_launches[CRGPU_T_NSLOTS] = {0};
+    uint64_t acc_units[CRGPU_T_NSLOTS] = {0};  // elements (reads / keys) the timed launches processed
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> event_pool;
 };
@@ -131,7 +133,8 @@ struct CrTimer {
     crgpu_ctx *ctx;
     int slot;
     hipEvent_t start = nullptr, stop = nullptr;
-    CrTimer(crgpu_ctx *c, int s);
+    uint64_t units;
+    CrTimer(crgpu_ctx *c, int s, uint64_t units = 0);
     ~CrTimer();
 };
 

@@ -182,7 +182,7 @@ static hipEvent_t take_event(crgpu_ctx *ctx) {
     return e;
 }
 
-CrTimer::CrTimer(crgpu_ctx *c, int s) : ctx(c), slot(s) {
+CrTimer::CrTimer(crgpu_ctx *c, int s, uint64_t u) : ctx(c), slot(s), units(u) {
     if (!ctx->timing) return;
     start = take_event(ctx);
     stop = take_event(ctx);
@@ -192,7 +192,7 @@ CrTimer::CrTimer(crgpu_ctx *c, int s) : ctx(c), slot(s) {
 CrTimer::~CrTimer() {
     if (!start) return;
     hipEventRecord(stop, ctx->stream);
-    ctx->spans.push_back({slot, start, stop});
+    ctx->spans.push_back({slot, start, stop, units});
 }
 
 static int drain_spans(crgpu_ctx *ctx) {
@@ -202,6 +202,7 @@ static int drain_spans(crgpu_ctx *ctx) {
         CR_HIP(ctx, hipEventElapsedTime(&ms, s.start, s.stop));
         ctx->acc_ms[s.slot] += ms;
         ctx->acc_launches[s.slot] += 1;
+        ctx->acc_units[s.slot] += s.units;
         ctx->event_pool.push_back(s.start);
         ctx->event_pool.push_back(s.stop);
     }
@@ -222,16 +223,18 @@ extern "C" int crgpu_timing_reset(crgpu_ctx *ctx) {
     for (int i = 0; i < CRGPU_T_NSLOTS; i++) {
         ctx->acc_ms[i] = 0;
         ctx->acc_launches[i] = 0;
+        ctx->acc_units[i] = 0;
     }
     return CRGPU_OK;
 }
 
-extern "C" int crgpu_timing_get(crgpu_ctx *ctx, double *ms_out, uint64_t *launches_out) {
+extern "C" int crgpu_timing_get(crgpu_ctx *ctx, double *ms_out, uint64_t *launches_out, uint64_t *units_out) {
     if (!ctx) return CRGPU_EINVAL;
     CR_TRY(drain_spans(ctx));
     for (int i = 0; i < CRGPU_T_NSLOTS; i++) {
         if (ms_out) ms_out[i] = ctx->acc_ms[i];
         if (launches_out) launches_out[i] = ctx->acc_launches[i];
+        if (units_out) units_out[i] = ctx->acc_units[i];
     }
     return CRGPU_OK;
 }

@@ -132,7 +132,7 @@ extern "C" int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, u
                "crgpu_build_keys: NULL buffer");
     unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
     {
-        CrTimer t(ctx, CRGPU_T_KEYS);
+        CrTimer t(ctx, CRGPU_T_KEYS, recs->n);
         CR_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(*d_n), ctx->stream));
         hipLaunchKernelGGL(k_build_keys, dim3(cr_grid(recs->n, 256)), dim3(256), 0, ctx->stream, make_kl(ctx->layout),
                            recs->d_bc_idx, recs->d_umi, recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n,
@@ -150,7 +150,6 @@ extern "C" int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, 
     if (!ctx || !counts_out) return CRGPU_EINVAL;
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_partition_keys: call crgpu_set_key_layout first");
     CR_REQUIRE(ctx, n == 0 || (d_keys && d_keys_out), CRGPU_EINVAL, "crgpu_partition_keys: NULL buffer");
-    CrTimer t(ctx, CRGPU_T_KEYS);
     return cr_partition_by_owner(ctx, d_keys, d_keys_out, n, ctx->layout.sh_bc(), n_ranks, counts_out);
 }
 
@@ -530,10 +529,7 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
     DevBuf tmp;
     CR_TRY(dmalloc(ctx, tmp, n_keys * sizeof(uint64_t)));
     bool in_tmp = false;
-    {
-        CrTimer t(ctx, CRGPU_T_SORT);
-        CR_TRY(cr_radix_sort_u64(ctx, d_keys_inout, tmp.as<uint64_t>(), nullptr, nullptr, n_keys, 0, L.total_bits(), &in_tmp));
-    }
+    CR_TRY(cr_radix_sort_u64(ctx, d_keys_inout, tmp.as<uint64_t>(), nullptr, nullptr, n_keys, 0, L.total_bits(), &in_tmp));
     const uint64_t *keys = in_tmp ? tmp.as<uint64_t>() : d_keys_inout;
 
     // 2. distinct (barcode, feature, library, UMI) keys and their run starts (DupBuilder::observe)
@@ -586,11 +582,8 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
             CR_HIP(ctx, hipGetLastError());
         }
         bool s_in_tmp = false;
-        {
-            CrTimer t(ctx, CRGPU_T_SORT);
-            CR_TRY(cr_radix_sort_u64(ctx, k2_b.as<uint64_t>(), k2t_b.as<uint64_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(),
-                                     nd, 0, L.total_bits() - 1, &s_in_tmp));
-        }
+        CR_TRY(cr_radix_sort_u64(ctx, k2_b.as<uint64_t>(), k2t_b.as<uint64_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(), nd,
+                                 0, L.total_bits() - 1, &s_in_tmp));
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
             hipLaunchKernelGGL(k_low_support, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl,
@@ -647,6 +640,135 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
     mreads_b.p = nullptr;
     guard.armed = false;
     *out = res;
+    return CRGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 on the device: barcode index + CSC (barcode_index.rs:20-53, count_matrix.rs:382-448)
+// ------------------------------------------------------------------------------------------------
+struct CountTables {
+    const uint32_t *t[2 * CRGPU_MAX_LIB];
+    uint32_t n;
+};
+struct SeenFlag {  // barcode has a non-zero valid or corrected count in some library
+    CountTables ct;
+    __device__ __forceinline__ bool operator()(uint64_t r) const {
+        uint32_t any = 0;
+        for (uint32_t k = 0; k < ct.n; k++) any |= ct.t[k][r];
+        return any != 0u;
+    }
+};
+struct EmitCol {
+    uint32_t *rank;
+    __device__ __forceinline__ void operator()(uint64_t r, uint32_t o) const { rank[o] = (uint32_t)r; }
+};
+
+__global__ __launch_bounds__(256) void k_csc(const uint32_t *__restrict__ col_rank, uint64_t n_cols,
+                                             const uint32_t *__restrict__ t_bc, const uint32_t *__restrict__ t_feat,
+                                             const uint32_t *__restrict__ t_cnt, uint64_t nt,
+                                             long long *__restrict__ indptr, int32_t *__restrict__ indices,
+                                             int32_t *__restrict__ data) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // indptr[c] = first triplet whose barcode rank >= col_rank[c]; columns without counts get empty ranges
+    for (uint64_t c = tid; c <= n_cols; c += stride) {
+        if (c == n_cols) {
+            indptr[c] = (long long)nt;
+            continue;
+        }
+        const uint32_t r = col_rank[c];
+        uint64_t lo = 0, hi = nt;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (t_bc[mid] < r) lo = mid + 1; else hi = mid;
+        }
+        indptr[c] = (long long)lo;
+    }
+    for (uint64_t i = tid; i < nt; i += stride) {
+        indices[i] = (int32_t)t_feat[i];
+        data[i] = (int32_t)t_cnt[i];
+    }
+}
+
+struct MatrixDevImpl {
+    crgpu_matrix_dev view;
+    uint32_t *d_rank = nullptr;
+    long long *d_indptr = nullptr;
+    int32_t *d_indices = nullptr, *d_data = nullptr;
+};
+
+extern "C" int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, const uint32_t *d_feature,
+                                         const uint32_t *d_count, uint64_t n_triplets, crgpu_matrix_dev **out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    *out = nullptr;
+    CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_assemble_matrix_dev: no whitelist set");
+    CR_REQUIRE(ctx, n_triplets == 0 || (d_bc && d_feature && d_count), CRGPU_EINVAL, "NULL triplets");
+    CR_REQUIRE(ctx, n_triplets < 0xFFFFFFFFull, CRGPU_ERANGE, "too many triplets");
+    SeenFlag seen;
+    seen.ct.n = 0;
+    for (int l = 0; l < CRGPU_MAX_LIB; l++)
+        if (ctx->wl[l].set) {
+            seen.ct.t[seen.ct.n++] = ctx->wl[l].d_valid;
+            seen.ct.t[seen.ct.n++] = ctx->wl[l].d_corrected;
+        }
+    MatrixDevImpl *m = new (std::nothrow) MatrixDevImpl();
+    if (!m) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
+    struct Guard {
+        crgpu_ctx *c;
+        MatrixDevImpl *m;
+        bool armed = true;
+        ~Guard() {
+            if (armed) crgpu_matrix_dev_free(c, &m->view);
+        }
+    } guard{ctx, m};
+    const uint32_t W = ctx->n_canon;
+    CR_HIP(ctx, hipMalloc((void **)&m->d_rank, (size_t)W * sizeof(uint32_t)));
+    uint32_t *d_total = ctx->d_scalars + 16;
+    uint32_t V = 0;
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX);
+        CR_TRY(compact(ctx, seen, EmitCol{m->d_rank}, W, ctx->d_sort_hist, d_total));
+    }
+    CR_TRY(read_u32(ctx, d_total, &V));
+    CR_HIP(ctx, hipMalloc((void **)&m->d_indptr, ((size_t)V + 1) * sizeof(long long)));
+    CR_HIP(ctx, hipMalloc((void **)&m->d_indices, (n_triplets ? n_triplets : 1) * sizeof(int32_t)));
+    CR_HIP(ctx, hipMalloc((void **)&m->d_data, (n_triplets ? n_triplets : 1) * sizeof(int32_t)));
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX);
+        const uint64_t work = n_triplets > V ? n_triplets : (uint64_t)V + 1;
+        hipLaunchKernelGGL(k_csc, dim3(cr_grid(work, 256)), dim3(256), 0, ctx->stream, m->d_rank, (uint64_t)V, d_bc, d_feature,
+                           d_count, n_triplets, m->d_indptr, m->d_indices, m->d_data);
+        CR_HIP(ctx, hipGetLastError());
+    }
+    m->view.n_barcodes = V;
+    m->view.nnz = n_triplets;
+    m->view.d_barcode_rank = m->d_rank;
+    m->view.d_indptr = (const int64_t *)m->d_indptr;
+    m->view.d_indices = m->d_indices;
+    m->view.d_data = m->d_data;
+    guard.armed = false;
+    *out = &m->view;
+    return CRGPU_OK;
+}
+
+extern "C" void crgpu_matrix_dev_free(crgpu_ctx *ctx, crgpu_matrix_dev *mv) {
+    if (!mv) return;
+    MatrixDevImpl *m = reinterpret_cast<MatrixDevImpl *>(mv);  // view is the first member
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(m->d_rank);
+    (void)hipFree(m->d_indptr);
+    (void)hipFree(m->d_indices);
+    (void)hipFree(m->d_data);
+    delete m;
+}
+
+extern "C" int crgpu_matrix_dev_download(crgpu_ctx *ctx, const crgpu_matrix_dev *mv, uint32_t *rank_out, int64_t *indptr_out,
+                                         int32_t *indices_out, int32_t *data_out) {
+    if (!ctx || !mv) return CRGPU_EINVAL;
+    if (rank_out) CR_TRY(crgpu_memcpy_d2h(ctx, rank_out, mv->d_barcode_rank, mv->n_barcodes * sizeof(uint32_t)));
+    if (indptr_out) CR_TRY(crgpu_memcpy_d2h(ctx, indptr_out, mv->d_indptr, (mv->n_barcodes + 1) * sizeof(int64_t)));
+    if (indices_out) CR_TRY(crgpu_memcpy_d2h(ctx, indices_out, mv->d_indices, mv->nnz * sizeof(int32_t)));
+    if (data_out) CR_TRY(crgpu_memcpy_d2h(ctx, data_out, mv->d_data, mv->nnz * sizeof(int32_t)));
     return CRGPU_OK;
 }
 

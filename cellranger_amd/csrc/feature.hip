@@ -140,7 +140,7 @@ extern "C" int crgpu_match_features_dev(crgpu_ctx *ctx, int pattern, const uint3
     CR_HIP(ctx, hipMemcpyAsync(d_pe, pe, sizeof(pe), hipMemcpyHostToDevice, ctx->stream));
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pe is a stack buffer
     PatView v{P.d_seq, P.d_index, P.has_dist ? P.d_dist : nullptr, P.n, P.len};
-    CrTimer t(ctx, CRGPU_T_MATCH);
+    CrTimer t(ctx, CRGPU_T_MATCH, n);
     hipLaunchKernelGGL(k_match_features, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, v, d_pe, d_seq, d_qualn, n,
                        d_feature_out);
     CR_HIP(ctx, hipGetLastError());

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(uint32_t *__restrict__ data
 }
 
 int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_total_out) {
+    CrTimer t(ctx, CRGPU_T_SCAN);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, d_data, n, d_total_out);
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
@@ -59,12 +60,13 @@ int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_tota
 
 // ---- digit extraction -------------------------------------------------------------------------
 // mode 0: (key >> shift) & mask           (radix pass)
-// mode 1: ((key >> shift) % mod)           (owner rank of the barcode, crgpu_partition_keys_dev)
+// mode 1: ((key >> shift) / width)         (owner rank of the barcode, crgpu_partition_keys_dev:
+//                                           contiguous barcode-rank ranges, like shardio's make_chunks)
 struct DigitFn {
-    uint32_t shift, mask, mod, mode;
+    uint32_t shift, mask, width, mode;
     __device__ __forceinline__ uint32_t operator()(uint64_t key) const {
         const uint64_t v = key >> shift;
-        return mode == 0 ? (uint32_t)(v & mask) : (uint32_t)(v % mod);
+        return mode == 0 ? (uint32_t)(v & mask) : (uint32_t)(v / width);
     }
 };
 
@@ -179,8 +181,12 @@ static int radix_pass(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, con
                       uint64_t n, DigitFn dig, uint32_t *d_hist) {
     uint64_t tile;
     const uint32_t nb = sort_blocks(n, &tile);
-    hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
+    {
+        CrTimer t(ctx, CRGPU_T_SORT_HIST, n);
+        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
+    }
     CR_TRY(cr_scan_small(ctx, d_hist, (uint64_t)RADIX * nb, nullptr));
+    CrTimer t(ctx, CRGPU_T_SORT, n);
     if (d_vin)
         hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout, n,
                            tile, dig, d_hist, nb);
@@ -227,7 +233,9 @@ int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
     uint64_t tile;
     const uint32_t nb = sort_blocks(n, &tile);
     uint32_t *d_hist = ctx->d_sort_hist;
-    DigitFn dig{sh_bc, 0u, n_ranks, 1u};
+    // rank r owns canonical barcode ranks [r*width, (r+1)*width)
+    const uint32_t width = (ctx->n_canon + n_ranks - 1) / n_ranks;
+    DigitFn dig{sh_bc, 0u, width ? width : 1u, 1u};
     int rc = radix_pass(ctx, d_in, d_out, nullptr, nullptr, n, dig, d_hist);
     // after the scan d_hist[d*nb + 0] is the start of digit d: counts = differences
     std::vector<uint32_t> starts(RADIX);

@@ -62,7 +62,7 @@ extern "C" int crgpu_synth_dev(crgpu_ctx *ctx, const crgpu_synth_params *p, uint
         if ((rc = to_dev(ctx, p->ambient_wl_pos, p->n_ambient, &dp.ambient_wl_pos, owned))) break;
         if ((rc = to_dev(ctx, p->gene_cdf, p->n_genes, &dp.gene_cdf, owned))) break;
         {
-            CrTimer t(ctx, CRGPU_T_SYNTH);
+            CrTimer t(ctx, CRGPU_T_SYNTH, n);
             hipLaunchKernelGGL(k_synth, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, dp, first, n, *d_out);
         }
         if (hipGetLastError() != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "k_synth launch failed");

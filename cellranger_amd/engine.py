@@ -155,6 +155,32 @@ class Matrix:
             pass
 
 
+class MatrixDev:
+    """crgpu_matrix_dev: device-resident CSC (barcode_rank, indptr, indices, data)."""
+
+    def __init__(self, ctx, mv_ptr):
+        self.ctx, self._mv = ctx, mv_ptr
+        self.n_barcodes, self.nnz = int(mv_ptr.contents.n_barcodes), int(mv_ptr.contents.nnz)
+
+    def download(self):
+        V, nnz = self.n_barcodes, self.nnz
+        rank, indptr = np.zeros(V, np.uint32), np.zeros(V + 1, np.int64)
+        indices, data = np.zeros(nnz, np.int32), np.zeros(nnz, np.int32)
+        self.ctx._check(self.ctx.L.crgpu_matrix_dev_download(self.ctx.h, self._mv, ptr(rank), ptr(indptr), ptr(indices), ptr(data)))
+        return rank, indptr, indices, data
+
+    def free(self):
+        if self._mv is not None and self.ctx.h:
+            self.ctx.L.crgpu_matrix_dev_free(self.ctx.h, self._mv)
+        self._mv = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Counts:
     """crgpu_counts: sorted (barcode, feature, count) triplets + the molecule table."""
 
@@ -251,8 +277,9 @@ class Context:
     def timing_get(self):
         ms = np.zeros(len(_lib.T_NAMES), np.float64)
         ln = np.zeros(len(_lib.T_NAMES), np.uint64)
-        self._check(self.L.crgpu_timing_get(self.h, ptr(ms), ptr(ln)))
-        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(_lib.T_NAMES)}
+        un = np.zeros(len(_lib.T_NAMES), np.uint64)
+        self._check(self.L.crgpu_timing_get(self.h, ptr(ms), ptr(ln), ptr(un)))
+        return {k: (float(ms[i]), int(ln[i]), int(un[i])) for i, k in enumerate(_lib.T_NAMES)}
 
     # ---- whitelist ------------------------------------------------------------------------------
     def set_whitelist(self, lib, keys, canon=None, translate_to=None, length=None):
@@ -365,6 +392,11 @@ class Context:
         mv = C.POINTER(MatrixView)()
         self._check(self.L.crgpu_assemble_matrix(self.h, ptr(bc), ptr(ft), ptr(ct), len(bc), n_features, C.byref(mv)))
         return Matrix(self, mv)
+
+    def assemble_matrix_dev(self, d_bc, d_feature, d_count, n_triplets):
+        mv = C.POINTER(_lib.MatrixDevView)()
+        self._check(self.L.crgpu_assemble_matrix_dev(self.h, _p(d_bc), _p(d_feature), _p(d_count), n_triplets, C.byref(mv)))
+        return MatrixDev(self, mv)
 
     def count(self, recs, n_features):
         mv = C.POINTER(MatrixView)()

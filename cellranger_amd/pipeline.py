@@ -1,0 +1,202 @@
+"""Host orchestration of one GEM well across the GPUs of a node.
+
+One process per GPU.  Reads are sharded; the path has three real exchange steps, issued through
+torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests):
+
+  C1  all-reduce(sum) of the per-library valid-barcode histogram  -> the corrector's GLOBAL prior
+      (make_shard.rs:343-358 join -> barcode_correction.rs:295-325)
+  C2  all-to-all of 64-bit molecule keys by barcode range          -> every barcode's reads on one GPU
+      (the reference gets this from barcode-sorted shards + make_chunks, align_and_count.rs:505-524)
+  C3  gather of the disjoint (barcode, feature, count) triplets    -> rank 0 assembles the CSC matrix
+
+The compute calls go through a backend object.  `HipBackend` is the product (libcrgpu via the C ABI,
+no CPU fallback).  The tests drive the same orchestration with an oracle-backed stand-in under gloo.
+"""
+import numpy as np
+
+from . import engine as E
+from ._lib import COUNTS_CORRECTED, COUNTS_VALID
+
+
+class _DevView:
+    """Alias of a device allocation with a torch-friendly dtype (for collectives)."""
+
+    def __init__(self, ptr, shape, typestr, owner=None):
+        self.ptr, self.shape, self.typestr, self.owner = ptr, tuple(shape), typestr, owner
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.typestr, "data": (self.ptr, False), "version": 2}
+
+
+class HipBackend:
+    """Compute backend = libcrgpu on one MI355X.  Tensors handed to collectives alias device memory."""
+
+    def __init__(self, ctx, device_index=0):
+        self.ctx = ctx
+        self.device_index = device_index
+        self._keep = []
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _tensor(self, ptr, n, typestr):
+        import torch
+
+        if n == 0:
+            dt = {"<i4": torch.int32, "<i8": torch.int64}[typestr]
+            return torch.empty(0, dtype=dt, device="cuda:%d" % self.device_index)
+        return torch.as_tensor(_DevView(ptr, (n,), typestr), device="cuda:%d" % self.device_index)
+
+    def before_collective(self):
+        self.ctx.synchronize()
+
+    def after_collective(self):
+        import torch
+
+        torch.cuda.synchronize(self.device_index)
+
+    # -- barcode stage --------------------------------------------------------------------------------
+    def reset(self):
+        self.ctx.reset_counts()
+        self._keep = []
+
+    def libs(self):
+        return self._libs
+
+    def set_libs(self, libs):
+        self._libs = list(libs)
+
+    def match_and_count(self, shard):
+        self.ctx.match_and_count(shard["cb"], shard.get("flags"), shard["n"], shard["idx"])
+
+    def hist_tensor(self, lib, which):
+        return self._tensor(self.ctx.counts_dev(lib, which), self.ctx.n_canon, "<i4")
+
+    def correct(self, shard):
+        self.ctx.correct(shard["cb"], shard["cb_qualn"], shard.get("flags"), shard["n"], shard["idx"], shard.get("corrected"))
+
+    # -- count stage ------------------------------------------------------------------------------------
+    def build_keys(self, shard):
+        recs = self.ctx.records(shard["n"], shard["umi_len"], shard["idx"], shard["umi"], shard["umi_qualn"],
+                                shard["feature"], shard.get("flags"))
+        keys = shard.get("keys")
+        if keys is None:
+            keys = self.ctx.empty(max(shard["n"], 1), np.uint64)
+            self._keep.append(keys)
+        n_keys = self.ctx.build_keys(recs, keys)
+        return keys, n_keys
+
+    def partition(self, keys, n_keys, n_ranks):
+        out = self.ctx.empty(max(n_keys, 1), np.uint64)
+        self._keep.append(out)
+        counts = self.ctx.partition_keys(keys, n_keys, n_ranks, out)
+        return out, [int(x) for x in counts]
+
+    def keys_tensor(self, keys, n_keys):
+        return self._tensor(keys.ptr, n_keys, "<i8")
+
+    def alloc_keys(self, n):
+        k = self.ctx.empty(max(n, 1), np.uint64)
+        self._keep.append(k)
+        return k
+
+    def count_keys(self, keys, n_keys):
+        counts = self.ctx.count_keys(keys, n_keys)
+        self._keep.append(counts)
+        return counts
+
+    def triplet_tensors(self, counts):
+        b, f, c = counts.triplets_dev()
+        n = counts.n_triplets
+        return self._tensor(b, n, "<i4"), self._tensor(f, n, "<i4"), self._tensor(c, n, "<i4")
+
+    def alloc_triplets(self, n):
+        arrs = [self.ctx.empty(max(n, 1), np.uint32) for _ in range(3)]
+        self._keep.extend(arrs)
+        return arrs, [self._tensor(a.ptr, n, "<i4") for a in arrs]
+
+    def assemble(self, d_bc, d_feature, d_count, n_triplets):
+        m = self.ctx.assemble_matrix_dev(d_bc, d_feature, d_count, n_triplets)
+        self._keep.append(m)
+        return m
+
+
+class CountPipeline:
+    """barcode-correct -> UMI-dedup -> matrix for one shard of reads per rank."""
+
+    def __init__(self, backend, libs=(0,), dist=None):
+        self.be = backend
+        self.libs = list(libs)
+        self.dist = dist  # torch.distributed module (initialised) or None for a single process
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+
+    # -- collectives -------------------------------------------------------------------------------------
+    def _allreduce_hist(self, which):
+        if self.world == 1:
+            return
+        self.be.before_collective()
+        for lib in self.libs:
+            t = self.be.hist_tensor(lib, which)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.be.after_collective()
+
+    def _all_to_all_keys(self, keys, n_keys):
+        """C2: returns (keys buffer, n) holding every key of the barcode range this rank owns."""
+        import torch
+
+        part, send_counts = self.be.partition(keys, n_keys, self.world)
+        self.be.before_collective()
+        dev = self.be.keys_tensor(part, n_keys).device
+        send_t = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        recv_t = torch.empty(self.world, dtype=torch.int64, device=dev)
+        self.dist.all_to_all_single(recv_t, send_t)
+        recv_counts = [int(x) for x in recv_t.tolist()]
+        n_recv = sum(recv_counts)
+        recv = self.be.alloc_keys(n_recv)
+        self.dist.all_to_all_single(self.be.keys_tensor(recv, n_recv), self.be.keys_tensor(part, n_keys),
+                                    output_split_sizes=recv_counts, input_split_sizes=send_counts)
+        self.be.after_collective()
+        return recv, n_recv
+
+    def _gather_triplets(self, counts):
+        """C3: rank 0 receives every rank's triplets, concatenated in rank order (== barcode order)."""
+        import torch
+
+        tb, tf, tc = self.be.triplet_tensors(counts)
+        n = int(tb.numel())
+        self.be.before_collective()
+        sizes = torch.zeros(self.world, dtype=torch.int64, device=tb.device)
+        mine = torch.tensor([n], dtype=torch.int64, device=tb.device)
+        self.dist.all_gather_into_tensor(sizes, mine)
+        sizes = [int(x) for x in sizes.tolist()]
+        total = sum(sizes) if self.rank == 0 else 0
+        arrs, outs = self.be.alloc_triplets(total)
+        in_splits = [n] + [0] * (self.world - 1)
+        out_splits = sizes if self.rank == 0 else [0] * self.world
+        for src, dst in zip((tb, tf, tc), outs):
+            self.dist.all_to_all_single(dst, src, output_split_sizes=out_splits, input_split_sizes=in_splits)
+        self.be.after_collective()
+        return arrs, total
+
+    # -- the step ---------------------------------------------------------------------------------------
+    def correct_barcodes(self, shard):
+        """cfg2: pass A + C1 + pass B.  shard['idx'] receives the corrected barcode ranks."""
+        self.be.match_and_count(shard)
+        self._allreduce_hist(COUNTS_VALID)
+        self.be.correct(shard)
+
+    def run(self, shard):
+        """Full path.  Returns the device CSC on rank 0 (None elsewhere)."""
+        self.correct_barcodes(shard)
+        self._allreduce_hist(COUNTS_CORRECTED)   # matrix columns = barcodes seen on ANY rank
+        keys, n_keys = self.be.build_keys(shard)
+        if self.world > 1:
+            keys, n_keys = self._all_to_all_keys(keys, n_keys)
+        counts = self.be.count_keys(keys, n_keys)
+        if self.world == 1:
+            b, f, c = counts.triplets_dev() if hasattr(counts, "triplets_dev") else self.be.triplet_ptrs(counts)
+            return self.be.assemble(b, f, c, counts.n_triplets)
+        arrs, total = self._gather_triplets(counts)
+        if self.rank != 0:
+            return None
+        return self.be.assemble(arrs[0], arrs[1], arrs[2], total)

@@ -80,15 +80,18 @@ int crgpu_memset(crgpu_ctx *ctx, void *d_dst, int value, uint64_t bytes);
 #define CRGPU_T_MATCH 1       /* K1 exact match + histogram */
 #define CRGPU_T_CORRECT 2     /* K2 posterior correction */
 #define CRGPU_T_KEYS 3        /* key building / compaction */
-#define CRGPU_T_SORT 4        /* radix sort passes */
+#define CRGPU_T_SORT 4        /* radix sort: stable scatter kernel (one span per pass) */
 #define CRGPU_T_DEDUP 5       /* run-length, UMI correction, low support, counting */
 #define CRGPU_T_MATRIX 6      /* CSC assembly */
 #define CRGPU_T_SYNTH 7       /* synthetic data generation */
-#define CRGPU_T_NSLOTS 8
+#define CRGPU_T_SORT_HIST 8   /* radix sort: digit histogram kernel (one span per pass) */
+#define CRGPU_T_SCAN 9        /* small scans of block histograms / block counts */
+#define CRGPU_T_NSLOTS 10
 int crgpu_timing_enable(crgpu_ctx *ctx, int on);
 int crgpu_timing_reset(crgpu_ctx *ctx);
-/* ms_out[CRGPU_T_NSLOTS], launches_out[CRGPU_T_NSLOTS] (either may be NULL); synchronises. */
-int crgpu_timing_get(crgpu_ctx *ctx, double *ms_out, uint64_t *launches_out);
+/* ms_out / launches_out / units_out [CRGPU_T_NSLOTS] (any may be NULL); synchronises.  units = the
+ * elements (reads or keys) the timed launches of a slot processed. */
+int crgpu_timing_get(crgpu_ctx *ctx, double *ms_out, uint64_t *launches_out, uint64_t *units_out);
 
 /* ---- whitelist ---------------------------------------------------------------------------------
  * Replaces Whitelist::construct / WhitelistSource::as_whitelist (barcode/src/whitelist.rs:313-330,
@@ -183,8 +186,10 @@ int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_t umi_len, 
                          uint32_t multiplexing_lib_mask);
 int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out,
                          uint64_t *n_keys_out);
-/* owner rank of a key's barcode for the all-to-all (bc rank % n_ranks).  Partition d_keys (n) into
- * n_ranks contiguous groups in d_keys_out; counts_out[r] = keys owned by rank r (host). */
+/* owner rank of a key's barcode for the all-to-all: rank r owns the contiguous canonical-rank range
+ * [r*w, (r+1)*w), w = ceil(n_canon / n_ranks) -- barcode-range chunks like shardio's make_chunks
+ * (align_and_count.rs:505-524).  Stable partition of d_keys (n) into n_ranks contiguous groups in
+ * d_keys_out; counts_out[r] = keys owned by rank r (host). */
 int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n, uint32_t n_ranks,
                              uint64_t *d_keys_out, uint64_t *counts_out);
 
@@ -229,6 +234,24 @@ void crgpu_matrix_free(crgpu_ctx *ctx, crgpu_matrix *m);
  * metadata_line is the full "%metadata_json: ..." line.  gem_group suffixes barcodes.tsv rows. */
 int crgpu_write_mtx(crgpu_ctx *ctx, const crgpu_matrix *m, const char *metadata_line, const char *mtx_path,
                     const char *barcodes_tsv_path, uint16_t gem_group);
+
+/* The same assembly on the device: triplets (device arrays, sorted by (barcode rank, feature), unique
+ * pairs -- what crgpu_count_keys_dev emits; per-rank outputs concatenated in rank order stay sorted
+ * because crgpu_partition_keys_dev gives each rank a contiguous barcode range).  Library-owned. */
+typedef struct {
+    uint64_t n_barcodes;            /* V */
+    uint64_t nnz;
+    const uint32_t *d_barcode_rank; /* V canonical ranks, ascending */
+    const int64_t *d_indptr;        /* V + 1 */
+    const int32_t *d_indices;       /* nnz */
+    const int32_t *d_data;          /* nnz */
+} crgpu_matrix_dev;
+int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, const uint32_t *d_feature, const uint32_t *d_count,
+                              uint64_t n_triplets, crgpu_matrix_dev **out);
+void crgpu_matrix_dev_free(crgpu_ctx *ctx, crgpu_matrix_dev *m);
+/* copy to caller-allocated host arrays (any may be NULL) */
+int crgpu_matrix_dev_download(crgpu_ctx *ctx, const crgpu_matrix_dev *m, uint32_t *rank_out, int64_t *indptr_out,
+                              int32_t *indices_out, int32_t *data_out);
 
 /* one-call convenience (single GPU): build keys -> dedup -> matrix */
 int crgpu_count(crgpu_ctx *ctx, const crgpu_records *recs, uint32_t n_features, crgpu_matrix **out);

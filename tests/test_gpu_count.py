@@ -59,13 +59,16 @@ def test_radix_sort_matches_numpy():
     """The ballot-multisplit LSD sort, exercised through partition + count on raw keys."""
     import gpu_helpers as G
 
+    from cellranger_amd import synth as S
+
     c = G.fresh_ctx()
-    c.set_whitelist_ascii(0, ["ACGTACGTACGTACGT", "TTTTACGTACGTACGT", "GGGGACGTACGTACGT"])
+    w = S.Workload(n_total=1000, seed=1, n_wl=1000, n_cells=10, n_ambient=10)
+    c.set_whitelist(0, w.wl_packed, length=16)
     c.set_key_layout(1000, 12, 1, 0)
     rng = np.random.default_rng(1)
-    # keys: [bc 2 bits][feature 10][umi 24][1]
+    # keys: [bc 10 bits][feature 10][umi 24][1]
     n = 300_000
-    bc = rng.integers(0, 3, n).astype(np.uint64)
+    bc = rng.integers(0, 1000, n).astype(np.uint64)
     ft = rng.integers(0, 1000, n).astype(np.uint64)
     umi = rng.integers(0, 1 << 24, n).astype(np.uint64)
     keys = (bc << np.uint64(35)) | (ft << np.uint64(25)) | (umi << np.uint64(1))
@@ -73,7 +76,8 @@ def test_radix_sort_matches_numpy():
     for n_ranks in (1, 2, 3, 8):
         cnt = c.partition_keys(d_in, n, n_ranks, d_out)
         out = d_out.to_host()
-        owner = (keys >> np.uint64(35)) % np.uint64(n_ranks)
+        width = (1000 + n_ranks - 1) // n_ranks     # contiguous barcode-rank ranges
+        owner = (keys >> np.uint64(35)) // np.uint64(width)
         exp = np.concatenate([keys[owner == r] for r in range(n_ranks)])  # stable
         assert np.array_equal(out, exp)
         assert list(cnt) == [int((owner == r).sum()) for r in range(n_ranks)]
