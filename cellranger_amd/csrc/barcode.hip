@@ -9,6 +9,7 @@
 // f64 multiply and the running sum are never fused (the reference's rustc flags have no +fma,
 // lib/rust/.cargo/config.toml:5-8).
 #include "common.h"
+#include "block_utils.h"
 #include "wl_view.h"
 
 int cr_make_views(crgpu_ctx *ctx, WlView *views);
@@ -143,21 +144,26 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
 // ------------------------------------------------------------------------------------------------
 // K2: posterior correction of the reads that missed
 // ------------------------------------------------------------------------------------------------
+#define MISS_ITEMS 8
+// Compact the indices of the reads that missed.  One global atomic per 2048-read chunk: a single hot
+// counter serialises, so the reservation is aggregated over the whole workgroup.
 __global__ __launch_bounds__(256) void k_collect_miss(const uint32_t *__restrict__ idx, uint64_t n,
-                                                      uint32_t *__restrict__ miss_list, uint32_t *__restrict__ n_miss) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    // every lane of a wave runs the same number of iterations so the ballot is well defined
-    const uint64_t n_round = (n + stride - 1) / stride * stride;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        const bool miss = i < n && idx[i] == CRGPU_MISS;
-        const unsigned long long m = __ballot(miss);
-        if (m) {
-            uint32_t base = 0;
-            if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(n_miss, (uint32_t)__popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1);
-            if (miss) miss_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+                                                      uint32_t *__restrict__ miss_list,
+                                                      unsigned long long *__restrict__ n_miss) {
+    __shared__ __attribute__((aligned(8))) uint32_t lds[10];
+    const uint64_t chunk = 256ull * MISS_ITEMS;
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int j = 0; j < MISS_ITEMS; j++) {
+            const uint64_t i = c * chunk + (uint64_t)j * 256 + threadIdx.x;
+            if (i < n && idx[i] == CRGPU_MISS) mask |= 1u << j;
         }
+        unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_miss, lds);
+#pragma unroll
+        for (int j = 0; j < MISS_ITEMS; j++)
+            if (mask & (1u << j)) miss_list[o++] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);
     }
 }
 
@@ -174,11 +180,11 @@ template <bool UNIFORM>
 __global__ __launch_bounds__(256) void k_correct(const WlViewSet vs, const uint32_t *__restrict__ cb,
                                                  const uint8_t *__restrict__ qualn, const uint8_t *__restrict__ flags,
                                                  const uint32_t *__restrict__ miss_list,
-                                                 const uint32_t *__restrict__ n_miss_ptr, uint32_t len,
+                                                 const unsigned long long *__restrict__ n_miss_ptr, uint32_t len,
                                                  const double *__restrict__ ptab, double max_expected, double thresh,
                                                  bool check_expected,
                                                  uint32_t *__restrict__ idx_inout, uint8_t *__restrict__ corrected_out) {
-    const uint32_t n_miss = *n_miss_ptr;
+    const uint32_t n_miss = (uint32_t)*n_miss_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_miss; j += stride) {
         const uint64_t i = miss_list[j];
@@ -308,9 +314,9 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
     void *ws;
     CR_TRY(cr_scratch(ctx, n * sizeof(uint32_t), &ws));
     uint32_t *miss_list = (uint32_t *)ws;
-    uint32_t *n_miss = ctx->d_scalars;
+    unsigned long long *n_miss = (unsigned long long *)ctx->d_scalars;
     CrTimer t(ctx, CRGPU_T_CORRECT, n);
-    CR_HIP(ctx, hipMemsetAsync(n_miss, 0, sizeof(uint32_t), ctx->stream));
+    CR_HIP(ctx, hipMemsetAsync(n_miss, 0, sizeof(unsigned long long), ctx->stream));
     if (d_corrected_out) CR_HIP(ctx, hipMemsetAsync(d_corrected_out, 0, n, ctx->stream));
     hipLaunchKernelGGL(k_collect_miss, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_idx_inout, n, miss_list, n_miss);
     // K2 is launched for the worst case and loops over the device-side count: no host round trip

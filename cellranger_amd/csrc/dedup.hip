@@ -18,6 +18,7 @@
 //   * a (barcode, feature) segment is one matrix entry.
 // Low-support grouping needs (barcode, library, UMI) across features: a second sort of the
 // DISTINCT keys on [barcode][library][UMI][feature] with the distinct-key index as payload.
+#include "block_utils.h"
 #include "common.h"
 
 int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_total_out);
@@ -73,16 +74,22 @@ __device__ __forceinline__ uint64_t lowmask(uint32_t bits) { return bits >= 64 ?
 // ------------------------------------------------------------------------------------------------
 // build keys (compacting)
 // ------------------------------------------------------------------------------------------------
+#define KEY_ITEMS 4
 __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t *__restrict__ bc_idx,
                                                     const uint32_t *__restrict__ umi, const uint8_t *__restrict__ umi_q,
                                                     const uint32_t *__restrict__ feature, const uint8_t *__restrict__ flags,
                                                     uint64_t n, uint64_t *__restrict__ keys_out,
                                                     unsigned long long *__restrict__ n_out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t n_round = (n + stride - 1) / stride * stride;
+    __shared__ __attribute__((aligned(8))) uint32_t lds[10];
     const uint32_t L = kl.umi_len;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const uint64_t chunk = 256ull * KEY_ITEMS;
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+      uint64_t keys[KEY_ITEMS];
+      uint32_t mask = 0;
+#pragma unroll
+      for (int j = 0; j < KEY_ITEMS; j++) {
+        const uint64_t i = c * chunk + (uint64_t)j * 256 + threadIdx.x;
         bool keep = false;
         uint64_t key = 0;
         if (i < n) {
@@ -94,10 +101,21 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                 const uint32_t u = umi[i] & (uint32_t)lowmask(kl.bits_umi);
                 // UmiInfo::new (umi/src/info.rs:20-37)
                 bool has_n = false, low_q = false;
-                for (uint32_t k = 0; k < L; k++) {
-                    const uint32_t q = umi_q[i * L + k];
-                    has_n |= (q & 0x80u) != 0u;
-                    low_q |= (uint8_t)((q & 0x7Fu) - 33u) < 10u;  // u8 wrapping subtraction, UMI_MIN_QV = 10
+                if ((L & 3u) == 0u) {
+                    // rows of 4k bytes are dword aligned: k dword loads instead of 4k byte loads
+                    const uint32_t *qw = reinterpret_cast<const uint32_t *>(umi_q + i * L);
+                    for (uint32_t k = 0; k < (L >> 2); k++) {
+                        const uint32_t w = qw[k];
+                        has_n |= (w & 0x80808080u) != 0u;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) low_q |= (uint8_t)(((w >> (8 * b)) & 0x7Fu) - 33u) < 10u;
+                    }
+                } else {
+                    for (uint32_t k = 0; k < L; k++) {
+                        const uint32_t q = umi_q[i * L + k];
+                        has_n |= (q & 0x80u) != 0u;
+                        low_q |= (uint8_t)((q & 0x7Fu) - 33u) < 10u;  // u8 wrapping subtraction, UMI_MIN_QV = 10
+                    }
                 }
                 // is_homopolymer: every adjacent pair equal (true for a 1-base UMI)
                 const uint32_t adj = (u ^ (u >> 2)) & (uint32_t)lowmask(kl.bits_umi - 2u);
@@ -109,14 +127,14 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                 }
             }
         }
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            unsigned long long base = 0;
-            if ((int)lane == leader) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
-            base = __shfl(base, leader);
-            if (keep) keys_out[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = key;
-        }
+        keys[j] = key;
+        if (keep) mask |= 1u << j;
+      }
+      // one global atomic per 1024-read chunk (a single hot counter serialises at the memory side)
+      unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_out, lds);
+#pragma unroll
+      for (int j = 0; j < KEY_ITEMS; j++)
+        if (mask & (1u << j)) keys_out[o++] = keys[j];
     }
 }
 
@@ -130,6 +148,8 @@ extern "C" int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, u
     if (recs->n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, recs->d_bc_idx && recs->d_umi && recs->d_umi_qualn && recs->d_feature && d_keys_out, CRGPU_EINVAL,
                "crgpu_build_keys: NULL buffer");
+    CR_REQUIRE(ctx, (recs->umi_len & 3u) != 0u || (uintptr_t)recs->d_umi_qualn % 4 == 0, CRGPU_EINVAL,
+               "crgpu_build_keys: the UMI quality buffer must be 4-byte aligned");
     unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
     {
         CrTimer t(ctx, CRGPU_T_KEYS, recs->n);

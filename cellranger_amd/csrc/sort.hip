@@ -1,52 +1,56 @@
 // sort.hip -- LSD radix sort of 64-bit molecule keys (optionally with a 32-bit payload) built on
-// wave64 ballot multisplit, plus the small device-wide scan used by the sort and the compactions.
+// wave64 ballot multisplit, plus the small device-wide scan used by the compactions.
 //
 // This is the "sort" the reference gets from shardio's sorted shards + std HashMap grouping
 // (cr_lib/src/barcode_sort.rs:97-162, par_proc.rs:131-152); integer work, HBM bound: every pass
 // streams the keys once for the digit histogram and once for the scatter.
+//
+// One pass = 3 launches:
+//   k_radix_hist     per-block digit histogram           -> block_hist[digit][block]
+//   k_scan_digits    one workgroup per digit: exclusive scan over blocks + digit total
+//   k_radix_scatter  stable scatter; each block derives its digit bases from the digit totals
+#include "block_utils.h"
 #include "common.h"
 
 #define SORT_BLOCK 256
-#define SORT_ITEMS 8                      // keys per thread per chunk
+#define SORT_ITEMS 8  // keys per thread per chunk
 #define SORT_CHUNK (SORT_BLOCK * SORT_ITEMS)
 #define SORT_WAVES (SORT_BLOCK / 64)
 #define RADIX_BITS 8
 #define RADIX 256
+#define SORT_MAX_BLOCKS 2048
 
-// ---- exclusive scan of a small u32 array (block histograms / block counts), single workgroup ----
+// ---- exclusive scan of a small u32 array (block counts of the compactions), single workgroup -----
 __global__ __launch_bounds__(1024) void k_scan_small(uint32_t *__restrict__ data, uint64_t n,
                                                      uint32_t *__restrict__ total_out) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t lo = (uint64_t)tid * per, hi = lo + per < n ? lo + per : n;
-    uint32_t sum = 0;
-    for (uint64_t i = lo; i < hi; i++) sum += data[i];
-    // inclusive scan of `sum` across the block
-    uint32_t x = sum;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    // coalesced rounds of 1024 elements with a running carry
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + tid;
+        const uint32_t v = i < n ? data[i] : 0u;
+        uint32_t x = v;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    if (lane == 63) wave_sums[wave] = x;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t c = 0;
-        for (int w = 0; w < 16; w++) {
-            const uint32_t t = wave_sums[w];
-            wave_sums[w] = c;
-            c += t;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
         }
-        carry_s = c;
-    }
-    __syncthreads();
-    uint32_t run = wave_sums[wave] + x - sum;  // exclusive prefix of this thread's segment
-    for (uint64_t i = lo; i < hi; i++) {
-        const uint32_t v = data[i];
-        data[i] = run;
-        run += v;
+        if (lane == 63) wave_sums[wave] = x;
+        __syncthreads();
+        uint32_t wpre = 0, tot = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            const uint32_t t = wave_sums[w];
+            if (w < wave) wpre += t;
+            tot += t;
+        }
+        const uint32_t carry = carry_s;
+        if (i < n) data[i] = carry + wpre + x - v;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tot;
+        __syncthreads();
     }
     if (tid == 0 && total_out) *total_out = carry_s;
 }
@@ -84,23 +88,46 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(const uint64_t *__res
     block_hist[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// ---- pass 2: stable scatter ------------------------------------------------------------------------
+// ---- pass 2: one workgroup per digit scans that digit's row of block counts ------------------------
+__global__ __launch_bounds__(256) void k_scan_digits(uint32_t *__restrict__ block_hist, uint32_t n_blocks,
+                                                     uint32_t *__restrict__ digit_totals) {
+    __shared__ uint32_t lds[8];
+    uint32_t *row = block_hist + (uint64_t)blockIdx.x * n_blocks;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_blocks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? row[i] : 0u;
+        uint32_t tot;
+        const uint32_t pre = block_excl_scan_256(v, lds, &tot);
+        if (i < n_blocks) row[i] = carry + pre;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) digit_totals[blockIdx.x] = carry;
+}
+
+// ---- pass 3: stable scatter ------------------------------------------------------------------------
 // Order inside a chunk: wave-major, then item, then lane, so a wave owns 64*SORT_ITEMS consecutive
-// keys.  Rank of a key = block_base[d] + (same-digit keys of earlier waves) + (same-digit keys of this
-// wave's earlier items) + (same-digit lanes below it), all from ballots and LDS counters.
+// keys.  Rank of a key = digit_base[d] + block_offs[d][block] + (same-digit keys of earlier chunks and
+// earlier waves) + (same-digit keys of this wave's earlier items) + (same-digit lanes below it),
+// all from ballots and LDS counters.
 template <bool HAS_VALS>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const uint64_t *__restrict__ keys_in,
                                                               uint64_t *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
                                                               uint32_t *__restrict__ vals_out, uint64_t n, uint64_t tile,
                                                               DigitFn dig, const uint32_t *__restrict__ block_offs,
+                                                              const uint32_t *__restrict__ digit_totals,
                                                               uint32_t n_blocks) {
     __shared__ uint32_t wcount[SORT_WAVES][RADIX];  // per-wave same-digit counts of the chunk
     __shared__ uint32_t base[RADIX];                // running output offset of each digit for this block
+    __shared__ uint32_t lds[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    base[tid] = block_offs[(uint64_t)tid * n_blocks + blockIdx.x];
+    {
+        const uint32_t digit_base = block_excl_scan_256(digit_totals[tid], lds, nullptr);
+        base[tid] = digit_base + block_offs[(uint64_t)tid * n_blocks + blockIdx.x];
+    }
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
 
@@ -120,6 +147,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const uint64_t *__
             const bool ok = i < hi;
             key[it] = ok ? keys_in[i] : 0ull;
             if (HAS_VALS) val[it] = ok ? vals_in[i] : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < SORT_ITEMS; it++) {
+            const uint64_t i = wave_base + (uint64_t)it * 64 + lane;
+            const bool ok = i < hi;
             const uint32_t d = ok ? dig(key[it]) : 0u;
             digit[it] = d;
             // lanes holding the same digit: intersect the 8 bit ballots
@@ -167,7 +199,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const uint64_t *__
 static uint32_t sort_blocks(uint64_t n, uint64_t *tile_out) {
     uint64_t nb = (n + SORT_CHUNK * 4 - 1) / (SORT_CHUNK * 4);
     if (nb < 1) nb = 1;
-    if (nb > 2048) nb = 2048;
+    if (nb > SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
     uint64_t tile = (n + nb - 1) / nb;
     tile = (tile + SORT_CHUNK - 1) / SORT_CHUNK * SORT_CHUNK;
     nb = (n + tile - 1) / tile;
@@ -176,23 +208,30 @@ static uint32_t sort_blocks(uint64_t n, uint64_t *tile_out) {
     return (uint32_t)nb;
 }
 
-// one counting-sort pass keyed by `dig` (stable).  d_hist: RADIX * n_blocks u32 workspace.
+static uint32_t *digit_totals_buf(crgpu_ctx *ctx) { return ctx->d_scalars + 256; }  // 256 u32 inside the scalar page
+
+// one counting-sort pass keyed by `dig` (stable).
 static int radix_pass(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, const uint32_t *d_vin, uint32_t *d_vout,
-                      uint64_t n, DigitFn dig, uint32_t *d_hist) {
+                      uint64_t n, DigitFn dig) {
     uint64_t tile;
     const uint32_t nb = sort_blocks(n, &tile);
+    uint32_t *d_hist = ctx->d_sort_hist;
+    uint32_t *d_tot = digit_totals_buf(ctx);
     {
         CrTimer t(ctx, CRGPU_T_SORT_HIST, n);
         hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
     }
-    CR_TRY(cr_scan_small(ctx, d_hist, (uint64_t)RADIX * nb, nullptr));
+    {
+        CrTimer t(ctx, CRGPU_T_SCAN);
+        hipLaunchKernelGGL(k_scan_digits, dim3(RADIX), dim3(256), 0, ctx->stream, d_hist, nb, d_tot);
+    }
     CrTimer t(ctx, CRGPU_T_SORT, n);
     if (d_vin)
         hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout, n,
-                           tile, dig, d_hist, nb);
+                           tile, dig, d_hist, d_tot, nb);
     else
         hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout, n,
-                           tile, dig, d_hist, nb);
+                           tile, dig, d_hist, d_tot, nb);
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
 }
@@ -204,14 +243,12 @@ int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_
     *result_in_tmp = false;
     if (n <= 1 || hi_bit <= lo_bit) return CRGPU_OK;
     CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "sort: at most 2^32-2 keys per call");
-    uint32_t *d_hist = ctx->d_sort_hist;
     uint64_t *in = d_keys, *out = d_tmp;
     uint32_t *vin = d_vals, *vout = d_vals_tmp;
-    int rc = CRGPU_OK;
-    for (uint32_t shift = lo_bit; shift < hi_bit && rc == CRGPU_OK; shift += RADIX_BITS) {
+    for (uint32_t shift = lo_bit; shift < hi_bit; shift += RADIX_BITS) {
         const uint32_t bits = hi_bit - shift < RADIX_BITS ? hi_bit - shift : RADIX_BITS;
         DigitFn dig{shift, (1u << bits) - 1u, 1u, 0u};
-        rc = radix_pass(ctx, in, out, vin, vout, n, dig, d_hist);
+        CR_TRY(radix_pass(ctx, in, out, vin, vout, n, dig));
         uint64_t *t = in;
         in = out;
         out = t;
@@ -220,35 +257,22 @@ int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_
         vout = tv;
         *result_in_tmp = !*result_in_tmp;
     }
-    return rc;
+    return CRGPU_OK;
 }
 
-// Stable partition of keys by owner rank of their barcode (bc % n_ranks): one counting-sort pass.
+// Stable partition of keys by the owner rank of their barcode: one counting-sort pass.
 int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
                           uint32_t n_ranks, uint64_t *counts_out) {
     CR_REQUIRE(ctx, n_ranks >= 1 && n_ranks <= RADIX, CRGPU_EINVAL, "partition: n_ranks must be 1..256");
     CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "partition: at most 2^32-2 keys per call");
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = 0;
     if (n == 0) return CRGPU_OK;
-    uint64_t tile;
-    const uint32_t nb = sort_blocks(n, &tile);
-    uint32_t *d_hist = ctx->d_sort_hist;
     // rank r owns canonical barcode ranks [r*width, (r+1)*width)
     const uint32_t width = (ctx->n_canon + n_ranks - 1) / n_ranks;
     DigitFn dig{sh_bc, 0u, width ? width : 1u, 1u};
-    int rc = radix_pass(ctx, d_in, d_out, nullptr, nullptr, n, dig, d_hist);
-    // after the scan d_hist[d*nb + 0] is the start of digit d: counts = differences
-    std::vector<uint32_t> starts(RADIX);
-    if (rc == CRGPU_OK) {
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        for (uint32_t d = 0; d < RADIX && e == hipSuccess; d++)
-            e = hipMemcpy(&starts[d], d_hist + (uint64_t)d * nb, sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "partition: %s", hipGetErrorString(e));
-    }
-    if (rc != CRGPU_OK) return rc;
-    for (uint32_t r = 0; r < n_ranks; r++) {
-        const uint64_t end = r + 1 < RADIX ? starts[r + 1] : n;
-        counts_out[r] = (r + 1 < n_ranks ? end : n) - starts[r];
-    }
+    CR_TRY(radix_pass(ctx, d_in, d_out, nullptr, nullptr, n, dig));
+    uint32_t totals[RADIX];
+    CR_TRY(crgpu_memcpy_d2h(ctx, totals, digit_totals_buf(ctx), sizeof(totals)));
+    for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = totals[r];
     return CRGPU_OK;
 }
