@@ -112,6 +112,7 @@ SYMBOLS = {
     "crgpu_stream": (_vp, [_vp]),
     "crgpu_malloc": (_i, [_vp, C.POINTER(_vp), _u64]),
     "crgpu_free": (_i, [_vp, _vp]),
+    "crgpu_trim": (_i, [_vp]),
     "crgpu_memcpy_h2d": (_i, [_vp, _vp, _vp, _u64]),
     "crgpu_memcpy_d2h": (_i, [_vp, _vp, _vp, _u64]),
     "crgpu_memset": (_i, [_vp, _vp, _i, _u64]),

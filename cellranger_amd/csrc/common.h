@@ -93,6 +93,12 @@ struct crgpu_ctx {
     uint32_t *d_sort_hist = nullptr;  // RADIX x 2048 block histograms of the radix passes
     void *d_scratch = nullptr;      // growable workspace
     uint64_t scratch_bytes = 0;
+    struct PoolBlock {
+        void *p;
+        uint64_t bytes;
+        bool in_use;
+    };
+    std::vector<PoolBlock> pool;
 
     // timing ledger
     bool timing = false;
@@ -127,6 +133,13 @@ void cr_set_thread_error(const char *msg);
 
 // workspace that only grows; returned pointer valid until the next cr_scratch call
 int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out);
+
+// Caching device pool for the per-step temporaries and results of the count stage.  hipMalloc /
+// hipFree of multi-GB buffers cost far more than the kernels; blocks are recycled instead.  Reuse is
+// safe without synchronisation because every kernel of a context runs on its one in-order stream.
+int cr_pool_alloc(crgpu_ctx *ctx, void **out, uint64_t bytes);
+void cr_pool_free(crgpu_ctx *ctx, void *p);
+void cr_pool_release_all(crgpu_ctx *ctx);  // hipFree every cached block (destroy / memory pressure)
 
 // timing scope: records a HIP event pair around the launches of one family when enabled
 struct CrTimer {

@@ -97,6 +97,7 @@ extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
     hipFree(ctx->d_scalars);
     hipFree(ctx->d_sort_hist);
     hipFree(ctx->d_scratch);
+    cr_pool_release_all(ctx);
     for (auto &s : ctx->spans) {
         hipEventDestroy(s.start);
         hipEventDestroy(s.stop);
@@ -116,17 +117,26 @@ extern "C" void *crgpu_stream(crgpu_ctx *ctx) { return ctx ? (void *)ctx->stream
 
 extern "C" int crgpu_malloc(crgpu_ctx *ctx, void **d_out, uint64_t bytes) {
     if (!ctx || !d_out) return CRGPU_EINVAL;
-    *d_out = nullptr;
-    hipError_t e = hipMalloc(d_out, bytes ? bytes : 1);
-    if (e != hipSuccess) return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
-    return CRGPU_OK;
+    return cr_pool_alloc(ctx, d_out, bytes);
 }
 
 extern "C" int crgpu_free(crgpu_ctx *ctx, void *d_ptr) {
     if (!ctx) return CRGPU_EINVAL;
-    if (!d_ptr) return CRGPU_OK;
+    cr_pool_free(ctx, d_ptr);
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_trim(crgpu_ctx *ctx) {
+    if (!ctx) return CRGPU_EINVAL;
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    CR_HIP(ctx, hipFree(d_ptr));
+    for (size_t i = 0; i < ctx->pool.size();) {
+        if (!ctx->pool[i].in_use) {
+            (void)hipFree(ctx->pool[i].p);
+            ctx->pool.erase(ctx->pool.begin() + i);
+        } else {
+            i++;
+        }
+    }
     return CRGPU_OK;
 }
 
@@ -167,6 +177,62 @@ int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out) {
     }
     *out = ctx->d_scratch;
     return CRGPU_OK;
+}
+
+// ---- caching pool ----------------------------------------------------------------------------------
+
+int cr_pool_alloc(crgpu_ctx *ctx, void **out, uint64_t bytes) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 8;
+    bytes = (bytes + 255) & ~255ull;
+    // best fit among the free blocks that waste at most 25 %
+    int best = -1;
+    for (size_t i = 0; i < ctx->pool.size(); i++) {
+        const auto &b = ctx->pool[i];
+        if (b.in_use || b.bytes < bytes || b.bytes - bytes > bytes / 4 + 4096) continue;
+        if (best < 0 || b.bytes < ctx->pool[best].bytes) best = (int)i;
+    }
+    if (best >= 0) {
+        ctx->pool[best].in_use = true;
+        *out = ctx->pool[best].p;
+        return CRGPU_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // memory pressure: drop every cached free block and retry once
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        for (size_t i = 0; i < ctx->pool.size();) {
+            if (!ctx->pool[i].in_use) {
+                (void)hipFree(ctx->pool[i].p);
+                ctx->pool.erase(ctx->pool.begin() + i);
+            } else {
+                i++;
+            }
+        }
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess)
+        return cr_fail(ctx, CRGPU_ENOMEM, "device pool hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    ctx->pool.push_back({p, bytes, true});
+    *out = p;
+    return CRGPU_OK;
+}
+
+void cr_pool_free(crgpu_ctx *ctx, void *p) {
+    if (!p || !ctx) return;
+    for (auto &b : ctx->pool)
+        if (b.p == p) {
+            b.in_use = false;
+            return;
+        }
+    (void)hipFree(p);  // not from the pool
+}
+
+void cr_pool_release_all(crgpu_ctx *ctx) {
+    for (auto &b : ctx->pool) (void)hipFree(b.p);
+    ctx->pool.clear();
 }
 
 // ---- timing ------------------------------------------------------------------------------------

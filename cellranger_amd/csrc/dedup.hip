@@ -501,17 +501,17 @@ __global__ __launch_bounds__(256) void k_triplets(const KL kl, const uint64_t *_
 // ------------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------------
-struct DevBuf {
+struct DevBuf {  // pooled temporary, returned to the context's pool at scope exit
+    crgpu_ctx *ctx = nullptr;
     void *p = nullptr;
-    ~DevBuf() { (void)hipFree(p); }
+    ~DevBuf() { cr_pool_free(ctx, p); }
     template <typename T>
     T *as() { return (T *)p; }
 };
 
 static int dmalloc(crgpu_ctx *ctx, DevBuf &b, uint64_t bytes) {
-    hipError_t e = hipMalloc(&b.p, bytes ? bytes : 8);
-    if (e != hipSuccess) return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
-    return CRGPU_OK;
+    b.ctx = ctx;
+    return cr_pool_alloc(ctx, &b.p, bytes);
 }
 
 static int read_u32(crgpu_ctx *ctx, const uint32_t *d, uint32_t *h) {
@@ -611,7 +611,6 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
                                s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), nd, upos, n_keys, corr, inc1, low);
             CR_HIP(ctx, hipGetLastError());
         }
-        CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // buffers of this scope are freed below
     }
 
     // 5. molecules = distinct keys some read lands on and that are not low support
@@ -642,16 +641,15 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
         CR_TRY(read_u32(ctx, d_total, &nt32));
     }
     const uint64_t nt = nt32;
-    CR_HIP(ctx, hipMalloc((void **)&res->d_bc, (nt ? nt : 1) * sizeof(uint32_t)));
-    CR_HIP(ctx, hipMalloc((void **)&res->d_feature, (nt ? nt : 1) * sizeof(uint32_t)));
-    CR_HIP(ctx, hipMalloc((void **)&res->d_count, (nt ? nt : 1) * sizeof(uint32_t)));
+    CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_bc, nt * sizeof(uint32_t)));
+    CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_feature, nt * sizeof(uint32_t)));
+    CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_count, nt * sizeof(uint32_t)));
     if (nt) {
         CrTimer t(ctx, CRGPU_T_DEDUP);
         hipLaunchKernelGGL(k_triplets, dim3(cr_grid(nt, 256)), dim3(256), 0, ctx->stream, kl, mkeys_b.as<uint64_t>(),
                            tpos_b.as<uint32_t>(), nt, nm, res->d_bc, res->d_feature, res->d_count);
         CR_HIP(ctx, hipGetLastError());
     }
-    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     res->n_triplets = nt;
     res->n_molecules = nm;
     res->d_mkeys = (uint64_t *)mkeys_b.p;
@@ -742,7 +740,7 @@ extern "C" int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, c
         }
     } guard{ctx, m};
     const uint32_t W = ctx->n_canon;
-    CR_HIP(ctx, hipMalloc((void **)&m->d_rank, (size_t)W * sizeof(uint32_t)));
+    CR_TRY(cr_pool_alloc(ctx, (void **)&m->d_rank, (size_t)W * sizeof(uint32_t)));
     uint32_t *d_total = ctx->d_scalars + 16;
     uint32_t V = 0;
     {
@@ -750,9 +748,9 @@ extern "C" int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, c
         CR_TRY(compact(ctx, seen, EmitCol{m->d_rank}, W, ctx->d_sort_hist, d_total));
     }
     CR_TRY(read_u32(ctx, d_total, &V));
-    CR_HIP(ctx, hipMalloc((void **)&m->d_indptr, ((size_t)V + 1) * sizeof(long long)));
-    CR_HIP(ctx, hipMalloc((void **)&m->d_indices, (n_triplets ? n_triplets : 1) * sizeof(int32_t)));
-    CR_HIP(ctx, hipMalloc((void **)&m->d_data, (n_triplets ? n_triplets : 1) * sizeof(int32_t)));
+    CR_TRY(cr_pool_alloc(ctx, (void **)&m->d_indptr, ((size_t)V + 1) * sizeof(long long)));
+    CR_TRY(cr_pool_alloc(ctx, (void **)&m->d_indices, n_triplets * sizeof(int32_t)));
+    CR_TRY(cr_pool_alloc(ctx, (void **)&m->d_data, n_triplets * sizeof(int32_t)));
     {
         CrTimer t(ctx, CRGPU_T_MATRIX);
         const uint64_t work = n_triplets > V ? n_triplets : (uint64_t)V + 1;
@@ -774,11 +772,10 @@ extern "C" int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, c
 extern "C" void crgpu_matrix_dev_free(crgpu_ctx *ctx, crgpu_matrix_dev *mv) {
     if (!mv) return;
     MatrixDevImpl *m = reinterpret_cast<MatrixDevImpl *>(mv);  // view is the first member
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(m->d_rank);
-    (void)hipFree(m->d_indptr);
-    (void)hipFree(m->d_indices);
-    (void)hipFree(m->d_data);
+    cr_pool_free(ctx, m->d_rank);
+    cr_pool_free(ctx, m->d_indptr);
+    cr_pool_free(ctx, m->d_indices);
+    cr_pool_free(ctx, m->d_data);
     delete m;
 }
 
@@ -858,11 +855,10 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
 
 extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
     if (!c) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(c->d_bc);
-    (void)hipFree(c->d_feature);
-    (void)hipFree(c->d_count);
-    (void)hipFree(c->d_mkeys);
-    (void)hipFree(c->d_mreads);
+    cr_pool_free(ctx, c->d_bc);
+    cr_pool_free(ctx, c->d_feature);
+    cr_pool_free(ctx, c->d_count);
+    cr_pool_free(ctx, c->d_mkeys);
+    cr_pool_free(ctx, c->d_mreads);
     delete c;
 }

@@ -136,12 +136,12 @@ extern "C" int crgpu_count(crgpu_ctx *ctx, const crgpu_records *recs, uint32_t n
     CR_REQUIRE(ctx, ctx->layout.set && ctx->layout.n_features == n_features, CRGPU_ESTATE,
                "crgpu_count: call crgpu_set_key_layout with the same n_features first");
     uint64_t *d_keys = nullptr;
-    CR_HIP(ctx, hipMalloc((void **)&d_keys, (recs->n ? recs->n : 1) * sizeof(uint64_t)));
+    CR_TRY(cr_pool_alloc(ctx, (void **)&d_keys, recs->n * sizeof(uint64_t)));
     uint64_t n_keys = 0;
     crgpu_counts *c = nullptr;
     int rc = crgpu_build_keys_dev(ctx, recs, d_keys, &n_keys);
     if (rc == CRGPU_OK) rc = crgpu_count_keys_dev(ctx, d_keys, n_keys, &c);
-    (void)hipFree(d_keys);
+    cr_pool_free(ctx, d_keys);
     if (rc != CRGPU_OK) return rc;
     uint64_t nt = 0;
     crgpu_counts_info(ctx, c, &nt, nullptr);

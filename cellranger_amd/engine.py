@@ -267,6 +267,9 @@ class Context:
     def synchronize(self):
         self._check(self.L.crgpu_synchronize(self.h))
 
+    def trim(self):
+        self._check(self.L.crgpu_trim(self.h))
+
     # ---- timing -------------------------------------------------------------------------------
     def timing(self, on=True):
         self._check(self.L.crgpu_timing_enable(self.h, int(on)))

@@ -67,9 +67,13 @@ const char *crgpu_last_error(const crgpu_ctx *ctx);
 int crgpu_synchronize(crgpu_ctx *ctx);
 /* The HIP stream (hipStream_t) every kernel of this context is launched on. */
 void *crgpu_stream(crgpu_ctx *ctx);
-/* device-memory helpers for hosts without their own allocator (Rust host, tests) */
+/* device-memory helpers for hosts without their own allocator (Rust host, tests).  Backed by the
+ * context's caching pool (multi-GB hipMalloc/hipFree cost more than the kernels): crgpu_free returns
+ * the block to the pool, crgpu_trim gives cached blocks back to the driver.  A freed block may be
+ * reused by later work on the context's stream, so synchronise other streams before freeing. */
 int crgpu_malloc(crgpu_ctx *ctx, void **d_out, uint64_t bytes);
 int crgpu_free(crgpu_ctx *ctx, void *d_ptr);
+int crgpu_trim(crgpu_ctx *ctx);
 int crgpu_memcpy_h2d(crgpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int crgpu_memcpy_d2h(crgpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 int crgpu_memset(crgpu_ctx *ctx, void *d_dst, int value, uint64_t bytes);
