@@ -16,6 +16,7 @@ int cr_make_views(crgpu_ctx *ctx, WlView *views);
 
 struct WlViewSet {
     WlView v[CRGPU_MAX_LIB];
+    uint32_t n_canon;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -123,6 +124,155 @@ static bool uniform_lib0(const crgpu_ctx *ctx) {
     return true;
 }
 
+// ---- K1 with an LDS-binned histogram ---------------------------------------------------------------
+// Scattered device-scope atomics run at ~20 G/s on this chip (one 64-B fabric request per lane), which
+// made the histogram 5x more expensive than the lookups.  Instead:
+//   k_match_binned  looks the reads up, writes idx_out, and appends (rank & 0x7FFF) as u16 to the
+//                   staging region of its bucket (bucket = library slot, rank >> 15).  A tile of 4096
+//                   reads is ranked by bucket in LDS and copied out in contiguous runs; one global
+//                   atomic per (tile, non-empty bucket) reserves the space.
+//   k_hist_buckets  one workgroup per (bucket, slice): 32768 u32 counters in LDS (128 KB), streams the
+//                   bucket's u16 entries with 16-byte loads, then adds the non-zero counters to the
+//                   library's valid table (contiguous atomics, a few per barcode).
+#define BIN_SHIFT 15
+#define BIN_SIZE (1u << BIN_SHIFT)
+#define MB_ITEMS 16
+#define MB_TILE (256 * MB_ITEMS)
+#define MB_MAX_BUCKETS 1024
+#define MB_BPT (MB_MAX_BUCKETS / 256)  // buckets per thread in the tile scan
+
+struct BinPlan {
+    uint32_t lib_slot[CRGPU_MAX_LIB];  // library id -> slot (0xFFFFFFFF = not configured)
+    uint32_t buckets_per_lib;
+    uint32_t n_buckets;
+    uint64_t cap;  // staging entries per bucket
+};
+
+template <bool UNIFORM>
+__global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const BinPlan plan,
+                                                      const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
+                                                      uint64_t n, uint32_t *__restrict__ idx_out,
+                                                      uint16_t *__restrict__ stage, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t bcnt[MB_MAX_BUCKETS];    // tile counts, then global base of each bucket
+    __shared__ uint32_t bstart[MB_MAX_BUCKETS];  // tile-local exclusive prefix
+    __shared__ uint16_t sval[MB_TILE];
+    __shared__ uint16_t sbkt[MB_TILE];
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t tile_hits;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t NB = plan.n_buckets;
+    const uint64_t n_tiles = (n + MB_TILE - 1) / MB_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (uint32_t b = tid; b < NB; b += 256) bcnt[b] = 0;
+        __syncthreads();
+        uint32_t bv[MB_ITEMS];    // (bucket << 16) | value, 0xFFFFFFFF = no hit
+        uint16_t loff[MB_ITEMS];  // arrival order inside (tile, bucket)
+#pragma unroll
+        for (int j = 0; j < MB_ITEMS; j++) {
+            const uint64_t i = tile * MB_TILE + (uint64_t)j * 256 + tid;
+            bv[j] = 0xFFFFFFFFu;
+            loff[j] = 0;
+            if (i < n) {
+                const uint32_t key = cb[i];
+                const uint32_t f = flags ? flags[i] : 0u;
+                const uint32_t lib = f & CRGPU_FLAG_LIB_MASK;
+                uint32_t rank = CRGPU_MISS;
+                if (!(f & CRGPU_FLAG_CB_HAS_N)) {
+                    if (UNIFORM) {
+                        if (lib == 0) rank = wl_lookup(vs.v[0], key);
+                    } else {
+                        if (vs.v[lib].n) rank = wl_lookup(vs.v[lib], key);
+                    }
+                }
+                idx_out[i] = rank;
+                if (rank != CRGPU_MISS) {
+                    const uint32_t b = (UNIFORM ? 0u : plan.lib_slot[lib] * plan.buckets_per_lib) + (rank >> BIN_SHIFT);
+                    loff[j] = (uint16_t)atomicAdd(&bcnt[b], 1u);
+                    bv[j] = (b << 16) | (rank & (BIN_SIZE - 1u));
+                }
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the tile's bucket counts (MB_BPT consecutive buckets per thread) and one
+        // global reservation per non-empty bucket
+        {
+            uint32_t c[MB_BPT], s = 0;
+#pragma unroll
+            for (int k = 0; k < MB_BPT; k++) {
+                const uint32_t b = tid * MB_BPT + k;
+                c[k] = b < NB ? bcnt[b] : 0u;
+                s += c[k];
+            }
+            uint32_t tot;
+            uint32_t run = block_excl_scan_256(s, lds, &tot);
+            if (tid == 0) tile_hits = tot;
+#pragma unroll
+            for (int k = 0; k < MB_BPT; k++) {
+                const uint32_t b = tid * MB_BPT + k;
+                if (b < NB) {
+                    bstart[b] = run;
+                    run += c[k];
+                    bcnt[b] = c[k] ? atomicAdd(&cursor[b], c[k]) : 0u;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MB_ITEMS; j++)
+            if (bv[j] != 0xFFFFFFFFu) {
+                const uint32_t b = bv[j] >> 16;
+                const uint32_t p = bstart[b] + loff[j];
+                sval[p] = (uint16_t)(bv[j] & 0xFFFFu);
+                sbkt[p] = (uint16_t)b;
+            }
+        __syncthreads();
+        // contiguous runs per bucket: neighbouring p of one bucket go to neighbouring addresses
+        const uint32_t hits = tile_hits;
+        for (uint32_t p = tid; p < hits; p += 256) {
+            const uint32_t b = sbkt[p];
+            stage[(uint64_t)b * plan.cap + bcnt[b] + (p - bstart[b])] = sval[p];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(512) void k_hist_buckets(const WlViewSet vs, const BinPlan plan, uint32_t slices,
+                                                      const uint16_t *__restrict__ stage,
+                                                      const uint32_t *__restrict__ cursor) {
+    extern __shared__ uint32_t cnt[];  // BIN_SIZE counters
+    const uint32_t b = blockIdx.x / slices, s = blockIdx.x % slices;
+    const uint32_t total = cursor[b];
+    // slice boundaries in units of 8 entries (16-byte loads); the last slice takes the ragged tail
+    const uint32_t groups = (total + 7u) / 8u;
+    const uint32_t g_lo = (uint32_t)((uint64_t)groups * s / slices), g_hi = (uint32_t)((uint64_t)groups * (s + 1) / slices);
+    if (g_lo >= g_hi) return;
+    for (uint32_t c = threadIdx.x; c < BIN_SIZE; c += 512) cnt[c] = 0;
+    __syncthreads();
+    const uint16_t *src = stage + (uint64_t)b * plan.cap;
+    for (uint32_t g = g_lo + threadIdx.x; g < g_hi; g += 512) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + (uint64_t)g * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t valid = total - g * 8u;  // entries of this group that exist (>= 8 except in the tail)
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((uint32_t)k < valid) atomicAdd(&cnt[(w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu], 1u);
+    }
+    __syncthreads();
+    // bucket -> (library slot, rank range)
+    const uint32_t slot = b / plan.buckets_per_lib, sub = b % plan.buckets_per_lib;
+    uint32_t lib = 0;
+    for (uint32_t l = 0; l < CRGPU_MAX_LIB; l++)
+        if (plan.lib_slot[l] == slot) lib = l;
+    uint32_t *dst = vs.v[lib].valid + (uint64_t)sub * BIN_SIZE;
+    const uint32_t limit = vs.n_canon - sub * BIN_SIZE < BIN_SIZE ? vs.n_canon - sub * BIN_SIZE : BIN_SIZE;
+    for (uint32_t c = threadIdx.x; c < limit; c += 512) {
+        const uint32_t x = cnt[c];
+        if (x) atomicAdd(&dst[c], x);
+    }
+}
+
+#define MB_STAGE_BUDGET (2ull << 30)  // bytes of u16 staging per super-batch
+
 extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_flags, uint64_t n,
                                          uint32_t *d_idx_out) {
     if (!ctx) return CRGPU_EINVAL;
@@ -131,22 +281,78 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     CR_REQUIRE(ctx, d_cb && d_idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
     WlViewSet vs;
     CR_TRY(cr_make_views(ctx, vs.v));
-    CrTimer t(ctx, CRGPU_T_MATCH, n);
-    const dim3 grid(cr_grid(n, 256)), block(256);
-    if (uniform_lib0(ctx))
-        hipLaunchKernelGGL(k_match<true>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, n, d_idx_out);
-    else
-        hipLaunchKernelGGL(k_match<false>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, n, d_idx_out);
-    CR_HIP(ctx, hipGetLastError());
+    vs.n_canon = ctx->n_canon;
+    const bool uniform = uniform_lib0(ctx);
+
+    BinPlan plan;
+    uint32_t n_slots = 0;
+    for (int l = 0; l < CRGPU_MAX_LIB; l++) plan.lib_slot[l] = ctx->wl[l].set ? n_slots++ : 0xFFFFFFFFu;
+    plan.buckets_per_lib = (ctx->n_canon + BIN_SIZE - 1) / BIN_SIZE;
+    plan.n_buckets = plan.buckets_per_lib * n_slots;
+
+    if (plan.n_buckets > MB_MAX_BUCKETS) {
+        // very large whitelist x many libraries: plain device atomics
+        CrTimer t(ctx, CRGPU_T_MATCH, n);
+        const dim3 grid(cr_grid(n, 256)), block(256);
+        if (uniform)
+            hipLaunchKernelGGL(k_match<true>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, n, d_idx_out);
+        else
+            hipLaunchKernelGGL(k_match<false>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, n, d_idx_out);
+        CR_HIP(ctx, hipGetLastError());
+        return CRGPU_OK;
+    }
+
+    // super-batches sized so that every bucket could take ALL reads of the batch
+    uint64_t sb = MB_STAGE_BUDGET / 2 / plan.n_buckets;
+    sb = sb / MB_TILE * MB_TILE;
+    if (sb < MB_TILE) sb = MB_TILE;
+    if (sb > n) sb = (n + MB_TILE - 1) / MB_TILE * MB_TILE;
+    plan.cap = sb;  // multiple of 4096 -> every bucket region is 16-byte aligned
+    uint16_t *d_stage = nullptr;
+    uint32_t *d_cursor = nullptr;
+    CR_TRY(cr_pool_alloc(ctx, (void **)&d_stage, (uint64_t)plan.n_buckets * plan.cap * sizeof(uint16_t)));
+    int rc = cr_pool_alloc(ctx, (void **)&d_cursor, plan.n_buckets * sizeof(uint32_t));
+    if (rc != CRGPU_OK) {
+        cr_pool_free(ctx, d_stage);
+        return rc;
+    }
+    // slices per bucket: ~2 workgroups per CU in total (128 KB of LDS each -> one resident per CU)
+    uint32_t slices = 512 / plan.n_buckets;
+    if (slices < 1) slices = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_hist_buckets, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SIZE * 4);
+        attr_set = true;
+    }
+    hipError_t e = hipSuccess;
+    for (uint64_t off = 0; off < n && e == hipSuccess; off += sb) {
+        const uint64_t m = n - off < sb ? n - off : sb;
+        CrTimer t(ctx, CRGPU_T_MATCH, m);
+        e = hipMemsetAsync(d_cursor, 0, plan.n_buckets * sizeof(uint32_t), ctx->stream);
+        const dim3 grid(cr_grid((m + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)), block(256);
+        if (uniform)
+            hipLaunchKernelGGL(k_match_binned<true>, grid, block, 0, ctx->stream, vs, plan, d_cb + off,
+                               d_flags ? d_flags + off : nullptr, m, d_idx_out + off, d_stage, d_cursor);
+        else
+            hipLaunchKernelGGL(k_match_binned<false>, grid, block, 0, ctx->stream, vs, plan, d_cb + off,
+                               d_flags ? d_flags + off : nullptr, m, d_idx_out + off, d_stage, d_cursor);
+        hipLaunchKernelGGL(k_hist_buckets, dim3(plan.n_buckets * slices), dim3(512), BIN_SIZE * 4, ctx->stream, vs, plan, slices,
+                           d_stage, d_cursor);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    cr_pool_free(ctx, d_stage);
+    cr_pool_free(ctx, d_cursor);
+    if (e != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "crgpu_match_and_count: %s", hipGetErrorString(e));
     return CRGPU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2: posterior correction of the reads that missed
 // ------------------------------------------------------------------------------------------------
-#define MISS_ITEMS 8
-// Compact the indices of the reads that missed.  One global atomic per 2048-read chunk: a single hot
-// counter serialises, so the reservation is aggregated over the whole workgroup.
+#define MISS_ITEMS 64
+// Compact the indices of the reads that missed.  One global atomic per 16384-read chunk: same-address
+// atomics saturate near 88 per microsecond on this chip, so the reservation is aggregated over the
+// whole workgroup and over 64 reads per thread (a 64-bit miss mask per thread).
 __global__ __launch_bounds__(256) void k_collect_miss(const uint32_t *__restrict__ idx, uint64_t n,
                                                       uint32_t *__restrict__ miss_list,
                                                       unsigned long long *__restrict__ n_miss) {
@@ -154,16 +360,18 @@ __global__ __launch_bounds__(256) void k_collect_miss(const uint32_t *__restrict
     const uint64_t chunk = 256ull * MISS_ITEMS;
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        uint32_t mask = 0;
-#pragma unroll
+        unsigned long long mask = 0;
+#pragma unroll 16
         for (int j = 0; j < MISS_ITEMS; j++) {
             const uint64_t i = c * chunk + (uint64_t)j * 256 + threadIdx.x;
-            if (i < n && idx[i] == CRGPU_MISS) mask |= 1u << j;
+            if (i < n && idx[i] == CRGPU_MISS) mask |= 1ull << j;
         }
-        unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_miss, lds);
-#pragma unroll
-        for (int j = 0; j < MISS_ITEMS; j++)
-            if (mask & (1u << j)) miss_list[o++] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);
+        unsigned long long o = block_reserve_256((uint32_t)__popcll(mask), n_miss, lds);
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            miss_list[o++] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);
+        }
     }
 }
 
