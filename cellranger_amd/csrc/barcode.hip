@@ -433,24 +433,25 @@ __global__ __launch_bounds__(256) void k_correct(const WlViewSet vs, const uint3
             const uint32_t head = key >> w.bitsB;
             const uint32_t tail = key & ((1u << w.bitsB) - 1u);
             const uint32_t hA = w.bitsA >> 1;
+            // the four bin bounds are independent loads
+            const uint32_t a_lo = w.offA[head], a_hi = w.offA[head + 1];
+            const uint32_t b_lo = w.offB[tail], b_hi = w.offB[tail + 1];
             // mutation in the tail: same head -> bin A
-            for (uint32_t p = w.offA[head], e = w.offA[head + 1]; p < e; ++p) {
-                const uint32_t t = w.tailA[p];
+            scan_u16_range(w.tailA, a_lo, a_hi, [&](uint32_t t, uint32_t) {
                 const int bo = one_base_diff(t, tail);
                 if (bo >= 0) {
                     const uint32_t pos = len - 1u - (uint32_t)(bo >> 1);
                     cand |= 1ull << (pos * 4u + ((t >> bo) & 3u));
                 }
-            }
+            });
             // mutation in the head: same tail -> bin B
-            for (uint32_t p = w.offB[tail], e = w.offB[tail + 1]; p < e; ++p) {
-                const uint32_t h = w.headB[p];
+            scan_u16_range(w.headB, b_lo, b_hi, [&](uint32_t h, uint32_t) {
                 const int bo = one_base_diff(h, head);
                 if (bo >= 0) {
                     const uint32_t pos = hA - 1u - (uint32_t)(bo >> 1);
                     cand |= 1ull << (pos * 4u + ((h >> bo) & 3u));
                 }
-            }
+            });
         } else if (n_n == 1) {
             // the N is "observed": all four bases are tried at its position (corrector.rs:128-131);
             // a candidate built at any other position still contains the N and cannot match.

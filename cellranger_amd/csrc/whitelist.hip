@@ -33,7 +33,8 @@ static int pack_ascii(crgpu_ctx *ctx, const char *s, uint32_t n, uint32_t len, s
 template <typename T>
 static int upload(crgpu_ctx *ctx, T **d, const std::vector<T> &h) {
     *d = nullptr;
-    hipError_t e = hipMalloc((void **)d, std::max<size_t>(h.size(), 1) * sizeof(T));
+    // +8 bytes of padding: scan_u16_range reads whole dwords around a bin
+    hipError_t e = hipMalloc((void **)d, std::max<size_t>(h.size(), 1) * sizeof(T) + 8);
     if (e != hipSuccess) return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc whitelist table: %s", hipGetErrorString(e));
     if (!h.empty()) CR_HIP(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return CRGPU_OK;

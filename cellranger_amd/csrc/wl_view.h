@@ -1,13 +1,13 @@
-// wl_view.h -- device view of one library's whitelist tables + the exact-lookup primitive.
+// wl_view.h -- device view of one library's whitelist tables + the lookup primitives.
 #pragma once
 #include <cstdint>
 
 struct WlView {
     const uint32_t *offA;
-    const uint16_t *tailA;
-    const uint32_t *valA;  // nullptr => rank == sorted position
+    const uint16_t *tailA;  // n entries (+2 of padding), 4-byte aligned base
+    const uint32_t *valA;   // nullptr => rank == sorted position
     const uint32_t *offB;
-    const uint16_t *headB;
+    const uint16_t *headB;  // n entries (+2 of padding), 4-byte aligned base
     uint32_t *valid;
     uint32_t *corrected;
     const uint32_t *prior;
@@ -16,19 +16,36 @@ struct WlView {
     uint32_t pad;
 };
 
+// Visit the u16 entries arr[lo, hi) in rounds of 16: the 8 dword loads of a round are independent
+// (one memory latency per round instead of one per entry -- a per-entry load/compare/branch loop is a
+// serial latency chain and made the lookups latency bound).  f(value, position) is called for every
+// entry of the range.  arr must be 4-byte aligned and padded by 2 entries.
+template <typename F>
+__device__ __forceinline__ void scan_u16_range(const uint16_t *__restrict__ arr, uint32_t lo, uint32_t hi, F f) {
+    const uint32_t *__restrict__ w = reinterpret_cast<const uint32_t *>(arr);
+    for (uint32_t p = lo & ~1u; p < hi; p += 16u) {
+        uint32_t d[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) d[k] = (p + 2u * k < hi) ? w[(p >> 1) + k] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t pos = p + k;
+            if (pos >= lo && pos < hi) f((d[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu, pos);
+        }
+    }
+}
+
 // Exact whitelist membership (Whitelist::check_and_update, barcode/src/whitelist.rs:494-517):
 // returns the canonical rank of the (translated) barcode or 0xFFFFFFFF.
 __device__ __forceinline__ uint32_t wl_lookup(const WlView &w, uint32_t key) {
     const uint32_t head = key >> w.bitsB;  // bitsB <= 16 < 32 always; bitsA may be 0
     const uint32_t tail = key & ((1u << w.bitsB) - 1u);
-    uint32_t lo = w.offA[head];
+    const uint32_t lo = w.offA[head];
     const uint32_t hi = w.offA[head + 1];
-    for (; lo < hi; ++lo) {
-        const uint32_t t = w.tailA[lo];
-        if (t >= tail) {
-            if (t == tail) return w.valA ? w.valA[lo] : lo;
-            break;
-        }
-    }
-    return 0xFFFFFFFFu;
+    uint32_t found = 0xFFFFFFFFu;
+    scan_u16_range(w.tailA, lo, hi, [&](uint32_t t, uint32_t pos) {
+        if (t == tail) found = pos;
+    });
+    if (found == 0xFFFFFFFFu) return found;
+    return w.valA ? w.valA[found] : found;
 }
