@@ -167,3 +167,5 @@ static inline uint32_t cr_grid(uint64_t n, uint32_t block, uint32_t max_blocks =
 // internal entry points shared between translation units
 int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
                       uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp);
+int cr_radix_sort_u32(crgpu_ctx *ctx, uint32_t *d_keys, uint32_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
+                      uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp);

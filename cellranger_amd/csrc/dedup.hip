@@ -432,54 +432,72 @@ __global__ __launch_bounds__(256) void k_rep_utype(const KL kl, const uint64_t *
 // ------------------------------------------------------------------------------------------------
 // low-support filter (determine_low_support_umigenes, mark_dups.rs:87-108)
 // ------------------------------------------------------------------------------------------------
-// secondary key [barcode][library][UMI][feature] so that all features of one (barcode, library, UMI)
-// are adjacent; payload = index of the distinct key.
-__global__ __launch_bounds__(256) void k_secondary_keys(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
-                                                        uint64_t *__restrict__ key2, uint32_t *__restrict__ val) {
+// The rule groups the keys of one (barcode, library, UMI) across features.  Instead of re-sorting the
+// 64-bit keys in [barcode][library][UMI][feature] order (8 passes over 12-byte pairs) the distinct
+// keys are sorted by a 32-bit hash of (barcode, library, UMI) with their index as payload (4 passes
+// over 8-byte pairs); members of a group are then adjacent inside a run of equal hashes, and every
+// comparison below re-checks the exact (barcode, library, UMI) so hash collisions cannot merge groups.
+__device__ __forceinline__ uint64_t group_id(const KL &kl, uint64_t key) {  // (barcode, library, UMI), exact
+    const uint64_t umi = (key >> kl.sh_umi) & lowmask(kl.bits_umi);
+    const uint64_t lib = (key >> kl.sh_lib) & lowmask(kl.bits_lib);
+    const uint64_t bc = key >> kl.sh_bc;
+    return ((bc << kl.bits_lib) | lib) << kl.bits_umi | umi;
+}
+__device__ __forceinline__ uint32_t group_hash(uint64_t g) {
+    g ^= g >> 33;
+    g *= 0xff51afd7ed558ccdull;
+    g ^= g >> 33;
+    g *= 0xc4ceb9fe1a85ec53ull;
+    g ^= g >> 33;
+    return (uint32_t)g;
+}
+
+__global__ __launch_bounds__(256) void k_group_hashes(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
+                                                      uint32_t *__restrict__ hash, uint32_t *__restrict__ val) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
-        const uint64_t key = ukey[k];
-        const uint64_t umi = (key >> kl.sh_umi) & lowmask(kl.bits_umi);
-        const uint64_t lib = (key >> kl.sh_lib) & lowmask(kl.bits_lib);
-        const uint64_t feat = (key >> kl.sh_feat) & lowmask(kl.bits_feat);
-        const uint64_t bc = key >> kl.sh_bc;
-        key2[k] = (((bc << kl.bits_lib | lib) << kl.bits_umi | umi) << kl.bits_feat) | feat;
+        hash[k] = group_hash(group_id(kl, ukey[k]));
         val[k] = (uint32_t)k;
     }
 }
 
-__global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint64_t *__restrict__ key2,
+__global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint32_t *__restrict__ hash,
                                                      const uint32_t *__restrict__ val, uint64_t nd,
+                                                     const uint64_t *__restrict__ ukey,
                                                      const uint32_t *__restrict__ upos, uint64_t n_keys,
                                                      const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc1,
                                                      uint8_t *__restrict__ low) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nd; j += stride) {
-        const uint64_t pre = key2[j] >> kl.bits_feat;
-        // only the first element of a group does the work; groups are almost always singletons
-        if (j > 0 && (key2[j - 1] >> kl.bits_feat) == pre) continue;
-        uint64_t e = j + 1;
-        while (e < nd && (key2[e] >> kl.bits_feat) == pre) e++;
-        if (e - j < 2) continue;  // a single (umi, feature): it is its own strict maximum, never low support
+        const uint32_t h = hash[j];
+        // almost every run of equal hashes is a singleton: a single (umi, feature) key is its own
+        // strict maximum and never low support
+        const bool same_prev = j > 0 && hash[j - 1] == h;
+        const bool same_next = j + 1 < nd && hash[j + 1] == h;
+        if (!same_prev && !same_next) continue;
+        uint64_t s = j, e = j + 1;
+        while (s > 0 && hash[s - 1] == h) s--;
+        while (e < nd && hash[e] == h) e++;
+        const uint32_t me = val[j];
+        const uint64_t g = group_id(kl, ukey[me]);
         // counts after moving ONE read of each corrected key (mark_dups.rs:226-232); zero-count keys stay
-        uint32_t mx = 0;
-        for (uint64_t t = j; t < e; t++) {
+        const uint32_t my_c1 = run_count(upos, nd, n_keys, me) - (corr[me] != NONE32 ? 1u : 0u) + inc1[me];
+        uint32_t mx = my_c1, n_members = 0, n_max = 0;
+        for (uint64_t t = s; t < e; t++) {
             const uint32_t k = val[t];
+            if (group_id(kl, ukey[k]) != g) continue;  // hash collision: a different group
             const uint32_t c1 = run_count(upos, nd, n_keys, k) - (corr[k] != NONE32 ? 1u : 0u) + inc1[k];
-            mx = c1 > mx ? c1 : mx;
+            n_members++;
+            if (c1 > mx) {
+                mx = c1;
+                n_max = 1;
+            } else if (c1 == mx) {
+                n_max++;
+            }
         }
-        uint32_t n_max = 0;
-        for (uint64_t t = j; t < e; t++) {
-            const uint32_t k = val[t];
-            const uint32_t c1 = run_count(upos, nd, n_keys, k) - (corr[k] != NONE32 ? 1u : 0u) + inc1[k];
-            n_max += c1 == mx ? 1u : 0u;
-        }
-        const bool tied = n_max >= 2;
-        for (uint64_t t = j; t < e; t++) {
-            const uint32_t k = val[t];
-            const uint32_t c1 = run_count(upos, nd, n_keys, k) - (corr[k] != NONE32 ? 1u : 0u) + inc1[k];
-            if (tied || c1 < mx) low[k] = 1;
-        }
+        if (n_members < 2) continue;
+        // low iff below the group's maximum, or the maximum is shared (mark_dups.rs:96-106)
+        if (my_c1 < mx || n_max >= 2) low[me] = 1;
     }
 }
 
@@ -588,27 +606,27 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
         CR_HIP(ctx, hipGetLastError());
     }
 
-    // 4. low support: group the distinct keys by (barcode, library, UMI)
+    // 4. low support: group the distinct keys by (barcode, library, UMI) through a 32-bit hash sort
     {
-        DevBuf k2_b, k2t_b, v_b, vt_b;
-        CR_TRY(dmalloc(ctx, k2_b, nd * sizeof(uint64_t)));
-        CR_TRY(dmalloc(ctx, k2t_b, nd * sizeof(uint64_t)));
+        DevBuf h_b, ht_b, v_b, vt_b;
+        CR_TRY(dmalloc(ctx, h_b, nd * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, ht_b, nd * sizeof(uint32_t)));
         CR_TRY(dmalloc(ctx, v_b, nd * sizeof(uint32_t)));
         CR_TRY(dmalloc(ctx, vt_b, nd * sizeof(uint32_t)));
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
-            hipLaunchKernelGGL(k_secondary_keys, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd,
-                               k2_b.as<uint64_t>(), v_b.as<uint32_t>());
+            hipLaunchKernelGGL(k_group_hashes, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd,
+                               h_b.as<uint32_t>(), v_b.as<uint32_t>());
             CR_HIP(ctx, hipGetLastError());
         }
         bool s_in_tmp = false;
-        CR_TRY(cr_radix_sort_u64(ctx, k2_b.as<uint64_t>(), k2t_b.as<uint64_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(), nd,
-                                 0, L.total_bits() - 1, &s_in_tmp));
+        CR_TRY(cr_radix_sort_u32(ctx, h_b.as<uint32_t>(), ht_b.as<uint32_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(), nd, 0,
+                                 32, &s_in_tmp));
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
             hipLaunchKernelGGL(k_low_support, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl,
-                               s_in_tmp ? k2t_b.as<uint64_t>() : k2_b.as<uint64_t>(),
-                               s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), nd, upos, n_keys, corr, inc1, low);
+                               s_in_tmp ? ht_b.as<uint32_t>() : h_b.as<uint32_t>(),
+                               s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), nd, ukey, upos, n_keys, corr, inc1, low);
             CR_HIP(ctx, hipGetLastError());
         }
     }

@@ -1,5 +1,5 @@
-// sort.hip -- LSD radix sort of 64-bit molecule keys (optionally with a 32-bit payload) built on
-// wave64 ballot multisplit, plus the small device-wide scan used by the compactions.
+// sort.hip -- LSD radix sort of 64-bit molecule keys / 32-bit group hashes (optionally with a 32-bit
+// payload) built on wave64 ballot multisplit, plus the small device-wide scan used by the compactions.
 //
 // This is the "sort" the reference gets from shardio's sorted shards + std HashMap grouping
 // (cr_lib/src/barcode_sort.rs:97-162, par_proc.rs:131-152); integer work, HBM bound: every pass
@@ -75,15 +75,16 @@ struct DigitFn {
 };
 
 // ---- pass 1: per-block digit histogram ------------------------------------------------------------
-__global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(const uint64_t *__restrict__ keys, uint64_t n,
-                                                           uint64_t tile, DigitFn dig, uint32_t *__restrict__ block_hist,
+template <typename K>
+__global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(const K *__restrict__ keys, uint64_t n, uint64_t tile,
+                                                           DigitFn dig, uint32_t *__restrict__ block_hist,
                                                            uint32_t n_blocks) {
     __shared__ uint32_t h[RADIX];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) atomicAdd(&h[dig(keys[i])], 1u);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) atomicAdd(&h[dig((uint64_t)keys[i])], 1u);
     __syncthreads();
     block_hist[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
@@ -111,15 +112,14 @@ __global__ __launch_bounds__(256) void k_scan_digits(uint32_t *__restrict__ bloc
 // keys of earlier waves + of this wave's earlier items + of lower lanes), then copied out so that
 // neighbouring threads write neighbouring addresses: the global stores are contiguous runs per digit
 // (a direct scatter issues ~56 separate 8-byte stores per wave instruction).
-template <bool HAS_VALS>
-__global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const uint64_t *__restrict__ keys_in,
-                                                              uint64_t *__restrict__ keys_out,
+template <typename K, bool HAS_VALS>
+__global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
                                                               uint32_t *__restrict__ vals_out, uint64_t n, uint64_t tile,
                                                               DigitFn dig, const uint32_t *__restrict__ block_offs,
                                                               const uint32_t *__restrict__ digit_totals,
                                                               uint32_t n_blocks) {
-    __shared__ uint64_t skeys[SORT_CHUNK];
+    __shared__ K skeys[SORT_CHUNK];
     __shared__ uint32_t svals[HAS_VALS ? SORT_CHUNK : 1];
     __shared__ uint32_t wcount[SORT_WAVES][RADIX];  // per-wave same-digit counts -> LDS position of (wave, digit)
     __shared__ uint32_t base[RADIX];                // running global offset of each digit for this block
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const uint64_t *__
         for (int w = 0; w < SORT_WAVES; w++) wcount[w][tid] = 0;
         __syncthreads();
 
-        uint64_t key[SORT_ITEMS];
+        K key[SORT_ITEMS];
         uint32_t val[SORT_ITEMS];
         uint32_t dr[SORT_ITEMS];  // (digit << 16) | rank inside (wave, digit); rank < 1024
         const uint64_t wave_base = chunk + (uint64_t)wave * (64 * SORT_ITEMS);
@@ -148,14 +148,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const uint64_t *__
         for (int it = 0; it < SORT_ITEMS; it++) {
             const uint64_t i = wave_base + (uint64_t)it * 64 + lane;
             const bool ok = i < hi;
-            key[it] = ok ? keys_in[i] : 0ull;
+            key[it] = ok ? keys_in[i] : (K)0;
             if (HAS_VALS) val[it] = ok ? vals_in[i] : 0u;
         }
 #pragma unroll
         for (int it = 0; it < SORT_ITEMS; it++) {
             const uint64_t i = wave_base + (uint64_t)it * 64 + lane;
             const bool ok = i < hi;
-            const uint32_t d = ok ? dig(key[it]) : 0u;
+            const uint32_t d = ok ? dig((uint64_t)key[it]) : 0u;
             // lanes holding the same digit: intersect the 8 bit ballots
             unsigned long long peers = __ballot(ok);
 #pragma unroll
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const uint64_t *__
         __syncthreads();
         const uint32_t chunk_n = hi - chunk < SORT_CHUNK ? (uint32_t)(hi - chunk) : SORT_CHUNK;
         for (uint32_t p = tid; p < chunk_n; p += SORT_BLOCK) {
-            const uint64_t k = skeys[p];
-            const uint32_t pos = p + gdelta[dig(k)];
+            const K k = skeys[p];
+            const uint32_t pos = p + gdelta[dig((uint64_t)k)];
             keys_out[pos] = k;
             if (HAS_VALS) vals_out[pos] = svals[p];
         }
@@ -228,15 +228,16 @@ static uint32_t sort_blocks(uint64_t n, uint64_t *tile_out) {
 static uint32_t *digit_totals_buf(crgpu_ctx *ctx) { return ctx->d_scalars + 256; }  // 256 u32 inside the scalar page
 
 // one counting-sort pass keyed by `dig` (stable).
-static int radix_pass(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, const uint32_t *d_vin, uint32_t *d_vout,
-                      uint64_t n, DigitFn dig) {
+template <typename K>
+static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d_vin, uint32_t *d_vout, uint64_t n,
+                      DigitFn dig) {
     uint64_t tile;
     const uint32_t nb = sort_blocks(n, &tile);
     uint32_t *d_hist = ctx->d_sort_hist;
     uint32_t *d_tot = digit_totals_buf(ctx);
     {
         CrTimer t(ctx, CRGPU_T_SORT_HIST, n);
-        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
     }
     {
         CrTimer t(ctx, CRGPU_T_SCAN);
@@ -244,29 +245,28 @@ static int radix_pass(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, con
     }
     CrTimer t(ctx, CRGPU_T_SORT, n);
     if (d_vin)
-        hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout, n,
-                           tile, dig, d_hist, d_tot, nb);
+        hipLaunchKernelGGL((k_radix_scatter<K, true>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout,
+                           n, tile, dig, d_hist, d_tot, nb);
     else
-        hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout, n,
-                           tile, dig, d_hist, d_tot, nb);
+        hipLaunchKernelGGL((k_radix_scatter<K, false>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout,
+                           n, tile, dig, d_hist, d_tot, nb);
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
 }
 
-// Sort d_keys[0..n) ascending on bits [lo_bit, hi_bit).  d_tmp (n keys) and, when d_vals != NULL,
-// d_vals_tmp (n u32) are ping-pong buffers; *result_in_tmp tells where the sorted data ended up.
-int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
-                      uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
+template <typename K>
+static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp, uint64_t n,
+                      uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
     *result_in_tmp = false;
     if (n <= 1 || hi_bit <= lo_bit) return CRGPU_OK;
     CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "sort: at most 2^32-2 keys per call");
-    uint64_t *in = d_keys, *out = d_tmp;
+    K *in = d_keys, *out = d_tmp;
     uint32_t *vin = d_vals, *vout = d_vals_tmp;
     for (uint32_t shift = lo_bit; shift < hi_bit; shift += RADIX_BITS) {
         const uint32_t bits = hi_bit - shift < RADIX_BITS ? hi_bit - shift : RADIX_BITS;
         DigitFn dig{shift, (1u << bits) - 1u, 1u, 0u};
-        CR_TRY(radix_pass(ctx, in, out, vin, vout, n, dig));
-        uint64_t *t = in;
+        CR_TRY(radix_pass<K>(ctx, in, out, vin, vout, n, dig));
+        K *t = in;
         in = out;
         out = t;
         uint32_t *tv = vin;
@@ -275,6 +275,18 @@ int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_
         *result_in_tmp = !*result_in_tmp;
     }
     return CRGPU_OK;
+}
+
+// Sort d_keys[0..n) ascending on bits [lo_bit, hi_bit).  d_tmp (n keys) and, when d_vals != NULL,
+// d_vals_tmp (n u32) are ping-pong buffers; *result_in_tmp tells where the sorted data ended up.
+int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
+                      uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
+    return radix_sort<uint64_t>(ctx, d_keys, d_tmp, d_vals, d_vals_tmp, n, lo_bit, hi_bit, result_in_tmp);
+}
+
+int cr_radix_sort_u32(crgpu_ctx *ctx, uint32_t *d_keys, uint32_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
+                      uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
+    return radix_sort<uint32_t>(ctx, d_keys, d_tmp, d_vals, d_vals_tmp, n, lo_bit, hi_bit, result_in_tmp);
 }
 
 // Stable partition of keys by the owner rank of their barcode: one counting-sort pass.
@@ -287,7 +299,7 @@ int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
     // rank r owns canonical barcode ranks [r*width, (r+1)*width)
     const uint32_t width = (ctx->n_canon + n_ranks - 1) / n_ranks;
     DigitFn dig{sh_bc, 0u, width ? width : 1u, 1u};
-    CR_TRY(radix_pass(ctx, d_in, d_out, nullptr, nullptr, n, dig));
+    CR_TRY(radix_pass<uint64_t>(ctx, d_in, d_out, nullptr, nullptr, n, dig));
     uint32_t totals[RADIX];
     CR_TRY(crgpu_memcpy_d2h(ctx, totals, digit_totals_buf(ctx), sizeof(totals)));
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = totals[r];
