@@ -16,8 +16,8 @@
 //   * equal keys (ignoring the last bit) are the reads of one (UMI, feature): run length = read count,
 //   * a (barcode, feature, library) segment holds every UMI that correct_umis may compare,
 //   * a (barcode, feature) segment is one matrix entry.
-// Low-support grouping needs (barcode, library, UMI) across features: a second sort of the
-// DISTINCT keys on [barcode][library][UMI][feature] with the distinct-key index as payload.
+// Low-support grouping needs (barcode, library, UMI) across features: the DISTINCT keys are sorted a
+// second time by a 32-bit hash of that triple (index as payload) and re-checked exactly.
 #include "block_utils.h"
 #include "common.h"
 
@@ -340,77 +340,7 @@ __device__ __forceinline__ uint32_t run_count(const uint32_t *__restrict__ upos,
     return end - upos[k];
 }
 
-#define SMALL_SEG 24
-
-__global__ __launch_bounds__(256) void k_correct_umis(const KL kl, const uint64_t *__restrict__ ukey,
-                                                      const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
-                                                      uint32_t *__restrict__ corr, uint32_t *__restrict__ inc1,
-                                                      uint32_t *__restrict__ inc_all) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t umi_mask = lowmask(kl.bits_umi);
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
-        const uint64_t key = ukey[k];
-        const uint32_t lib = (uint32_t)((key >> kl.sh_lib) & lowmask(kl.bits_lib));
-        uint32_t target = NONE32;
-        if (!((kl.mux_mask >> lib) & 1u)) {  // UmiCorrection::Disable for Multiplexing Capture (aligner.rs:315-318)
-            uint64_t s, e;
-            segment_bounds(ukey, nd, k, kl.sh_lib, s, e);
-            if (e - s > 1) {
-                const uint32_t my_umi = (uint32_t)((key >> kl.sh_umi) & umi_mask);
-                const uint32_t my_cnt = run_count(upos, nd, n_keys, k);
-                uint32_t best_cnt = my_cnt, best_umi = my_umi;
-                uint64_t best_idx = k;
-                if (e - s <= SMALL_SEG) {
-                    // all pairs: every existing Hamming-1 neighbour competes on (count, umi)
-                    for (uint64_t j = s; j < e; j++) {
-                        if (j == k) continue;
-                        const uint32_t u = (uint32_t)((ukey[j] >> kl.sh_umi) & umi_mask);
-                        const uint32_t x = u ^ my_umi;
-                        const uint32_t y = (x | (x >> 1)) & 0x55555555u;
-                        if (y == 0u || (y & (y - 1u)) != 0u) continue;  // not exactly one base apart
-                        const uint32_t c = run_count(upos, nd, n_keys, j);
-                        if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                            best_cnt = c;
-                            best_umi = u;
-                            best_idx = j;
-                        }
-                    }
-                } else {
-                    // 3L probes, each a binary search inside the segment (sorted by UMI)
-                    const uint64_t pre = (key >> kl.sh_lib) << kl.bits_umi;
-                    for (uint32_t pos = 0; pos < kl.umi_len; pos++) {
-                        const uint32_t sh = 2u * (kl.umi_len - 1u - pos);
-                        const uint32_t orig = (my_umi >> sh) & 3u;
-                        for (uint32_t b = 0; b < 4; b++) {
-                            if (b == orig) continue;
-                            const uint32_t u = (my_umi & ~(3u << sh)) | (b << sh);
-                            const uint64_t want = pre | u;  // == ukey >> sh_umi of the probed key
-                            uint64_t lo = s, hi = e;
-                            while (lo < hi) {
-                                const uint64_t mid = (lo + hi) >> 1;
-                                if ((ukey[mid] >> kl.sh_umi) < want) lo = mid + 1; else hi = mid;
-                            }
-                            if (lo < e && (ukey[lo] >> kl.sh_umi) == want) {
-                                const uint32_t c = run_count(upos, nd, n_keys, lo);
-                                if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                                    best_cnt = c;
-                                    best_umi = u;
-                                    best_idx = lo;
-                                }
-                            }
-                        }
-                    }
-                }
-                if (best_idx != k) {
-                    target = (uint32_t)best_idx;
-                    atomicAdd(&inc1[best_idx], 1u);          // phase 1 moves one read (mark_dups.rs:228-232)
-                    atomicAdd(&inc_all[best_idx], my_cnt);   // phases 1+2 move them all (:242-246)
-                }
-            }
-        }
-        corr[k] = target;
-    }
-}
+#include "umi_correct.h"
 
 // Representative-read bookkeeping (mark_dups.rs:248-268): for a corrected key K the representative
 // is the min-(utype, qname) read of the lexicographically smallest raw UMI R corrected onto K with
@@ -599,8 +529,8 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
         CR_HIP(ctx, hipMemsetAsync(inc_all, 0, nd * sizeof(uint32_t), ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(low, 0, nd, ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(minraw_b.p, 0xFF, nd * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_correct_umis, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, corr,
-                           inc1, inc_all);
+        hipLaunchKernelGGL(k_correct_umis_tiled, dim3(cr_grid((nd + UC_TILE - 1) / UC_TILE, 1, 256u * 4u)), dim3(256), 0,
+                           ctx->stream, kl, ukey, upos, nd, n_keys, corr, inc1, inc_all);
         hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd, corr,
                            minraw_b.as<unsigned long long>());
         CR_HIP(ctx, hipGetLastError());
