@@ -8,8 +8,9 @@
 // move to it when it beats (c, own UMI).  One step only, never transitive.
 //
 // The distinct keys are sorted, so a segment is a contiguous range.  A workgroup stages a tile of
-// UC_TILE consecutive keys (+1 halo on each side) in LDS, derives every key's segment bounds from
-// block-wide max / min scans of the segment-head flags, and searches out of LDS: all pairs for short
+// UC_TILE consecutive keys (+1 halo on each side) in LDS (lane-interleaved, so neighbouring lanes touch
+// neighbouring LDS words), derives every key's segment bounds from per-64-key ballots of the
+// segment-head flags, and searches out of LDS: all pairs for short
 // segments, 3L binary searches for long ones.  Only segments that cross a tile edge go through global
 // memory (galloping bounds + binary searches).
 #pragma once
@@ -76,35 +77,7 @@ __device__ uint32_t correct_one_global(const KL &kl, const uint64_t *__restrict_
     return best_idx != k ? (uint32_t)best_idx : NONE32;
 }
 
-// inclusive scans over the 256 threads of a workgroup (4 waves), forward max / backward min
-__device__ __forceinline__ int block_incl_max_256(int v, int *lds) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v = v > y ? v : y;
-    }
-    if (lane == 63u) lds[wave] = v;
-    __syncthreads();
-    int carry = -1;
-    for (uint32_t w = 0; w < wave; w++) carry = carry > lds[w] ? carry : lds[w];
-    __syncthreads();
-    return v > carry ? v : carry;
-}
-__device__ __forceinline__ int block_incl_min_rev_256(int v, int *lds) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_down(v, d);
-        if (lane + (uint32_t)d < 64u) v = v < y ? v : y;
-    }
-    if (lane == 0u) lds[wave] = v;
-    __syncthreads();
-    int carry = 0x7FFFFFFF;
-    for (uint32_t w = wave + 1; w < 4; w++) carry = carry < lds[w] ? carry : lds[w];
-    __syncthreads();
-    return v < carry ? v : carry;
-}
+#define UC_BLOCKS (UC_TILE / 64)
 
 __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const uint64_t *__restrict__ ukey,
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
@@ -113,17 +86,19 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
     __shared__ uint64_t s_pre[UC_TILE + 2];  // segment id (key >> sh_lib) of positions -1 .. UC_TILE
     __shared__ uint32_t s_umi[UC_TILE];
     __shared__ uint32_t s_cnt[UC_TILE];
-    __shared__ int lds[4];
-    __shared__ int s_incl_last[256];
-    __shared__ int s_incl_next[256];
-    const uint32_t tid = threadIdx.x;
+    __shared__ unsigned long long s_heads[UC_BLOCKS];  // bit l of entry b: position 64*b+l starts a segment
+    __shared__ int s_carry_start[UC_BLOCKS];           // last segment start in blocks < b, or -1
+    __shared__ int s_carry_end[UC_BLOCKS];             // first segment start in blocks > b (UC_TILE = halo), or INT_MAX
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
     const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t t0 = tile * UC_TILE;
         const uint32_t tn = nd - t0 < UC_TILE ? (uint32_t)(nd - t0) : UC_TILE;
-        // ---- stage (coalesced) ----
-        for (uint32_t p = tid; p < UC_TILE; p += 256) {
+        // ---- stage (coalesced; lane l of round r holds position 256*r + tid) ----
+#pragma unroll
+        for (int r = 0; r < UC_ITEMS; r++) {
+            const uint32_t p = (uint32_t)r * 256u + tid;
             if (p < tn) {
                 const uint64_t key = ukey[t0 + p];
                 s_pre[p + 1] = key >> kl.sh_lib;
@@ -139,47 +114,52 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             s_pre[UC_TILE + 1] = t0 + UC_TILE < nd ? (ukey[t0 + UC_TILE] >> kl.sh_lib) : ~0ull;
         }
         __syncthreads();
-        // ---- segment bounds: thread owns positions [8*tid, 8*tid+8) ----
-        const uint32_t p0 = tid * UC_ITEMS;
-        uint32_t head_mask = 0;  // bit j: position p0+j starts a segment
-        uint32_t headn_mask = 0; // bit j: position p0+j+1 starts a segment (position UC_TILE = halo)
+        // ---- segment-head bitmask of every 64-position block ----
 #pragma unroll
-        for (int j = 0; j < UC_ITEMS; j++) {
-            if (s_pre[p0 + j + 1] != s_pre[p0 + j]) head_mask |= 1u << j;
-            if (s_pre[p0 + j + 2] != s_pre[p0 + j + 1]) headn_mask |= 1u << j;
+        for (int r = 0; r < UC_ITEMS; r++) {
+            const uint32_t p = (uint32_t)r * 256u + tid;
+            const unsigned long long m = __ballot(s_pre[p + 1] != s_pre[p]);
+            if (lane == 0) s_heads[p >> 6] = m;
         }
-        // last head at or before each position (forward max scan); -1 = the segment starts left of the tile.
-        // Position 0 is a closed start only when the halo differs, which head_mask bit 0 already encodes.
-        const int my_last_head = head_mask ? (int)(p0 + 31u - (uint32_t)__clz((int)head_mask)) : -1;
-        const int incl_last = block_incl_max_256(my_last_head, lds);
-        // first segment start strictly after each position (backward min scan over "next is head" flags)
-        const int my_first_next = headn_mask ? (int)(p0 + (uint32_t)__ffs((int)headn_mask)) : 0x7FFFFFFF;  // = index of the next head
-        const int incl_next = block_incl_min_rev_256(my_first_next, lds);
-        // exclusive carries of the neighbouring threads, handed over through LDS
-        s_incl_last[tid] = incl_last;
-        s_incl_next[tid] = incl_next;
         __syncthreads();
-        const int carry_l = tid > 0 ? s_incl_last[tid - 1] : -1;
-        const int carry_r = tid < 255 ? s_incl_next[tid + 1] : 0x7FFFFFFF;
-
-        int cur_start = carry_l;
-#pragma unroll
-        for (int j = 0; j < UC_ITEMS; j++) {
-            const uint32_t p = p0 + j;
-            if (head_mask & (1u << j)) cur_start = (int)p;
+        if (tid < UC_BLOCKS) {
+            // serial prefix / suffix over 32 blocks (one thread each direction would do; all 32 threads
+            // compute their own entry by walking, it is 32 steps at most)
+            int cs = -1;
+            for (int b = 0; b < (int)tid; b++) {
+                const unsigned long long m = s_heads[b];
+                if (m) cs = b * 64 + 63 - __clzll((long long)m);
+            }
+            s_carry_start[tid] = cs;
+            int ce = 0x7FFFFFFF;
+            if (s_pre[UC_TILE + 1] != s_pre[UC_TILE]) ce = UC_TILE;  // the halo starts a new segment
+            for (int b = UC_BLOCKS - 1; b > (int)tid; b--) {
+                const unsigned long long m = s_heads[b];
+                if (m) ce = b * 64 + (__ffsll((long long)m) - 1);
+            }
+            s_carry_end[tid] = ce;
+        }
+        __syncthreads();
+        // ---- one key per lane per round ----
+#pragma unroll 1
+        for (int r = 0; r < UC_ITEMS; r++) {
+            const uint32_t p = (uint32_t)r * 256u + tid;
             if (p >= tn) continue;
-            // exclusive end = first head after p: inside this thread's range or from the right carry
-            const uint32_t later = headn_mask >> j;  // bit i: position p+i+1 is a head
-            int end = later ? (int)(p + (uint32_t)__ffs((int)later)) : carry_r;
+            const uint32_t b = p >> 6;
+            const unsigned long long heads = s_heads[b];
+            const unsigned long long le = heads & ((2ull << lane) - 1ull);  // heads at or before p
+            const int start = le ? (int)(b * 64u + 63u - (uint32_t)__clzll((long long)le)) : s_carry_start[b];
+            const unsigned long long gt = lane < 63u ? (heads >> (lane + 1u)) : 0ull;  // heads after p
+            const int end = gt ? (int)(p + (uint32_t)__ffsll((long long)gt)) : s_carry_end[b];
             const uint64_t k = t0 + p;
             const uint32_t my_umi = s_umi[p], my_cnt = s_cnt[p];
             const uint32_t lib = (uint32_t)(s_pre[p + 1] & lowmask(kl.bits_lib));
             uint32_t target = NONE32;
             if (!((kl.mux_mask >> lib) & 1u)) {  // UmiCorrection::Disable for Multiplexing Capture (aligner.rs:315-318)
-                if (cur_start < 0 || end > (int)UC_TILE) {
+                if (start < 0 || end > (int)UC_TILE) {
                     target = correct_one_global(kl, ukey, upos, nd, n_keys, k, my_cnt);
-                } else if (end - cur_start > 1) {
-                    const uint32_t s = (uint32_t)cur_start, e = (uint32_t)end;
+                } else if (end - start > 1) {
+                    const uint32_t s = (uint32_t)start, e = (uint32_t)end;
                     uint32_t best_cnt = my_cnt, best_umi = my_umi, best_p = p;
                     if (e - s <= UC_SMALL) {
                         for (uint32_t q = s; q < e; q++) {
@@ -196,9 +176,9 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
                         for (uint32_t pos = 0; pos < kl.umi_len; pos++) {
                             const uint32_t sh = 2u * (kl.umi_len - 1u - pos);
                             const uint32_t orig = (my_umi >> sh) & 3u;
-                            for (uint32_t b = 0; b < 4; b++) {
-                                if (b == orig) continue;
-                                const uint32_t u = (my_umi & ~(3u << sh)) | (b << sh);
+                            for (uint32_t bb = 0; bb < 4; bb++) {
+                                if (bb == orig) continue;
+                                const uint32_t u = (my_umi & ~(3u << sh)) | (bb << sh);
                                 uint32_t lo = s, hi = e;
                                 while (lo < hi) {
                                     const uint32_t mid = (lo + hi) >> 1;
