@@ -8,22 +8,17 @@
 // move to it when it beats (c, own UMI).  One step only, never transitive.
 //
 // The distinct keys are sorted, so a segment is a contiguous range.  A workgroup stages a tile of
-// UC_TILE consecutive keys in LDS (lane-interleaved, so neighbouring lanes touch neighbouring LDS
-// words) and derives every key's segment bounds from per-64-key ballots of the segment-head flags.
-//   * short segments (<= UC_SMALL keys): all pairs out of LDS;
-//   * long segments inside the tile: the reference's own 3L probes, against an LDS hash set of the
-//     tile's long-segment keys (one probe ~ one LDS read, instead of a log2(m)-step binary search);
-//   * segments that cross a tile edge: global memory (galloping bounds + binary searches).
+// UC_TILE consecutive keys (+1 halo on each side) in LDS (lane-interleaved, so neighbouring lanes touch
+// neighbouring LDS words), derives every key's segment bounds from per-64-key ballots of the
+// segment-head flags, and searches out of LDS: all pairs for short
+// segments, 3L binary searches for long ones.  Only segments that cross a tile edge go through global
+// memory (galloping bounds + binary searches).
 #pragma once
 
 #define UC_ITEMS 8
 #define UC_TILE (256 * UC_ITEMS)
-#define UC_BLOCKS (UC_TILE / 64)
 #define UC_SMALL 32
 #define UC_OPEN 0xFFFFu
-#define UC_HASH 4096u  // slots; at most UC_TILE keys are inserted (load <= 0.5)
-#define UC_EMPTY 0xFFFFFFFFu
-#define UC_NOCORR 0x80000000u  // flag inside s_cnt: UMI correction disabled for this key's library
 
 __device__ __forceinline__ bool hd1(uint32_t a, uint32_t b) {
     const uint32_t x = a ^ b;
@@ -82,69 +77,62 @@ __device__ uint32_t correct_one_global(const KL &kl, const uint64_t *__restrict_
     return best_idx != k ? (uint32_t)best_idx : NONE32;
 }
 
-__device__ __forceinline__ uint32_t uc_hash(uint32_t seg_start, uint32_t umi) {
-    uint32_t h = umi * 0x9E3779B1u ^ (seg_start * 0x85EBCA6Bu);
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
-    h ^= h >> 13;
-    return h & (UC_HASH - 1u);
-}
+#define UC_BLOCKS (UC_TILE / 64)
 
 __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const uint64_t *__restrict__ ukey,
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
                                                             uint64_t n_keys, uint32_t *__restrict__ corr,
                                                             uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all) {
+    __shared__ uint64_t s_pre[UC_TILE + 2];  // segment id (key >> sh_lib) of positions -1 .. UC_TILE
     __shared__ uint32_t s_umi[UC_TILE];
-    __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
-    __shared__ uint16_t s_start[UC_TILE];  // segment start inside the tile, UC_OPEN = not fully inside the tile
-    __shared__ uint16_t s_end[UC_TILE];    // exclusive end
-    __shared__ uint32_t s_hash[UC_HASH];   // open addressing: tile position of a long-segment key
+    __shared__ uint32_t s_cnt[UC_TILE];
     __shared__ unsigned long long s_heads[UC_BLOCKS];  // bit l of entry b: position 64*b+l starts a segment
     __shared__ int s_carry_start[UC_BLOCKS];           // last segment start in blocks < b, or -1
-    __shared__ int s_carry_end[UC_BLOCKS];             // first segment start in blocks > b, or INT_MAX
-    __shared__ uint32_t s_halo_head;                   // position UC_TILE starts a new segment
+    __shared__ int s_carry_end[UC_BLOCKS];             // first segment start in blocks > b (UC_TILE = halo), or INT_MAX
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
     const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
-    for (uint32_t h = tid; h < UC_HASH; h += 256) s_hash[h] = UC_EMPTY;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t t0 = tile * UC_TILE;
         const uint32_t tn = nd - t0 < UC_TILE ? (uint32_t)(nd - t0) : UC_TILE;
-        // ---- stage (coalesced; lane l of round r holds position 256*r + tid) + head flags ----
+        // ---- stage (coalesced; lane l of round r holds position 256*r + tid) ----
 #pragma unroll
         for (int r = 0; r < UC_ITEMS; r++) {
             const uint32_t p = (uint32_t)r * 256u + tid;
-            bool head = false;
             if (p < tn) {
                 const uint64_t key = ukey[t0 + p];
-                const uint64_t pre = key >> kl.sh_lib;
-                // the previous key is the neighbouring lane's load (same cache line)
-                head = (t0 + p == 0) || (ukey[t0 + p - 1] >> kl.sh_lib) != pre;
+                s_pre[p + 1] = key >> kl.sh_lib;
                 s_umi[p] = (uint32_t)((key >> kl.sh_umi) & umi_mask);
                 const uint32_t end = t0 + p + 1 < nd ? upos[t0 + p + 1] : (uint32_t)n_keys;
-                const uint32_t lib = (uint32_t)(pre & lowmask(kl.bits_lib));
-                // UmiCorrection::Disable for Multiplexing Capture (aligner.rs:315-318)
-                s_cnt[p] = (end - upos[t0 + p]) | (((kl.mux_mask >> lib) & 1u) ? UC_NOCORR : 0u);
+                s_cnt[p] = end - upos[t0 + p];
             } else {
-                head = p == tn;  // the padding behind the last key closes the last segment
+                s_pre[p + 1] = ~0ull;  // never equals a real segment id (a real one has < 63 bits)
             }
-            const unsigned long long m = __ballot(head);
-            if (lane == 0) s_heads[p >> 6] = m;
         }
         if (tid == 0) {
-            bool hh = true;  // the end of the array closes the segment
-            if (t0 + UC_TILE < nd) hh = (ukey[t0 + UC_TILE] >> kl.sh_lib) != (ukey[t0 + UC_TILE - 1] >> kl.sh_lib);
-            s_halo_head = hh ? 1u : 0u;
+            s_pre[0] = t0 > 0 ? (ukey[t0 - 1] >> kl.sh_lib) : ~0ull;
+            s_pre[UC_TILE + 1] = t0 + UC_TILE < nd ? (ukey[t0 + UC_TILE] >> kl.sh_lib) : ~0ull;
+        }
+        __syncthreads();
+        // ---- segment-head bitmask of every 64-position block ----
+#pragma unroll
+        for (int r = 0; r < UC_ITEMS; r++) {
+            const uint32_t p = (uint32_t)r * 256u + tid;
+            const unsigned long long m = __ballot(s_pre[p + 1] != s_pre[p]);
+            if (lane == 0) s_heads[p >> 6] = m;
         }
         __syncthreads();
         if (tid < UC_BLOCKS) {
+            // serial prefix / suffix over 32 blocks (one thread each direction would do; all 32 threads
+            // compute their own entry by walking, it is 32 steps at most)
             int cs = -1;
             for (int b = 0; b < (int)tid; b++) {
                 const unsigned long long m = s_heads[b];
                 if (m) cs = b * 64 + 63 - __clzll((long long)m);
             }
             s_carry_start[tid] = cs;
-            int ce = s_halo_head ? (int)UC_TILE : 0x7FFFFFFF;
+            int ce = 0x7FFFFFFF;
+            if (s_pre[UC_TILE + 1] != s_pre[UC_TILE]) ce = UC_TILE;  // the halo starts a new segment
             for (int b = UC_BLOCKS - 1; b > (int)tid; b--) {
                 const unsigned long long m = s_heads[b];
                 if (m) ce = b * 64 + (__ffsll((long long)m) - 1);
@@ -152,8 +140,8 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             s_carry_end[tid] = ce;
         }
         __syncthreads();
-        // ---- segment bounds of every key; long in-tile segments enter the hash set ----
-#pragma unroll
+        // ---- one key per lane per round ----
+#pragma unroll 1
         for (int r = 0; r < UC_ITEMS; r++) {
             const uint32_t p = (uint32_t)r * 256u + tid;
             if (p >= tn) continue;
@@ -163,36 +151,21 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             const int start = le ? (int)(b * 64u + 63u - (uint32_t)__clzll((long long)le)) : s_carry_start[b];
             const unsigned long long gt = lane < 63u ? (heads >> (lane + 1u)) : 0ull;  // heads after p
             const int end = gt ? (int)(p + (uint32_t)__ffsll((long long)gt)) : s_carry_end[b];
-            const bool closed = start >= 0 && end <= (int)UC_TILE;
-            s_start[p] = closed ? (uint16_t)start : (uint16_t)UC_OPEN;
-            s_end[p] = closed ? (uint16_t)end : (uint16_t)UC_OPEN;
-            if (closed && end - start > UC_SMALL) {
-                uint32_t h = uc_hash((uint32_t)start, s_umi[p]);
-                while (atomicCAS(&s_hash[h], UC_EMPTY, p) != UC_EMPTY) h = (h + 1u) & (UC_HASH - 1u);
-            }
-        }
-        __syncthreads();
-        // ---- one key per lane per round ----
-#pragma unroll 1
-        for (int r = 0; r < UC_ITEMS; r++) {
-            const uint32_t p = (uint32_t)r * 256u + tid;
-            if (p >= tn) continue;
             const uint64_t k = t0 + p;
-            const uint32_t my_umi = s_umi[p];
-            const uint32_t cw = s_cnt[p];
-            const uint32_t my_cnt = cw & ~UC_NOCORR;
+            const uint32_t my_umi = s_umi[p], my_cnt = s_cnt[p];
+            const uint32_t lib = (uint32_t)(s_pre[p + 1] & lowmask(kl.bits_lib));
             uint32_t target = NONE32;
-            if (!(cw & UC_NOCORR)) {
-                const uint32_t s = s_start[p], e = s_end[p];
-                if (s == UC_OPEN) {
+            if (!((kl.mux_mask >> lib) & 1u)) {  // UmiCorrection::Disable for Multiplexing Capture (aligner.rs:315-318)
+                if (start < 0 || end > (int)UC_TILE) {
                     target = correct_one_global(kl, ukey, upos, nd, n_keys, k, my_cnt);
-                } else if (e - s > 1) {
+                } else if (end - start > 1) {
+                    const uint32_t s = (uint32_t)start, e = (uint32_t)end;
                     uint32_t best_cnt = my_cnt, best_umi = my_umi, best_p = p;
                     if (e - s <= UC_SMALL) {
                         for (uint32_t q = s; q < e; q++) {
                             const uint32_t u = s_umi[q];
                             if (!hd1(u, my_umi)) continue;
-                            const uint32_t c = s_cnt[q] & ~UC_NOCORR;
+                            const uint32_t c = s_cnt[q];
                             if (c > best_cnt || (c == best_cnt && u > best_umi)) {
                                 best_cnt = c;
                                 best_umi = u;
@@ -206,20 +179,18 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
                             for (uint32_t bb = 0; bb < 4; bb++) {
                                 if (bb == orig) continue;
                                 const uint32_t u = (my_umi & ~(3u << sh)) | (bb << sh);
-                                uint32_t h = uc_hash(s, u);
-                                for (;;) {
-                                    const uint32_t q = s_hash[h];
-                                    if (q == UC_EMPTY) break;
-                                    if (s_umi[q] == u && s_start[q] == s) {
-                                        const uint32_t c = s_cnt[q] & ~UC_NOCORR;
-                                        if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                                            best_cnt = c;
-                                            best_umi = u;
-                                            best_p = q;
-                                        }
-                                        break;
+                                uint32_t lo = s, hi = e;
+                                while (lo < hi) {
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if (s_umi[mid] < u) lo = mid + 1; else hi = mid;
+                                }
+                                if (lo < e && s_umi[lo] == u) {
+                                    const uint32_t c = s_cnt[lo];
+                                    if (c > best_cnt || (c == best_cnt && u > best_umi)) {
+                                        best_cnt = c;
+                                        best_umi = u;
+                                        best_p = lo;
                                     }
-                                    h = (h + 1u) & (UC_HASH - 1u);
                                 }
                             }
                         }
@@ -233,8 +204,6 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
                 atomicAdd(&inc_all[target], my_cnt);   // phases 1+2 move them all (:242-246)
             }
         }
-        __syncthreads();
-        for (uint32_t h = tid; h < UC_HASH; h += 256) s_hash[h] = UC_EMPTY;
         __syncthreads();
     }
 }
