@@ -104,6 +104,9 @@ class HipBackend:
         self._keep.append(counts)
         return counts
 
+    def triplet_arrays(self, counts):
+        return counts.triplets_dev()
+
     def triplet_tensors(self, counts):
         b, f, c = counts.triplets_dev()
         n = counts.n_triplets
@@ -123,16 +126,18 @@ class HipBackend:
 class CountPipeline:
     """barcode-correct -> UMI-dedup -> matrix for one shard of reads per rank."""
 
-    def __init__(self, backend, libs=(0,), dist=None):
+    def __init__(self, backend, libs=(0,), dist=None, force_collectives=False):
         self.be = backend
         self.libs = list(libs)
         self.dist = dist  # torch.distributed module (initialised) or None for a single process
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
+        # exercise C1/C2/C3 even with one rank (tests: a 1-rank RCCL group on the single-GPU box)
+        self.collective = dist is not None and (self.world > 1 or force_collectives)
 
     # -- collectives -------------------------------------------------------------------------------------
     def _allreduce_hist(self, which):
-        if self.world == 1:
+        if not self.collective:
             return
         self.be.before_collective()
         for lib in self.libs:
@@ -190,11 +195,11 @@ class CountPipeline:
         self.correct_barcodes(shard)
         self._allreduce_hist(COUNTS_CORRECTED)   # matrix columns = barcodes seen on ANY rank
         keys, n_keys = self.be.build_keys(shard)
-        if self.world > 1:
+        if self.collective:
             keys, n_keys = self._all_to_all_keys(keys, n_keys)
         counts = self.be.count_keys(keys, n_keys)
-        if self.world == 1:
-            b, f, c = counts.triplets_dev() if hasattr(counts, "triplets_dev") else self.be.triplet_ptrs(counts)
+        if not self.collective:
+            b, f, c = self.be.triplet_arrays(counts)
             return self.be.assemble(b, f, c, counts.n_triplets)
         arrs, total = self._gather_triplets(counts)
         if self.rank != 0:
