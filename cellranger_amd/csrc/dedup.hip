@@ -529,8 +529,20 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
         CR_HIP(ctx, hipMemsetAsync(inc_all, 0, nd * sizeof(uint32_t), ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(low, 0, nd, ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(minraw_b.p, 0xFF, nd * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_correct_umis_tiled, dim3(cr_grid((nd + UC_TILE - 1) / UC_TILE, 1, 256u * 4u)), dim3(256), 0,
-                           ctx->stream, kl, ukey, upos, nd, n_keys, corr, inc1, inc_all);
+        const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
+        hipLaunchKernelGGL(k_correct_umis_tiled, dim3(cr_grid(n_tiles, 1, 256u * 4u)), dim3(256), 0, ctx->stream, kl, ukey,
+                           upos, nd, n_keys, corr, inc1, inc_all);
+        if (n_tiles > 1) {
+            const size_t edge_lds = (2 * UE_CAP + UE_HASH) * sizeof(uint32_t);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void *)k_correct_umis_edges, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)edge_lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_correct_umis_edges, dim3(cr_grid(n_tiles - 1, 1, 256u * 2u)), dim3(UE_THREADS), edge_lds,
+                               ctx->stream, kl, ukey, upos, nd, n_keys, corr, inc1, inc_all);
+        }
         hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd, corr,
                            minraw_b.as<unsigned long long>());
         CR_HIP(ctx, hipGetLastError());

@@ -1,4 +1,4 @@
-// umi_correct.h -- UMI correction kernel (correct_umis, tx_annotation/src/mark_dups.rs:19-59).
+// umi_correct.h -- UMI correction kernels (correct_umis, tx_annotation/src/mark_dups.rs:19-59).
 // Included by dedup.hip after KL / lowmask / segment_bounds / run_count are defined.
 //
 // For every distinct key (barcode, feature, library, UMI) with read count c: among the EXISTING keys of
@@ -7,18 +7,34 @@
 // `count > best || (count == best && umi > best_umi)`, which is an order-independent arg-max -- and
 // move to it when it beats (c, own UMI).  One step only, never transitive.
 //
-// The distinct keys are sorted, so a segment is a contiguous range.  A workgroup stages a tile of
-// UC_TILE consecutive keys (+1 halo on each side) in LDS (lane-interleaved, so neighbouring lanes touch
-// neighbouring LDS words), derives every key's segment bounds from per-64-key ballots of the
-// segment-head flags, and searches out of LDS: all pairs for short
-// segments, 3L binary searches for long ones.  Only segments that cross a tile edge go through global
-// memory (galloping bounds + binary searches).
+// The distinct keys are sorted, so a segment is a contiguous range.  Two kernels cover every key once:
+//
+//  k_correct_umis_tiled  A workgroup stages a tile of UC_TILE consecutive keys in LDS (lane-interleaved)
+//      and derives every key's segment bounds from per-64-key ballots of the segment-head flags.
+//      Segments that lie completely inside the tile are finished here: short ones (<= UC_SMALL keys) by
+//      all pairs, long ones by the reference's 3L probes against an LDS hash set of the tile's
+//      long-segment keys.  Keys of segments that cross a tile edge are left alone.
+//  k_correct_umis_edges  One workgroup per tile boundary that falls strictly inside a segment (the
+//      first such boundary owns the segment): the whole segment is loaded into LDS with a hash set and
+//      finished the same way; segments larger than the LDS budget fall back to binary searches in
+//      global memory.
+//
+// 3L probes into a hash set cost ~1.3 LDS reads each; the same probes as binary searches cost
+// log2(m) dependent reads each and were the dominant cost of the whole count stage.
 #pragma once
 
 #define UC_ITEMS 8
 #define UC_TILE (256 * UC_ITEMS)
+#define UC_BLOCKS (UC_TILE / 64)
 #define UC_SMALL 32
 #define UC_OPEN 0xFFFFu
+#define UC_HASH 4096u  // slots of the tile hash set; at most UC_TILE keys are inserted (load <= 0.5)
+#define UC_EMPTY 0xFFFFFFFFu
+#define UC_NOCORR 0x80000000u  // flag inside the staged count: UMI correction disabled for the key's library
+
+#define UE_THREADS 512
+#define UE_CAP 8192u     // keys of one edge segment held in LDS
+#define UE_HASH 16384u   // slots of its hash set
 
 __device__ __forceinline__ bool hd1(uint32_t a, uint32_t b) {
     const uint32_t x = a ^ b;
@@ -26,50 +42,34 @@ __device__ __forceinline__ bool hd1(uint32_t a, uint32_t b) {
     return y != 0u && (y & (y - 1u)) == 0u;
 }
 
-// global-memory path for one key (segments that are not fully inside a tile)
+// global-memory path for one key of the segment [s, e)
 __device__ uint32_t correct_one_global(const KL &kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ upos,
-                                       uint64_t nd, uint64_t n_keys, uint64_t k, uint32_t my_cnt) {
+                                       uint64_t nd, uint64_t n_keys, uint64_t k, uint32_t my_cnt, uint64_t s, uint64_t e) {
     const uint64_t umi_mask = lowmask(kl.bits_umi);
     const uint64_t key = ukey[k];
-    uint64_t s, e;
-    segment_bounds(ukey, nd, k, kl.sh_lib, s, e);
     if (e - s <= 1) return NONE32;
     const uint32_t my_umi = (uint32_t)((key >> kl.sh_umi) & umi_mask);
     uint32_t best_cnt = my_cnt, best_umi = my_umi;
     uint64_t best_idx = k;
-    if (e - s <= UC_SMALL) {
-        for (uint64_t j = s; j < e; j++) {
-            if (j == k) continue;
-            const uint32_t u = (uint32_t)((ukey[j] >> kl.sh_umi) & umi_mask);
-            if (!hd1(u, my_umi)) continue;
-            const uint32_t c = run_count(upos, nd, n_keys, j);
-            if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                best_cnt = c;
-                best_umi = u;
-                best_idx = j;
+    const uint64_t pre = (key >> kl.sh_lib) << kl.bits_umi;
+    for (uint32_t pos = 0; pos < kl.umi_len; pos++) {
+        const uint32_t sh = 2u * (kl.umi_len - 1u - pos);
+        const uint32_t orig = (my_umi >> sh) & 3u;
+        for (uint32_t b = 0; b < 4; b++) {
+            if (b == orig) continue;
+            const uint32_t u = (my_umi & ~(3u << sh)) | (b << sh);
+            const uint64_t want = pre | u;  // == ukey >> sh_umi of the probed key
+            uint64_t lo = s, hi = e;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if ((ukey[mid] >> kl.sh_umi) < want) lo = mid + 1; else hi = mid;
             }
-        }
-    } else {
-        const uint64_t pre = (key >> kl.sh_lib) << kl.bits_umi;
-        for (uint32_t pos = 0; pos < kl.umi_len; pos++) {
-            const uint32_t sh = 2u * (kl.umi_len - 1u - pos);
-            const uint32_t orig = (my_umi >> sh) & 3u;
-            for (uint32_t b = 0; b < 4; b++) {
-                if (b == orig) continue;
-                const uint32_t u = (my_umi & ~(3u << sh)) | (b << sh);
-                const uint64_t want = pre | u;  // == ukey >> sh_umi of the probed key
-                uint64_t lo = s, hi = e;
-                while (lo < hi) {
-                    const uint64_t mid = (lo + hi) >> 1;
-                    if ((ukey[mid] >> kl.sh_umi) < want) lo = mid + 1; else hi = mid;
-                }
-                if (lo < e && (ukey[lo] >> kl.sh_umi) == want) {
-                    const uint32_t c = run_count(upos, nd, n_keys, lo);
-                    if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                        best_cnt = c;
-                        best_umi = u;
-                        best_idx = lo;
-                    }
+            if (lo < e && (ukey[lo] >> kl.sh_umi) == want) {
+                const uint32_t c = run_count(upos, nd, n_keys, lo);
+                if (c > best_cnt || (c == best_cnt && u > best_umi)) {
+                    best_cnt = c;
+                    best_umi = u;
+                    best_idx = lo;
                 }
             }
         }
@@ -77,62 +77,117 @@ __device__ uint32_t correct_one_global(const KL &kl, const uint64_t *__restrict_
     return best_idx != k ? (uint32_t)best_idx : NONE32;
 }
 
-#define UC_BLOCKS (UC_TILE / 64)
+__device__ __forceinline__ uint32_t uc_hash(uint32_t seg_start, uint32_t umi, uint32_t mask) {
+    uint32_t h = umi * 0x9E3779B1u ^ (seg_start * 0x85EBCA6Bu);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h & mask;
+}
+
+// best Hamming-1 neighbour of (my_umi, my_cnt) among the keys of segment [s, e) staged in LDS.
+// `seg_tag` distinguishes segments inside one hash set.  Returns the LDS position or `self`.
+template <uint32_t HASH_SLOTS>
+__device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, const uint32_t *s_cnt, const uint32_t *s_hash,
+                                                       const uint16_t *s_tag, uint32_t s, uint32_t e, uint32_t seg_tag,
+                                                       uint32_t self, uint32_t my_umi, uint32_t my_cnt, uint32_t umi_len) {
+    uint32_t best_cnt = my_cnt, best_umi = my_umi, best_p = self;
+    if (e - s <= UC_SMALL) {
+        for (uint32_t q = s; q < e; q++) {
+            const uint32_t u = s_umi[q];
+            if (!hd1(u, my_umi)) continue;
+            const uint32_t c = s_cnt[q] & ~UC_NOCORR;
+            if (c > best_cnt || (c == best_cnt && u > best_umi)) {
+                best_cnt = c;
+                best_umi = u;
+                best_p = q;
+            }
+        }
+    } else {
+        for (uint32_t pos = 0; pos < umi_len; pos++) {
+            const uint32_t sh = 2u * (umi_len - 1u - pos);
+            const uint32_t orig = (my_umi >> sh) & 3u;
+            for (uint32_t bb = 0; bb < 4; bb++) {
+                if (bb == orig) continue;
+                const uint32_t u = (my_umi & ~(3u << sh)) | (bb << sh);
+                uint32_t h = uc_hash(seg_tag, u, HASH_SLOTS - 1u);
+                for (;;) {
+                    const uint32_t q = s_hash[h];
+                    if (q == UC_EMPTY) break;
+                    if (s_umi[q] == u && (s_tag == nullptr || s_tag[q] == (uint16_t)seg_tag)) {
+                        const uint32_t c = s_cnt[q] & ~UC_NOCORR;
+                        if (c > best_cnt || (c == best_cnt && u > best_umi)) {
+                            best_cnt = c;
+                            best_umi = u;
+                            best_p = q;
+                        }
+                        break;
+                    }
+                    h = (h + 1u) & (HASH_SLOTS - 1u);
+                }
+            }
+        }
+    }
+    return best_p;
+}
 
 __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const uint64_t *__restrict__ ukey,
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
                                                             uint64_t n_keys, uint32_t *__restrict__ corr,
                                                             uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all) {
-    __shared__ uint64_t s_pre[UC_TILE + 2];  // segment id (key >> sh_lib) of positions -1 .. UC_TILE
     __shared__ uint32_t s_umi[UC_TILE];
-    __shared__ uint32_t s_cnt[UC_TILE];
+    __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
+    __shared__ uint16_t s_start[UC_TILE];  // segment start inside the tile, UC_OPEN = not fully inside the tile
+    __shared__ uint16_t s_end[UC_TILE];    // exclusive end
+    __shared__ uint32_t s_hash[UC_HASH];   // open addressing: tile position of a long-segment key
     __shared__ unsigned long long s_heads[UC_BLOCKS];  // bit l of entry b: position 64*b+l starts a segment
     __shared__ int s_carry_start[UC_BLOCKS];           // last segment start in blocks < b, or -1
-    __shared__ int s_carry_end[UC_BLOCKS];             // first segment start in blocks > b (UC_TILE = halo), or INT_MAX
+    __shared__ int s_carry_end[UC_BLOCKS];             // first segment start in blocks > b, or INT_MAX
+    __shared__ uint32_t s_halo_head;                   // position UC_TILE starts a new segment
+    __shared__ uint32_t s_any_long;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
     const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
+    for (uint32_t h = tid; h < UC_HASH; h += 256) s_hash[h] = UC_EMPTY;
+    if (tid == 0) s_any_long = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t t0 = tile * UC_TILE;
         const uint32_t tn = nd - t0 < UC_TILE ? (uint32_t)(nd - t0) : UC_TILE;
-        // ---- stage (coalesced; lane l of round r holds position 256*r + tid) ----
+        // ---- stage (coalesced; lane l of round r holds position 256*r + tid) + head flags ----
 #pragma unroll
         for (int r = 0; r < UC_ITEMS; r++) {
             const uint32_t p = (uint32_t)r * 256u + tid;
+            bool head = false;
             if (p < tn) {
                 const uint64_t key = ukey[t0 + p];
-                s_pre[p + 1] = key >> kl.sh_lib;
+                const uint64_t pre = key >> kl.sh_lib;
+                // the previous key is the neighbouring lane's load (same cache line)
+                head = (t0 + p == 0) || (ukey[t0 + p - 1] >> kl.sh_lib) != pre;
                 s_umi[p] = (uint32_t)((key >> kl.sh_umi) & umi_mask);
                 const uint32_t end = t0 + p + 1 < nd ? upos[t0 + p + 1] : (uint32_t)n_keys;
-                s_cnt[p] = end - upos[t0 + p];
+                const uint32_t lib = (uint32_t)(pre & lowmask(kl.bits_lib));
+                // UmiCorrection::Disable for Multiplexing Capture (aligner.rs:315-318)
+                s_cnt[p] = (end - upos[t0 + p]) | (((kl.mux_mask >> lib) & 1u) ? UC_NOCORR : 0u);
             } else {
-                s_pre[p + 1] = ~0ull;  // never equals a real segment id (a real one has < 63 bits)
+                head = p == tn;  // the padding behind the last key closes the last segment
             }
+            const unsigned long long m = __ballot(head);
+            if (lane == 0) s_heads[p >> 6] = m;
         }
         if (tid == 0) {
-            s_pre[0] = t0 > 0 ? (ukey[t0 - 1] >> kl.sh_lib) : ~0ull;
-            s_pre[UC_TILE + 1] = t0 + UC_TILE < nd ? (ukey[t0 + UC_TILE] >> kl.sh_lib) : ~0ull;
-        }
-        __syncthreads();
-        // ---- segment-head bitmask of every 64-position block ----
-#pragma unroll
-        for (int r = 0; r < UC_ITEMS; r++) {
-            const uint32_t p = (uint32_t)r * 256u + tid;
-            const unsigned long long m = __ballot(s_pre[p + 1] != s_pre[p]);
-            if (lane == 0) s_heads[p >> 6] = m;
+            bool hh = true;  // the end of the array closes the segment
+            if (t0 + UC_TILE < nd) hh = (ukey[t0 + UC_TILE] >> kl.sh_lib) != (ukey[t0 + UC_TILE - 1] >> kl.sh_lib);
+            s_halo_head = hh ? 1u : 0u;
         }
         __syncthreads();
         if (tid < UC_BLOCKS) {
-            // serial prefix / suffix over 32 blocks (one thread each direction would do; all 32 threads
-            // compute their own entry by walking, it is 32 steps at most)
             int cs = -1;
             for (int b = 0; b < (int)tid; b++) {
                 const unsigned long long m = s_heads[b];
                 if (m) cs = b * 64 + 63 - __clzll((long long)m);
             }
             s_carry_start[tid] = cs;
-            int ce = 0x7FFFFFFF;
-            if (s_pre[UC_TILE + 1] != s_pre[UC_TILE]) ce = UC_TILE;  // the halo starts a new segment
+            int ce = s_halo_head ? (int)UC_TILE : 0x7FFFFFFF;
             for (int b = UC_BLOCKS - 1; b > (int)tid; b--) {
                 const unsigned long long m = s_heads[b];
                 if (m) ce = b * 64 + (__ffsll((long long)m) - 1);
@@ -140,8 +195,9 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             s_carry_end[tid] = ce;
         }
         __syncthreads();
-        // ---- one key per lane per round ----
-#pragma unroll 1
+        // ---- segment bounds of every key; long in-tile segments enter the hash set ----
+        bool inserted = false;
+#pragma unroll
         for (int r = 0; r < UC_ITEMS; r++) {
             const uint32_t p = (uint32_t)r * 256u + tid;
             if (p >= tn) continue;
@@ -151,52 +207,31 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             const int start = le ? (int)(b * 64u + 63u - (uint32_t)__clzll((long long)le)) : s_carry_start[b];
             const unsigned long long gt = lane < 63u ? (heads >> (lane + 1u)) : 0ull;  // heads after p
             const int end = gt ? (int)(p + (uint32_t)__ffsll((long long)gt)) : s_carry_end[b];
+            const bool closed = start >= 0 && end <= (int)UC_TILE;
+            s_start[p] = closed ? (uint16_t)start : (uint16_t)UC_OPEN;
+            s_end[p] = closed ? (uint16_t)end : (uint16_t)UC_OPEN;
+            if (closed && end - start > UC_SMALL) {
+                uint32_t h = uc_hash((uint32_t)start, s_umi[p], UC_HASH - 1u);
+                while (atomicCAS(&s_hash[h], UC_EMPTY, p) != UC_EMPTY) h = (h + 1u) & (UC_HASH - 1u);
+                inserted = true;
+            }
+        }
+        if (inserted) s_any_long = 1;
+        __syncthreads();
+        // ---- one key per lane per round; segments that cross a tile edge belong to k_correct_umis_edges ----
+#pragma unroll 1
+        for (int r = 0; r < UC_ITEMS; r++) {
+            const uint32_t p = (uint32_t)r * 256u + tid;
+            if (p >= tn) continue;
+            const uint32_t s = s_start[p], e = s_end[p];
+            if (s == UC_OPEN) continue;
             const uint64_t k = t0 + p;
-            const uint32_t my_umi = s_umi[p], my_cnt = s_cnt[p];
-            const uint32_t lib = (uint32_t)(s_pre[p + 1] & lowmask(kl.bits_lib));
+            const uint32_t cw = s_cnt[p];
+            const uint32_t my_cnt = cw & ~UC_NOCORR;
             uint32_t target = NONE32;
-            if (!((kl.mux_mask >> lib) & 1u)) {  // UmiCorrection::Disable for Multiplexing Capture (aligner.rs:315-318)
-                if (start < 0 || end > (int)UC_TILE) {
-                    target = correct_one_global(kl, ukey, upos, nd, n_keys, k, my_cnt);
-                } else if (end - start > 1) {
-                    const uint32_t s = (uint32_t)start, e = (uint32_t)end;
-                    uint32_t best_cnt = my_cnt, best_umi = my_umi, best_p = p;
-                    if (e - s <= UC_SMALL) {
-                        for (uint32_t q = s; q < e; q++) {
-                            const uint32_t u = s_umi[q];
-                            if (!hd1(u, my_umi)) continue;
-                            const uint32_t c = s_cnt[q];
-                            if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                                best_cnt = c;
-                                best_umi = u;
-                                best_p = q;
-                            }
-                        }
-                    } else {
-                        for (uint32_t pos = 0; pos < kl.umi_len; pos++) {
-                            const uint32_t sh = 2u * (kl.umi_len - 1u - pos);
-                            const uint32_t orig = (my_umi >> sh) & 3u;
-                            for (uint32_t bb = 0; bb < 4; bb++) {
-                                if (bb == orig) continue;
-                                const uint32_t u = (my_umi & ~(3u << sh)) | (bb << sh);
-                                uint32_t lo = s, hi = e;
-                                while (lo < hi) {
-                                    const uint32_t mid = (lo + hi) >> 1;
-                                    if (s_umi[mid] < u) lo = mid + 1; else hi = mid;
-                                }
-                                if (lo < e && s_umi[lo] == u) {
-                                    const uint32_t c = s_cnt[lo];
-                                    if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                                        best_cnt = c;
-                                        best_umi = u;
-                                        best_p = lo;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (best_p != p) target = (uint32_t)(t0 + best_p);
-                }
+            if (!(cw & UC_NOCORR) && e - s > 1) {
+                const uint32_t bp = best_neighbour_lds<UC_HASH>(s_umi, s_cnt, s_hash, s_start, s, e, s, p, s_umi[p], my_cnt, kl.umi_len);
+                if (bp != p) target = (uint32_t)(t0 + bp);
             }
             corr[k] = target;
             if (target != NONE32) {
@@ -205,5 +240,90 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             }
         }
         __syncthreads();
+        if (s_any_long) {
+            for (uint32_t h = tid; h < UC_HASH; h += 256) s_hash[h] = UC_EMPTY;
+            __syncthreads();
+            if (tid == 0) s_any_long = 0;
+        }
+    }
+}
+
+// Segments that contain a tile boundary strictly inside.  Boundary t (position t*UC_TILE) owns the
+// segment when the previous boundary is not inside the same segment.
+__global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, const uint64_t *__restrict__ ukey,
+                                                                   const uint32_t *__restrict__ upos, uint64_t nd,
+                                                                   uint64_t n_keys, uint32_t *__restrict__ corr,
+                                                                   uint32_t *__restrict__ inc1,
+                                                                   uint32_t *__restrict__ inc_all) {
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_umi = smem;                  // UE_CAP
+    uint32_t *s_cnt = smem + UE_CAP;         // UE_CAP
+    uint32_t *s_hash = smem + 2 * UE_CAP;    // UE_HASH
+    __shared__ unsigned long long s_bounds[2];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t umi_mask = lowmask(kl.bits_umi);
+    const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
+    for (uint64_t t = (uint64_t)blockIdx.x + 1; t < n_tiles; t += gridDim.x) {
+        const uint64_t x = t * UC_TILE;
+        const uint64_t pre = ukey[x] >> kl.sh_lib;
+        if ((ukey[x - 1] >> kl.sh_lib) != pre) continue;  // the boundary is a segment head: nothing crosses it
+        if (tid == 0) {
+            uint64_t s, e;
+            segment_bounds(ukey, nd, x, kl.sh_lib, s, e);
+            s_bounds[0] = s;
+            s_bounds[1] = e;
+        }
+        __syncthreads();
+        const uint64_t s = s_bounds[0], e = s_bounds[1];
+        __syncthreads();
+        if (x - UC_TILE > s) continue;  // the previous boundary is inside the same segment and owns it
+        const uint64_t m = e - s;
+        const uint32_t lib = (uint32_t)(pre & lowmask(kl.bits_lib));
+        const bool nocorr = (kl.mux_mask >> lib) & 1u;  // UmiCorrection::Disable (aligner.rs:315-318)
+        if (nocorr) {
+            for (uint64_t k = s + tid; k < e; k += UE_THREADS) corr[k] = NONE32;
+            continue;
+        }
+        if (m <= UE_CAP) {
+            const uint32_t mm = (uint32_t)m;
+            const bool use_hash = mm > UC_SMALL;
+            if (use_hash)
+                for (uint32_t h = tid; h < UE_HASH; h += UE_THREADS) s_hash[h] = UC_EMPTY;
+            for (uint32_t p = tid; p < mm; p += UE_THREADS) {
+                const uint64_t k = s + p;
+                s_umi[p] = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
+                s_cnt[p] = run_count(upos, nd, n_keys, k);
+            }
+            __syncthreads();
+            if (use_hash) {
+                for (uint32_t p = tid; p < mm; p += UE_THREADS) {
+                    uint32_t h = uc_hash(0u, s_umi[p], UE_HASH - 1u);
+                    while (atomicCAS(&s_hash[h], UC_EMPTY, p) != UC_EMPTY) h = (h + 1u) & (UE_HASH - 1u);
+                }
+                __syncthreads();
+            }
+            for (uint32_t p = tid; p < mm; p += UE_THREADS) {
+                const uint32_t my_cnt = s_cnt[p];
+                const uint32_t bp = best_neighbour_lds<UE_HASH>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p, s_umi[p], my_cnt, kl.umi_len);
+                const uint32_t target = bp != p ? (uint32_t)(s + bp) : NONE32;
+                corr[s + p] = target;
+                if (target != NONE32) {
+                    atomicAdd(&inc1[target], 1u);
+                    atomicAdd(&inc_all[target], my_cnt);
+                }
+            }
+            __syncthreads();
+        } else {
+            // larger than the LDS budget: the reference's 3L probes as binary searches in global memory
+            for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
+                const uint32_t my_cnt = run_count(upos, nd, n_keys, k);
+                const uint32_t target = correct_one_global(kl, ukey, upos, nd, n_keys, k, my_cnt, s, e);
+                corr[k] = target;
+                if (target != NONE32) {
+                    atomicAdd(&inc1[target], 1u);
+                    atomicAdd(&inc_all[target], my_cnt);
+                }
+            }
+        }
     }
 }
