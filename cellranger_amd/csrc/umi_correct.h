@@ -29,12 +29,12 @@
 #define UC_SMALL 32
 #define UC_OPEN 0xFFFFu
 #define UC_HASH 4096u  // slots of the tile hash set; at most UC_TILE keys are inserted (load <= 0.5)
-#define UC_EMPTY 0xFFFFFFFFu
+#define UC_EMPTY 0xFFFFFFFFFFFFFFFFull  // hash slot = (segment tag << 48) | (umi << 16) | position
 #define UC_NOCORR 0x80000000u  // flag inside the staged count: UMI correction disabled for the key's library
 
 #define UE_THREADS 512
-#define UE_CAP 8192u     // keys of one edge segment held in LDS
-#define UE_HASH 16384u   // slots of its hash set
+#define UE_CAP 4096u     // keys of one edge segment held in LDS
+#define UE_HASH 8192u    // slots of its hash set
 
 __device__ __forceinline__ bool hd1(uint32_t a, uint32_t b) {
     const uint32_t x = a ^ b;
@@ -85,12 +85,36 @@ __device__ __forceinline__ uint32_t uc_hash(uint32_t seg_start, uint32_t umi, ui
     return h & mask;
 }
 
+// hash slot helpers: a probe step is ONE 8-byte LDS read (the slot carries tag and UMI itself; a slot
+// that only held a position needed two more dependent reads per step and made the probes 10x slower)
+__device__ __forceinline__ unsigned long long uc_slot(uint32_t tag, uint32_t umi, uint32_t pos) {
+    return ((unsigned long long)tag << 48) | ((unsigned long long)umi << 16) | (unsigned long long)pos;
+}
+template <uint32_t HASH_SLOTS>
+__device__ __forceinline__ void uc_insert(unsigned long long *s_hash, uint32_t tag, uint32_t umi, uint32_t pos) {
+    uint32_t h = uc_hash(tag, umi, HASH_SLOTS - 1u);
+    const unsigned long long v = uc_slot(tag, umi, pos);
+    while (atomicCAS(&s_hash[h], UC_EMPTY, v) != UC_EMPTY) h = (h + 1u) & (HASH_SLOTS - 1u);
+}
+// continue a probe sequence whose first slot `v` (at index h) has already been read
+template <uint32_t HASH_SLOTS>
+__device__ __forceinline__ uint32_t uc_resolve(const unsigned long long *s_hash, unsigned long long v, uint32_t h,
+                                               unsigned long long want48) {
+    for (;;) {
+        if (v == UC_EMPTY) return 0xFFFFFFFFu;
+        if ((v >> 16) == want48) return (uint32_t)(v & 0xFFFFull);
+        h = (h + 1u) & (HASH_SLOTS - 1u);
+        v = s_hash[h];
+    }
+}
+
 // best Hamming-1 neighbour of (my_umi, my_cnt) among the keys of segment [s, e) staged in LDS.
 // `seg_tag` distinguishes segments inside one hash set.  Returns the LDS position or `self`.
 template <uint32_t HASH_SLOTS>
-__device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, const uint32_t *s_cnt, const uint32_t *s_hash,
-                                                       const uint16_t *s_tag, uint32_t s, uint32_t e, uint32_t seg_tag,
-                                                       uint32_t self, uint32_t my_umi, uint32_t my_cnt, uint32_t umi_len) {
+__device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, const uint32_t *s_cnt,
+                                                       const unsigned long long *s_hash, uint32_t s, uint32_t e,
+                                                       uint32_t seg_tag, uint32_t self, uint32_t my_umi, uint32_t my_cnt,
+                                                       uint32_t umi_len) {
     uint32_t best_cnt = my_cnt, best_umi = my_umi, best_p = self;
     if (e - s <= UC_SMALL) {
         for (uint32_t q = s; q < e; q++) {
@@ -107,23 +131,28 @@ __device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, co
         for (uint32_t pos = 0; pos < umi_len; pos++) {
             const uint32_t sh = 2u * (umi_len - 1u - pos);
             const uint32_t orig = (my_umi >> sh) & 3u;
-            for (uint32_t bb = 0; bb < 4; bb++) {
-                if (bb == orig) continue;
-                const uint32_t u = (my_umi & ~(3u << sh)) | (bb << sh);
-                uint32_t h = uc_hash(seg_tag, u, HASH_SLOTS - 1u);
-                for (;;) {
-                    const uint32_t q = s_hash[h];
-                    if (q == UC_EMPTY) break;
-                    if (s_umi[q] == u && (s_tag == nullptr || s_tag[q] == (uint16_t)seg_tag)) {
-                        const uint32_t c = s_cnt[q] & ~UC_NOCORR;
-                        if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                            best_cnt = c;
-                            best_umi = u;
-                            best_p = q;
-                        }
-                        break;
+            // the three substitutions of this position: hashes and first slots are independent reads
+            uint32_t u[3], h[3];
+            unsigned long long v[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const uint32_t bb = (orig + 1u + (uint32_t)i) & 3u;
+                u[i] = (my_umi & ~(3u << sh)) | (bb << sh);
+                h[i] = uc_hash(seg_tag, u[i], HASH_SLOTS - 1u);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) v[i] = s_hash[h[i]];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const unsigned long long want48 = ((unsigned long long)seg_tag << 32) | (unsigned long long)u[i];
+                const uint32_t q = uc_resolve<HASH_SLOTS>(s_hash, v[i], h[i], want48);
+                if (q != 0xFFFFFFFFu) {
+                    const uint32_t c = s_cnt[q] & ~UC_NOCORR;
+                    if (c > best_cnt || (c == best_cnt && u[i] > best_umi)) {
+                        best_cnt = c;
+                        best_umi = u[i];
+                        best_p = q;
                     }
-                    h = (h + 1u) & (HASH_SLOTS - 1u);
                 }
             }
         }
@@ -134,12 +163,13 @@ __device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, co
 __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const uint64_t *__restrict__ ukey,
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
                                                             uint64_t n_keys, uint32_t *__restrict__ corr,
-                                                            uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all) {
+                                                            uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all,
+                                                            int ablate) {
     __shared__ uint32_t s_umi[UC_TILE];
     __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
     __shared__ uint16_t s_start[UC_TILE];  // segment start inside the tile, UC_OPEN = not fully inside the tile
     __shared__ uint16_t s_end[UC_TILE];    // exclusive end
-    __shared__ uint32_t s_hash[UC_HASH];   // open addressing: tile position of a long-segment key
+    __shared__ unsigned long long s_hash[UC_HASH];  // open addressing, see uc_slot
     __shared__ unsigned long long s_heads[UC_BLOCKS];  // bit l of entry b: position 64*b+l starts a segment
     __shared__ int s_carry_start[UC_BLOCKS];           // last segment start in blocks < b, or -1
     __shared__ int s_carry_end[UC_BLOCKS];             // first segment start in blocks > b, or INT_MAX
@@ -210,9 +240,8 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             const bool closed = start >= 0 && end <= (int)UC_TILE;
             s_start[p] = closed ? (uint16_t)start : (uint16_t)UC_OPEN;
             s_end[p] = closed ? (uint16_t)end : (uint16_t)UC_OPEN;
-            if (closed && end - start > UC_SMALL) {
-                uint32_t h = uc_hash((uint32_t)start, s_umi[p], UC_HASH - 1u);
-                while (atomicCAS(&s_hash[h], UC_EMPTY, p) != UC_EMPTY) h = (h + 1u) & (UC_HASH - 1u);
+            if (closed && end - start > UC_SMALL && !(ablate & 16)) {
+                uc_insert<UC_HASH>(s_hash, (uint32_t)start, s_umi[p], p);
                 inserted = true;
             }
         }
@@ -229,12 +258,13 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             const uint32_t cw = s_cnt[p];
             const uint32_t my_cnt = cw & ~UC_NOCORR;
             uint32_t target = NONE32;
-            if (!(cw & UC_NOCORR) && e - s > 1) {
-                const uint32_t bp = best_neighbour_lds<UC_HASH>(s_umi, s_cnt, s_hash, s_start, s, e, s, p, s_umi[p], my_cnt, kl.umi_len);
+            if (!(cw & UC_NOCORR) && e - s > 1 && !(ablate & 1) && !((ablate & 4) && e - s > UC_SMALL) &&
+                !((ablate & 8) && e - s <= UC_SMALL)) {
+                const uint32_t bp = best_neighbour_lds<UC_HASH>(s_umi, s_cnt, s_hash, s, e, s, p, s_umi[p], my_cnt, kl.umi_len);
                 if (bp != p) target = (uint32_t)(t0 + bp);
             }
             corr[k] = target;
-            if (target != NONE32) {
+            if (target != NONE32 && !(ablate & 2)) {
                 atomicAdd(&inc1[target], 1u);          // phase 1 moves one read (mark_dups.rs:228-232)
                 atomicAdd(&inc_all[target], my_cnt);   // phases 1+2 move them all (:242-246)
             }
@@ -258,7 +288,7 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
     extern __shared__ uint32_t smem[];
     uint32_t *s_umi = smem;                  // UE_CAP
     uint32_t *s_cnt = smem + UE_CAP;         // UE_CAP
-    uint32_t *s_hash = smem + 2 * UE_CAP;    // UE_HASH
+    unsigned long long *s_hash = reinterpret_cast<unsigned long long *>(smem + 2 * UE_CAP);  // UE_HASH slots
     __shared__ unsigned long long s_bounds[2];
     const uint32_t tid = threadIdx.x;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
@@ -296,15 +326,12 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
             }
             __syncthreads();
             if (use_hash) {
-                for (uint32_t p = tid; p < mm; p += UE_THREADS) {
-                    uint32_t h = uc_hash(0u, s_umi[p], UE_HASH - 1u);
-                    while (atomicCAS(&s_hash[h], UC_EMPTY, p) != UC_EMPTY) h = (h + 1u) & (UE_HASH - 1u);
-                }
+                for (uint32_t p = tid; p < mm; p += UE_THREADS) uc_insert<UE_HASH>(s_hash, 0u, s_umi[p], p);
                 __syncthreads();
             }
             for (uint32_t p = tid; p < mm; p += UE_THREADS) {
                 const uint32_t my_cnt = s_cnt[p];
-                const uint32_t bp = best_neighbour_lds<UE_HASH>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p, s_umi[p], my_cnt, kl.umi_len);
+                const uint32_t bp = best_neighbour_lds<UE_HASH>(s_umi, s_cnt, s_hash, 0u, mm, 0u, p, s_umi[p], my_cnt, kl.umi_len);
                 const uint32_t target = bp != p ? (uint32_t)(s + bp) : NONE32;
                 corr[s + p] = target;
                 if (target != NONE32) {
