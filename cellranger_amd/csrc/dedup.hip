@@ -534,7 +534,7 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
         hipLaunchKernelGGL(k_correct_umis_tiled, dim3(cr_grid(n_tiles, 1, 256u * 4u)), dim3(256), 0, ctx->stream, kl, ukey,
                            upos, nd, n_keys, corr, inc1, inc_all, ablate);
         if (n_tiles > 1) {
-            const size_t edge_lds = 2 * UE_CAP * sizeof(uint32_t) + UE_HASH * sizeof(unsigned long long);
+            const size_t edge_lds = (2 * UE_CAP + UE_BUCKETS * 8) * sizeof(uint32_t);
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute((const void *)k_correct_umis_edges, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -28,13 +28,15 @@
 #define UC_BLOCKS (UC_TILE / 64)
 #define UC_SMALL 32
 #define UC_OPEN 0xFFFFu
-#define UC_HASH 4096u  // slots of the tile hash set; at most UC_TILE keys are inserted (load <= 0.5)
-#define UC_EMPTY 0xFFFFFFFFFFFFFFFFull  // hash slot = (segment tag << 48) | (umi << 16) | position
+#define UC_BUCKETS 1024u  // tile hash set: 8-slot buckets (32 B); at most UC_TILE keys => load <= 0.25
+#define UC_POSBITS 11u    // slot = (fingerprint << POSBITS) | position
+#define UC_EMPTY 0xFFFFFFFFu
 #define UC_NOCORR 0x80000000u  // flag inside the staged count: UMI correction disabled for the key's library
 
 #define UE_THREADS 512
-#define UE_CAP 4096u     // keys of one edge segment held in LDS
-#define UE_HASH 8192u    // slots of its hash set
+#define UE_CAP 4096u      // keys of one edge segment held in LDS
+#define UE_BUCKETS 2048u  // its hash set: load <= 0.25
+#define UE_POSBITS 12u
 
 __device__ __forceinline__ bool hd1(uint32_t a, uint32_t b) {
     const uint32_t x = a ^ b;
@@ -85,36 +87,73 @@ __device__ __forceinline__ uint32_t uc_hash(uint32_t seg_start, uint32_t umi, ui
     return h & mask;
 }
 
-// hash slot helpers: a probe step is ONE 8-byte LDS read (the slot carries tag and UMI itself; a slot
-// that only held a position needed two more dependent reads per step and made the probes 10x slower)
-__device__ __forceinline__ unsigned long long uc_slot(uint32_t tag, uint32_t umi, uint32_t pos) {
-    return ((unsigned long long)tag << 48) | ((unsigned long long)umi << 16) | (unsigned long long)pos;
+// ---- bucketised LDS hash set ------------------------------------------------------------------------
+// A probe chain is the enemy here: all 64 lanes of a wave wait for the lane with the longest chain, at
+// each of the 3L probes.  Buckets of 8 four-byte slots (32 B, two ds_read_b128) at load <= 0.25 answer a
+// probe with ONE wide read: slots of a bucket fill front to back, so a bucket with a free slot proves
+// absence and only a full bucket without a match (P ~ 1e-3) continues to the next bucket.
+// slot = (fingerprint << POSBITS) | position; a fingerprint hit is verified against the staged UMI / tag.
+template <uint32_t BUCKETS>
+__device__ __forceinline__ uint32_t uc_bucket(uint32_t tag, uint32_t umi, uint32_t &fp_out, uint32_t posbits) {
+    uint32_t h = umi * 0x9E3779B1u ^ (tag * 0x85EBCA6Bu);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    uint32_t f = (umi ^ (tag << 7)) * 0xC2B2AE35u;
+    f ^= f >> 16;
+    f &= (1u << (32u - posbits)) - 1u;
+    if (f == (1u << (32u - posbits)) - 1u) f = 0;  // all ones is reserved for EMPTY
+    fp_out = f;
+    return h & (BUCKETS - 1u);
 }
-template <uint32_t HASH_SLOTS>
-__device__ __forceinline__ void uc_insert(unsigned long long *s_hash, uint32_t tag, uint32_t umi, uint32_t pos) {
-    uint32_t h = uc_hash(tag, umi, HASH_SLOTS - 1u);
-    const unsigned long long v = uc_slot(tag, umi, pos);
-    while (atomicCAS(&s_hash[h], UC_EMPTY, v) != UC_EMPTY) h = (h + 1u) & (HASH_SLOTS - 1u);
-}
-// continue a probe sequence whose first slot `v` (at index h) has already been read
-template <uint32_t HASH_SLOTS>
-__device__ __forceinline__ uint32_t uc_resolve(const unsigned long long *s_hash, unsigned long long v, uint32_t h,
-                                               unsigned long long want48) {
+template <uint32_t BUCKETS, uint32_t POSBITS>
+__device__ __forceinline__ void uc_insert(uint32_t *s_hash, uint32_t tag, uint32_t umi, uint32_t pos) {
+    uint32_t fp;
+    uint32_t b = uc_bucket<BUCKETS>(tag, umi, fp, POSBITS);
+    const uint32_t v = (fp << POSBITS) | pos;
     for (;;) {
-        if (v == UC_EMPTY) return 0xFFFFFFFFu;
-        if ((v >> 16) == want48) return (uint32_t)(v & 0xFFFFull);
-        h = (h + 1u) & (HASH_SLOTS - 1u);
-        v = s_hash[h];
+        for (uint32_t j = 0; j < 8; j++)
+            if (atomicCAS(&s_hash[b * 8u + j], UC_EMPTY, v) == UC_EMPTY) return;
+        b = (b + 1u) & (BUCKETS - 1u);
+    }
+}
+struct UcBucket {
+    uint4 lo, hi;
+};
+__device__ __forceinline__ UcBucket uc_load(const uint32_t *s_hash, uint32_t b) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(s_hash + b * 8u);
+    UcBucket r;
+    r.lo = p[0];
+    r.hi = p[1];
+    return r;
+}
+// position of (tag, umi) or 0xFFFFFFFF; `bk` is the already loaded bucket b
+template <uint32_t BUCKETS, uint32_t POSBITS>
+__device__ __forceinline__ uint32_t uc_resolve(const uint32_t *s_hash, const uint32_t *s_umi, const uint16_t *s_tag,
+                                               UcBucket bk, uint32_t b, uint32_t fp, uint32_t tag, uint32_t umi) {
+    for (;;) {
+        const uint32_t w[8] = {bk.lo.x, bk.lo.y, bk.lo.z, bk.lo.w, bk.hi.x, bk.hi.y, bk.hi.z, bk.hi.w};
+        bool has_free = false;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            has_free |= w[j] == UC_EMPTY;
+            if ((w[j] >> POSBITS) == fp && w[j] != UC_EMPTY) {
+                const uint32_t q = w[j] & ((1u << POSBITS) - 1u);
+                if (s_umi[q] == umi && (s_tag == nullptr || s_tag[q] == (uint16_t)tag)) return q;
+            }
+        }
+        if (has_free) return 0xFFFFFFFFu;
+        b = (b + 1u) & (BUCKETS - 1u);
+        bk = uc_load(s_hash, b);
     }
 }
 
 // best Hamming-1 neighbour of (my_umi, my_cnt) among the keys of segment [s, e) staged in LDS.
 // `seg_tag` distinguishes segments inside one hash set.  Returns the LDS position or `self`.
-template <uint32_t HASH_SLOTS>
-__device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, const uint32_t *s_cnt,
-                                                       const unsigned long long *s_hash, uint32_t s, uint32_t e,
-                                                       uint32_t seg_tag, uint32_t self, uint32_t my_umi, uint32_t my_cnt,
-                                                       uint32_t umi_len) {
+template <uint32_t BUCKETS, uint32_t POSBITS>
+__device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, const uint32_t *s_cnt, const uint32_t *s_hash,
+                                                       const uint16_t *s_tag, uint32_t s, uint32_t e, uint32_t seg_tag,
+                                                       uint32_t self, uint32_t my_umi, uint32_t my_cnt, uint32_t umi_len) {
     uint32_t best_cnt = my_cnt, best_umi = my_umi, best_p = self;
     if (e - s <= UC_SMALL) {
         for (uint32_t q = s; q < e; q++) {
@@ -131,21 +170,20 @@ __device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, co
         for (uint32_t pos = 0; pos < umi_len; pos++) {
             const uint32_t sh = 2u * (umi_len - 1u - pos);
             const uint32_t orig = (my_umi >> sh) & 3u;
-            // the three substitutions of this position: hashes and first slots are independent reads
-            uint32_t u[3], h[3];
-            unsigned long long v[3];
+            // the three substitutions of this position: their bucket reads are independent
+            uint32_t u[3], b[3], fp[3];
+            UcBucket bk[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const uint32_t bb = (orig + 1u + (uint32_t)i) & 3u;
                 u[i] = (my_umi & ~(3u << sh)) | (bb << sh);
-                h[i] = uc_hash(seg_tag, u[i], HASH_SLOTS - 1u);
+                b[i] = uc_bucket<BUCKETS>(seg_tag, u[i], fp[i], POSBITS);
             }
 #pragma unroll
-            for (int i = 0; i < 3; i++) v[i] = s_hash[h[i]];
+            for (int i = 0; i < 3; i++) bk[i] = uc_load(s_hash, b[i]);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                const unsigned long long want48 = ((unsigned long long)seg_tag << 32) | (unsigned long long)u[i];
-                const uint32_t q = uc_resolve<HASH_SLOTS>(s_hash, v[i], h[i], want48);
+                const uint32_t q = uc_resolve<BUCKETS, POSBITS>(s_hash, s_umi, s_tag, bk[i], b[i], fp[i], seg_tag, u[i]);
                 if (q != 0xFFFFFFFFu) {
                     const uint32_t c = s_cnt[q] & ~UC_NOCORR;
                     if (c > best_cnt || (c == best_cnt && u[i] > best_umi)) {
@@ -169,7 +207,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
     __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
     __shared__ uint16_t s_start[UC_TILE];  // segment start inside the tile, UC_OPEN = not fully inside the tile
     __shared__ uint16_t s_end[UC_TILE];    // exclusive end
-    __shared__ unsigned long long s_hash[UC_HASH];  // open addressing, see uc_slot
+    __shared__ __attribute__((aligned(16))) uint32_t s_hash[UC_BUCKETS * 8];  // bucketised hash set
     __shared__ unsigned long long s_heads[UC_BLOCKS];  // bit l of entry b: position 64*b+l starts a segment
     __shared__ int s_carry_start[UC_BLOCKS];           // last segment start in blocks < b, or -1
     __shared__ int s_carry_end[UC_BLOCKS];             // first segment start in blocks > b, or INT_MAX
@@ -178,7 +216,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
     const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
-    for (uint32_t h = tid; h < UC_HASH; h += 256) s_hash[h] = UC_EMPTY;
+    for (uint32_t h = tid; h < UC_BUCKETS * 8; h += 256) s_hash[h] = UC_EMPTY;
     if (tid == 0) s_any_long = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t t0 = tile * UC_TILE;
@@ -241,7 +279,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             s_start[p] = closed ? (uint16_t)start : (uint16_t)UC_OPEN;
             s_end[p] = closed ? (uint16_t)end : (uint16_t)UC_OPEN;
             if (closed && end - start > UC_SMALL && !(ablate & 16)) {
-                uc_insert<UC_HASH>(s_hash, (uint32_t)start, s_umi[p], p);
+                uc_insert<UC_BUCKETS, UC_POSBITS>(s_hash, (uint32_t)start, s_umi[p], p);
                 inserted = true;
             }
         }
@@ -260,7 +298,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             uint32_t target = NONE32;
             if (!(cw & UC_NOCORR) && e - s > 1 && !(ablate & 1) && !((ablate & 4) && e - s > UC_SMALL) &&
                 !((ablate & 8) && e - s <= UC_SMALL)) {
-                const uint32_t bp = best_neighbour_lds<UC_HASH>(s_umi, s_cnt, s_hash, s, e, s, p, s_umi[p], my_cnt, kl.umi_len);
+                const uint32_t bp = best_neighbour_lds<UC_BUCKETS, UC_POSBITS>(s_umi, s_cnt, s_hash, s_start, s, e, s, p, s_umi[p], my_cnt, kl.umi_len);
                 if (bp != p) target = (uint32_t)(t0 + bp);
             }
             corr[k] = target;
@@ -271,7 +309,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
         }
         __syncthreads();
         if (s_any_long) {
-            for (uint32_t h = tid; h < UC_HASH; h += 256) s_hash[h] = UC_EMPTY;
+            for (uint32_t h = tid; h < UC_BUCKETS * 8; h += 256) s_hash[h] = UC_EMPTY;
             __syncthreads();
             if (tid == 0) s_any_long = 0;
         }
@@ -285,10 +323,10 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
                                                                    uint64_t n_keys, uint32_t *__restrict__ corr,
                                                                    uint32_t *__restrict__ inc1,
                                                                    uint32_t *__restrict__ inc_all) {
-    extern __shared__ uint32_t smem[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *s_umi = smem;                  // UE_CAP
     uint32_t *s_cnt = smem + UE_CAP;         // UE_CAP
-    unsigned long long *s_hash = reinterpret_cast<unsigned long long *>(smem + 2 * UE_CAP);  // UE_HASH slots
+    uint32_t *s_hash = smem + 2 * UE_CAP;    // UE_BUCKETS * 8 slots (16-byte aligned: UE_CAP is a multiple of 4)
     __shared__ unsigned long long s_bounds[2];
     const uint32_t tid = threadIdx.x;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
@@ -318,7 +356,7 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
             const uint32_t mm = (uint32_t)m;
             const bool use_hash = mm > UC_SMALL;
             if (use_hash)
-                for (uint32_t h = tid; h < UE_HASH; h += UE_THREADS) s_hash[h] = UC_EMPTY;
+                for (uint32_t h = tid; h < UE_BUCKETS * 8; h += UE_THREADS) s_hash[h] = UC_EMPTY;
             for (uint32_t p = tid; p < mm; p += UE_THREADS) {
                 const uint64_t k = s + p;
                 s_umi[p] = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
@@ -326,12 +364,12 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
             }
             __syncthreads();
             if (use_hash) {
-                for (uint32_t p = tid; p < mm; p += UE_THREADS) uc_insert<UE_HASH>(s_hash, 0u, s_umi[p], p);
+                for (uint32_t p = tid; p < mm; p += UE_THREADS) uc_insert<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, s_umi[p], p);
                 __syncthreads();
             }
             for (uint32_t p = tid; p < mm; p += UE_THREADS) {
                 const uint32_t my_cnt = s_cnt[p];
-                const uint32_t bp = best_neighbour_lds<UE_HASH>(s_umi, s_cnt, s_hash, 0u, mm, 0u, p, s_umi[p], my_cnt, kl.umi_len);
+                const uint32_t bp = best_neighbour_lds<UE_BUCKETS, UE_POSBITS>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p, s_umi[p], my_cnt, kl.umi_len);
                 const uint32_t target = bp != p ? (uint32_t)(s + bp) : NONE32;
                 corr[s + p] = target;
                 if (target != NONE32) {
