@@ -26,7 +26,7 @@
 #define UC_ITEMS 8
 #define UC_TILE (256 * UC_ITEMS)
 #define UC_BLOCKS (UC_TILE / 64)
-#define UC_SMALL 32
+#define UC_SMALL 192  // all pairs cost ~8 ops per member, a hashed 3L-probe search ~1500: break-even near 200
 #define UC_OPEN 0xFFFFu
 #define UC_BUCKETS 1024u  // tile hash set: 8-slot buckets (32 B); at most UC_TILE keys => load <= 0.25
 #define UC_POSBITS 11u    // slot = (fingerprint << POSBITS) | position
@@ -95,16 +95,12 @@ __device__ __forceinline__ uint32_t uc_hash(uint32_t seg_start, uint32_t umi, ui
 // slot = (fingerprint << POSBITS) | position; a fingerprint hit is verified against the staged UMI / tag.
 template <uint32_t BUCKETS>
 __device__ __forceinline__ uint32_t uc_bucket(uint32_t tag, uint32_t umi, uint32_t &fp_out, uint32_t posbits) {
-    uint32_t h = umi * 0x9E3779B1u ^ (tag * 0x85EBCA6Bu);
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
-    h ^= h >> 13;
-    uint32_t f = (umi ^ (tag << 7)) * 0xC2B2AE35u;
-    f ^= f >> 16;
-    f &= (1u << (32u - posbits)) - 1u;
+    // one multiply: the top bits pick the bucket, the low bits are the fingerprint
+    const uint32_t x = (umi ^ (tag * 0x85EBCA6Bu)) * 0x9E3779B1u;
+    uint32_t f = (x ^ (x >> 15)) & ((1u << (32u - posbits)) - 1u);
     if (f == (1u << (32u - posbits)) - 1u) f = 0;  // all ones is reserved for EMPTY
     fp_out = f;
-    return h & (BUCKETS - 1u);
+    return (x >> 20) & (BUCKETS - 1u);
 }
 template <uint32_t BUCKETS, uint32_t POSBITS>
 __device__ __forceinline__ void uc_insert(uint32_t *s_hash, uint32_t tag, uint32_t umi, uint32_t pos) {
