@@ -530,9 +530,8 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
         CR_HIP(ctx, hipMemsetAsync(low, 0, nd, ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(minraw_b.p, 0xFF, nd * sizeof(unsigned long long), ctx->stream));
         const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
-        const int ablate = getenv("CRGPU_ABLATE") ? atoi(getenv("CRGPU_ABLATE")) : 0;  // timing experiments only
         hipLaunchKernelGGL(k_correct_umis_tiled, dim3(cr_grid(n_tiles, 1, 256u * 4u)), dim3(256), 0, ctx->stream, kl, ukey,
-                           upos, nd, n_keys, corr, inc1, inc_all, ablate);
+                           upos, nd, n_keys, corr, inc1, inc_all);
         if (n_tiles > 1) {
             const size_t edge_lds = (2 * UE_CAP + UE_BUCKETS * 8) * sizeof(uint32_t);
             static bool attr_set = false;

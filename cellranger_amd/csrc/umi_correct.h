@@ -7,35 +7,37 @@
 // `count > best || (count == best && umi > best_umi)`, which is an order-independent arg-max -- and
 // move to it when it beats (c, own UMI).  One step only, never transitive.
 //
-// The distinct keys are sorted, so a segment is a contiguous range.  Two kernels cover every key once:
+// Pigeonhole: split the UMI into a high half (first L - L/2 bases) and a low half (last L/2 bases).
+// A Hamming-1 neighbour either
+//   (1) shares my high half -> the distinct keys are sorted by UMI, so it sits in my own contiguous run of
+//       equal high halves: scan outwards from my position (the run has ~m/4^(L-L/2) members), or
+//   (2) shares my low half  -> ONE lookup in a hash set keyed by (segment, low half) lists every member
+//       with that low half; check their high halves.
+// That is two short scans per key instead of the reference's 3L = 36 hash probes; the 36 probes (as LDS
+// hash probes, and before that as binary searches) were the dominant cost of the count stage.
 //
 //  k_correct_umis_tiled  A workgroup stages a tile of UC_TILE consecutive keys in LDS (lane-interleaved)
-//      and derives every key's segment bounds from per-64-key ballots of the segment-head flags.
-//      Segments that lie completely inside the tile are finished here: short ones (<= UC_SMALL keys) by
-//      all pairs, long ones by the reference's 3L probes against an LDS hash set of the tile's
-//      long-segment keys.  Keys of segments that cross a tile edge are left alone.
-//  k_correct_umis_edges  One workgroup per tile boundary that falls strictly inside a segment (the
-//      first such boundary owns the segment): the whole segment is loaded into LDS with a hash set and
-//      finished the same way; segments larger than the LDS budget fall back to binary searches in
-//      global memory.
-//
-// 3L probes into a hash set cost ~1.3 LDS reads each; the same probes as binary searches cost
-// log2(m) dependent reads each and were the dominant cost of the whole count stage.
+//      and derives every key's segment bounds from per-64-key ballots of the segment-head flags.  Segments
+//      completely inside the tile are finished here: <= UC_SMALL members by all pairs, longer ones by the
+//      pigeonhole search.  Keys of segments that cross a tile edge are left to
+//  k_correct_umis_edges  one workgroup per tile boundary that falls strictly inside a segment (the first
+//      such boundary owns the segment).  Segments up to UE_CAP keys are staged in LDS whole; larger ones
+//      are processed in chunks of UE_CAP table entries against which every key of the segment is probed.
 #pragma once
 
 #define UC_ITEMS 8
 #define UC_TILE (256 * UC_ITEMS)
 #define UC_BLOCKS (UC_TILE / 64)
-#define UC_SMALL 192  // all pairs cost ~8 ops per member, a hashed 3L-probe search ~1500: break-even near 200
+#define UC_SMALL 32
 #define UC_OPEN 0xFFFFu
-#define UC_BUCKETS 1024u  // tile hash set: 8-slot buckets (32 B); at most UC_TILE keys => load <= 0.25
+#define UC_BUCKETS 1024u  // tile hash set: 8-slot buckets (32 B); at most UC_TILE entries => load <= 0.25
 #define UC_POSBITS 11u    // slot = (fingerprint << POSBITS) | position
 #define UC_EMPTY 0xFFFFFFFFu
 #define UC_NOCORR 0x80000000u  // flag inside the staged count: UMI correction disabled for the key's library
 
 #define UE_THREADS 512
-#define UE_CAP 4096u      // keys of one edge segment held in LDS
-#define UE_BUCKETS 2048u  // its hash set: load <= 0.25
+#define UE_CAP 4096u      // table entries of one edge-segment chunk held in LDS
+#define UE_BUCKETS 2048u  // load <= 0.25
 #define UE_POSBITS 12u
 
 __device__ __forceinline__ bool hd1(uint32_t a, uint32_t b) {
@@ -44,68 +46,32 @@ __device__ __forceinline__ bool hd1(uint32_t a, uint32_t b) {
     return y != 0u && (y & (y - 1u)) == 0u;
 }
 
-// global-memory path for one key of the segment [s, e)
-__device__ uint32_t correct_one_global(const KL &kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ upos,
-                                       uint64_t nd, uint64_t n_keys, uint64_t k, uint32_t my_cnt, uint64_t s, uint64_t e) {
-    const uint64_t umi_mask = lowmask(kl.bits_umi);
-    const uint64_t key = ukey[k];
-    if (e - s <= 1) return NONE32;
-    const uint32_t my_umi = (uint32_t)((key >> kl.sh_umi) & umi_mask);
-    uint32_t best_cnt = my_cnt, best_umi = my_umi;
-    uint64_t best_idx = k;
-    const uint64_t pre = (key >> kl.sh_lib) << kl.bits_umi;
-    for (uint32_t pos = 0; pos < kl.umi_len; pos++) {
-        const uint32_t sh = 2u * (kl.umi_len - 1u - pos);
-        const uint32_t orig = (my_umi >> sh) & 3u;
-        for (uint32_t b = 0; b < 4; b++) {
-            if (b == orig) continue;
-            const uint32_t u = (my_umi & ~(3u << sh)) | (b << sh);
-            const uint64_t want = pre | u;  // == ukey >> sh_umi of the probed key
-            uint64_t lo = s, hi = e;
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if ((ukey[mid] >> kl.sh_umi) < want) lo = mid + 1; else hi = mid;
-            }
-            if (lo < e && (ukey[lo] >> kl.sh_umi) == want) {
-                const uint32_t c = run_count(upos, nd, n_keys, lo);
-                if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                    best_cnt = c;
-                    best_umi = u;
-                    best_idx = lo;
-                }
-            }
-        }
-    }
-    return best_idx != k ? (uint32_t)best_idx : NONE32;
+struct UmiSplit {
+    uint32_t lo_bits, lo_mask;
+};
+__device__ __forceinline__ UmiSplit umi_split(uint32_t umi_len) {
+    UmiSplit s;
+    s.lo_bits = 2u * (umi_len / 2u);
+    s.lo_mask = s.lo_bits >= 32u ? 0xFFFFFFFFu : ((1u << s.lo_bits) - 1u);
+    return s;
 }
 
-__device__ __forceinline__ uint32_t uc_hash(uint32_t seg_start, uint32_t umi, uint32_t mask) {
-    uint32_t h = umi * 0x9E3779B1u ^ (seg_start * 0x85EBCA6Bu);
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
-    h ^= h >> 13;
-    return h & mask;
-}
-
-// ---- bucketised LDS hash set ------------------------------------------------------------------------
-// A probe chain is the enemy here: all 64 lanes of a wave wait for the lane with the longest chain, at
-// each of the 3L probes.  Buckets of 8 four-byte slots (32 B, two ds_read_b128) at load <= 0.25 answer a
-// probe with ONE wide read: slots of a bucket fill front to back, so a bucket with a free slot proves
-// absence and only a full bucket without a match (P ~ 1e-3) continues to the next bucket.
-// slot = (fingerprint << POSBITS) | position; a fingerprint hit is verified against the staged UMI / tag.
+// ---- bucketised LDS hash set keyed by (segment tag, low half) --------------------------------------------
+// Buckets of 8 four-byte slots (32 B, two ds_read_b128), slot = (fingerprint << POSBITS) | position.  Slots
+// of a bucket fill front to back, so a bucket with a free slot ends the search; only a full bucket
+// continues to the next one.  Several members may share one (tag, low half): a lookup visits all of them.
 template <uint32_t BUCKETS>
-__device__ __forceinline__ uint32_t uc_bucket(uint32_t tag, uint32_t umi, uint32_t &fp_out, uint32_t posbits) {
-    // one multiply: the top bits pick the bucket, the low bits are the fingerprint
-    const uint32_t x = (umi ^ (tag * 0x85EBCA6Bu)) * 0x9E3779B1u;
+__device__ __forceinline__ uint32_t uc_bucket(uint32_t tag, uint32_t lo, uint32_t &fp_out, uint32_t posbits) {
+    const uint32_t x = (lo ^ (tag * 0x85EBCA6Bu)) * 0x9E3779B1u;
     uint32_t f = (x ^ (x >> 15)) & ((1u << (32u - posbits)) - 1u);
     if (f == (1u << (32u - posbits)) - 1u) f = 0;  // all ones is reserved for EMPTY
     fp_out = f;
     return (x >> 20) & (BUCKETS - 1u);
 }
 template <uint32_t BUCKETS, uint32_t POSBITS>
-__device__ __forceinline__ void uc_insert(uint32_t *s_hash, uint32_t tag, uint32_t umi, uint32_t pos) {
+__device__ __forceinline__ void uc_insert(uint32_t *s_hash, uint32_t tag, uint32_t lo, uint32_t pos) {
     uint32_t fp;
-    uint32_t b = uc_bucket<BUCKETS>(tag, umi, fp, POSBITS);
+    uint32_t b = uc_bucket<BUCKETS>(tag, lo, fp, POSBITS);
     const uint32_t v = (fp << POSBITS) | pos;
     for (;;) {
         for (uint32_t j = 0; j < 8; j++)
@@ -113,97 +79,83 @@ __device__ __forceinline__ void uc_insert(uint32_t *s_hash, uint32_t tag, uint32
         b = (b + 1u) & (BUCKETS - 1u);
     }
 }
-struct UcBucket {
-    uint4 lo, hi;
-};
-__device__ __forceinline__ UcBucket uc_load(const uint32_t *s_hash, uint32_t b) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(s_hash + b * 8u);
-    UcBucket r;
-    r.lo = p[0];
-    r.hi = p[1];
-    return r;
-}
-// position of (tag, umi) or 0xFFFFFFFF; `bk` is the already loaded bucket b
-template <uint32_t BUCKETS, uint32_t POSBITS>
-__device__ __forceinline__ uint32_t uc_resolve(const uint32_t *s_hash, const uint32_t *s_umi, const uint16_t *s_tag,
-                                               UcBucket bk, uint32_t b, uint32_t fp, uint32_t tag, uint32_t umi) {
+// f(position) for every table entry whose fingerprint matches (tag, lo); the caller verifies exactly
+template <uint32_t BUCKETS, uint32_t POSBITS, typename F>
+__device__ __forceinline__ void uc_for_each(const uint32_t *s_hash, uint32_t tag, uint32_t lo, F f) {
+    uint32_t fp;
+    uint32_t b = uc_bucket<BUCKETS>(tag, lo, fp, POSBITS);
     for (;;) {
-        const uint32_t w[8] = {bk.lo.x, bk.lo.y, bk.lo.z, bk.lo.w, bk.hi.x, bk.hi.y, bk.hi.z, bk.hi.w};
+        const uint4 *p = reinterpret_cast<const uint4 *>(s_hash + b * 8u);
+        const uint4 x = p[0], y = p[1];
+        const uint32_t w[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
         bool has_free = false;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             has_free |= w[j] == UC_EMPTY;
-            if ((w[j] >> POSBITS) == fp && w[j] != UC_EMPTY) {
-                const uint32_t q = w[j] & ((1u << POSBITS) - 1u);
-                if (s_umi[q] == umi && (s_tag == nullptr || s_tag[q] == (uint16_t)tag)) return q;
-            }
+            if (w[j] != UC_EMPTY && (w[j] >> POSBITS) == fp) f(w[j] & ((1u << POSBITS) - 1u));
         }
-        if (has_free) return 0xFFFFFFFFu;
+        if (has_free) return;
         b = (b + 1u) & (BUCKETS - 1u);
-        bk = uc_load(s_hash, b);
     }
 }
 
-// best Hamming-1 neighbour of (my_umi, my_cnt) among the keys of segment [s, e) staged in LDS.
-// `seg_tag` distinguishes segments inside one hash set.  Returns the LDS position or `self`.
+struct Best {
+    uint32_t cnt, umi, pos;
+    __device__ __forceinline__ void offer(uint32_t c, uint32_t u, uint32_t p) {
+        if (c > cnt || (c == cnt && u > umi)) {
+            cnt = c;
+            umi = u;
+            pos = p;
+        }
+    }
+};
+
+// best Hamming-1 neighbour of the key at LDS position `self` among the members of segment [s, e) staged in
+// LDS (s_umi sorted ascending inside the segment).  Returns the LDS position or `self`.
 template <uint32_t BUCKETS, uint32_t POSBITS>
 __device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, const uint32_t *s_cnt, const uint32_t *s_hash,
                                                        const uint16_t *s_tag, uint32_t s, uint32_t e, uint32_t seg_tag,
-                                                       uint32_t self, uint32_t my_umi, uint32_t my_cnt, uint32_t umi_len) {
-    uint32_t best_cnt = my_cnt, best_umi = my_umi, best_p = self;
+                                                       uint32_t self, uint32_t my_umi, uint32_t my_cnt, UmiSplit sp) {
+    Best best{my_cnt, my_umi, self};
     if (e - s <= UC_SMALL) {
         for (uint32_t q = s; q < e; q++) {
             const uint32_t u = s_umi[q];
-            if (!hd1(u, my_umi)) continue;
-            const uint32_t c = s_cnt[q] & ~UC_NOCORR;
-            if (c > best_cnt || (c == best_cnt && u > best_umi)) {
-                best_cnt = c;
-                best_umi = u;
-                best_p = q;
-            }
+            if (hd1(u, my_umi)) best.offer(s_cnt[q] & ~UC_NOCORR, u, q);
         }
-    } else {
-        for (uint32_t pos = 0; pos < umi_len; pos++) {
-            const uint32_t sh = 2u * (umi_len - 1u - pos);
-            const uint32_t orig = (my_umi >> sh) & 3u;
-            // the three substitutions of this position: their bucket reads are independent
-            uint32_t u[3], b[3], fp[3];
-            UcBucket bk[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const uint32_t bb = (orig + 1u + (uint32_t)i) & 3u;
-                u[i] = (my_umi & ~(3u << sh)) | (bb << sh);
-                b[i] = uc_bucket<BUCKETS>(seg_tag, u[i], fp[i], POSBITS);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; i++) bk[i] = uc_load(s_hash, b[i]);
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const uint32_t q = uc_resolve<BUCKETS, POSBITS>(s_hash, s_umi, s_tag, bk[i], b[i], fp[i], seg_tag, u[i]);
-                if (q != 0xFFFFFFFFu) {
-                    const uint32_t c = s_cnt[q] & ~UC_NOCORR;
-                    if (c > best_cnt || (c == best_cnt && u[i] > best_umi)) {
-                        best_cnt = c;
-                        best_umi = u[i];
-                        best_p = q;
-                    }
-                }
-            }
-        }
+        return best.pos;
     }
-    return best_p;
+    const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
+    // (1) same high half: my own run in the sorted segment
+    for (uint32_t q = self; q > s;) {
+        --q;
+        const uint32_t u = s_umi[q];
+        if ((u >> sp.lo_bits) != my_hi) break;
+        if (hd1(u & sp.lo_mask, my_lo)) best.offer(s_cnt[q] & ~UC_NOCORR, u, q);
+    }
+    for (uint32_t q = self + 1; q < e; q++) {
+        const uint32_t u = s_umi[q];
+        if ((u >> sp.lo_bits) != my_hi) break;
+        if (hd1(u & sp.lo_mask, my_lo)) best.offer(s_cnt[q] & ~UC_NOCORR, u, q);
+    }
+    // (2) same low half: every member listed under (segment, low half)
+    uc_for_each<BUCKETS, POSBITS>(s_hash, seg_tag, my_lo, [&](uint32_t q) {
+        const uint32_t u = s_umi[q];
+        if ((u & sp.lo_mask) != my_lo) return;                      // fingerprint collision
+        if (s_tag != nullptr && s_tag[q] != (uint16_t)seg_tag) return;  // another segment of the tile
+        if (hd1(u >> sp.lo_bits, my_hi)) best.offer(s_cnt[q] & ~UC_NOCORR, u, q);
+    });
+    return best.pos;
 }
 
 __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const uint64_t *__restrict__ ukey,
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
                                                             uint64_t n_keys, uint32_t *__restrict__ corr,
-                                                            uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all,
-                                                            int ablate) {
+                                                            uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all) {
     __shared__ uint32_t s_umi[UC_TILE];
     __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
     __shared__ uint16_t s_start[UC_TILE];  // segment start inside the tile, UC_OPEN = not fully inside the tile
     __shared__ uint16_t s_end[UC_TILE];    // exclusive end
-    __shared__ __attribute__((aligned(16))) uint32_t s_hash[UC_BUCKETS * 8];  // bucketised hash set
+    __shared__ __attribute__((aligned(16))) uint32_t s_hash[UC_BUCKETS * 8];
     __shared__ unsigned long long s_heads[UC_BLOCKS];  // bit l of entry b: position 64*b+l starts a segment
     __shared__ int s_carry_start[UC_BLOCKS];           // last segment start in blocks < b, or -1
     __shared__ int s_carry_end[UC_BLOCKS];             // first segment start in blocks > b, or INT_MAX
@@ -211,6 +163,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
     __shared__ uint32_t s_any_long;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
+    const UmiSplit sp = umi_split(kl.umi_len);
     const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
     for (uint32_t h = tid; h < UC_BUCKETS * 8; h += 256) s_hash[h] = UC_EMPTY;
     if (tid == 0) s_any_long = 0;
@@ -259,7 +212,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             s_carry_end[tid] = ce;
         }
         __syncthreads();
-        // ---- segment bounds of every key; long in-tile segments enter the hash set ----
+        // ---- segment bounds of every key; members of long in-tile segments enter the hash set ----
         bool inserted = false;
 #pragma unroll
         for (int r = 0; r < UC_ITEMS; r++) {
@@ -274,8 +227,8 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             const bool closed = start >= 0 && end <= (int)UC_TILE;
             s_start[p] = closed ? (uint16_t)start : (uint16_t)UC_OPEN;
             s_end[p] = closed ? (uint16_t)end : (uint16_t)UC_OPEN;
-            if (closed && end - start > UC_SMALL && !(ablate & 16)) {
-                uc_insert<UC_BUCKETS, UC_POSBITS>(s_hash, (uint32_t)start, s_umi[p], p);
+            if (closed && end - start > UC_SMALL && !(s_cnt[p] & UC_NOCORR)) {
+                uc_insert<UC_BUCKETS, UC_POSBITS>(s_hash, (uint32_t)start, s_umi[p] & sp.lo_mask, p);
                 inserted = true;
             }
         }
@@ -292,13 +245,13 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             const uint32_t cw = s_cnt[p];
             const uint32_t my_cnt = cw & ~UC_NOCORR;
             uint32_t target = NONE32;
-            if (!(cw & UC_NOCORR) && e - s > 1 && !(ablate & 1) && !((ablate & 4) && e - s > UC_SMALL) &&
-                !((ablate & 8) && e - s <= UC_SMALL)) {
-                const uint32_t bp = best_neighbour_lds<UC_BUCKETS, UC_POSBITS>(s_umi, s_cnt, s_hash, s_start, s, e, s, p, s_umi[p], my_cnt, kl.umi_len);
+            if (!(cw & UC_NOCORR) && e - s > 1) {
+                const uint32_t bp = best_neighbour_lds<UC_BUCKETS, UC_POSBITS>(s_umi, s_cnt, s_hash, s_start, s, e, s, p,
+                                                                              s_umi[p], my_cnt, sp);
                 if (bp != p) target = (uint32_t)(t0 + bp);
             }
             corr[k] = target;
-            if (target != NONE32 && !(ablate & 2)) {
+            if (target != NONE32) {
                 atomicAdd(&inc1[target], 1u);          // phase 1 moves one read (mark_dups.rs:228-232)
                 atomicAdd(&inc_all[target], my_cnt);   // phases 1+2 move them all (:242-246)
             }
@@ -320,12 +273,13 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
                                                                    uint32_t *__restrict__ inc1,
                                                                    uint32_t *__restrict__ inc_all) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *s_umi = smem;                  // UE_CAP
-    uint32_t *s_cnt = smem + UE_CAP;         // UE_CAP
-    uint32_t *s_hash = smem + 2 * UE_CAP;    // UE_BUCKETS * 8 slots (16-byte aligned: UE_CAP is a multiple of 4)
+    uint32_t *s_umi = smem;                // UE_CAP
+    uint32_t *s_cnt = smem + UE_CAP;       // UE_CAP
+    uint32_t *s_hash = smem + 2 * UE_CAP;  // UE_BUCKETS * 8 slots (16-byte aligned: UE_CAP is a multiple of 4)
     __shared__ unsigned long long s_bounds[2];
     const uint32_t tid = threadIdx.x;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
+    const UmiSplit sp = umi_split(kl.umi_len);
     const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
     for (uint64_t t = (uint64_t)blockIdx.x + 1; t < n_tiles; t += gridDim.x) {
         const uint64_t x = t * UC_TILE;
@@ -343,8 +297,7 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
         if (x - UC_TILE > s) continue;  // the previous boundary is inside the same segment and owns it
         const uint64_t m = e - s;
         const uint32_t lib = (uint32_t)(pre & lowmask(kl.bits_lib));
-        const bool nocorr = (kl.mux_mask >> lib) & 1u;  // UmiCorrection::Disable (aligner.rs:315-318)
-        if (nocorr) {
+        if ((kl.mux_mask >> lib) & 1u) {  // UmiCorrection::Disable (aligner.rs:315-318)
             for (uint64_t k = s + tid; k < e; k += UE_THREADS) corr[k] = NONE32;
             continue;
         }
@@ -360,12 +313,14 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
             }
             __syncthreads();
             if (use_hash) {
-                for (uint32_t p = tid; p < mm; p += UE_THREADS) uc_insert<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, s_umi[p], p);
+                for (uint32_t p = tid; p < mm; p += UE_THREADS)
+                    uc_insert<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, s_umi[p] & sp.lo_mask, p);
                 __syncthreads();
             }
             for (uint32_t p = tid; p < mm; p += UE_THREADS) {
                 const uint32_t my_cnt = s_cnt[p];
-                const uint32_t bp = best_neighbour_lds<UE_BUCKETS, UE_POSBITS>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p, s_umi[p], my_cnt, kl.umi_len);
+                const uint32_t bp = best_neighbour_lds<UE_BUCKETS, UE_POSBITS>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p,
+                                                                              s_umi[p], my_cnt, sp);
                 const uint32_t target = bp != p ? (uint32_t)(s + bp) : NONE32;
                 corr[s + p] = target;
                 if (target != NONE32) {
@@ -374,16 +329,83 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
                 }
             }
             __syncthreads();
-        } else {
-            // larger than the LDS budget: the reference's 3L probes as binary searches in global memory
-            for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
-                const uint32_t my_cnt = run_count(upos, nd, n_keys, k);
-                const uint32_t target = correct_one_global(kl, ukey, upos, nd, n_keys, k, my_cnt, s, e);
-                corr[k] = target;
-                if (target != NONE32) {
-                    atomicAdd(&inc1[target], 1u);
-                    atomicAdd(&inc_all[target], my_cnt);
+            continue;
+        }
+        // ---- larger than the LDS budget -----------------------------------------------------------------
+        // (1) same-high-half neighbours: the run around each key in the sorted global array
+        for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
+            const uint32_t my_umi = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
+            const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
+            Best best{run_count(upos, nd, n_keys, k), my_umi, 0u};
+            uint64_t best_k = k;
+            for (uint64_t q = k; q > s;) {
+                --q;
+                const uint32_t u = (uint32_t)((ukey[q] >> kl.sh_umi) & umi_mask);
+                if ((u >> sp.lo_bits) != my_hi) break;
+                if (hd1(u & sp.lo_mask, my_lo)) {
+                    const uint32_t c = run_count(upos, nd, n_keys, q);
+                    if (c > best.cnt || (c == best.cnt && u > best.umi)) {
+                        best.cnt = c;
+                        best.umi = u;
+                        best_k = q;
+                    }
                 }
+            }
+            for (uint64_t q = k + 1; q < e; q++) {
+                const uint32_t u = (uint32_t)((ukey[q] >> kl.sh_umi) & umi_mask);
+                if ((u >> sp.lo_bits) != my_hi) break;
+                if (hd1(u & sp.lo_mask, my_lo)) {
+                    const uint32_t c = run_count(upos, nd, n_keys, q);
+                    if (c > best.cnt || (c == best.cnt && u > best.umi)) {
+                        best.cnt = c;
+                        best.umi = u;
+                        best_k = q;
+                    }
+                }
+            }
+            corr[k] = best_k != k ? (uint32_t)best_k : NONE32;  // provisional; refined below
+        }
+        __syncthreads();
+        // (2) same-low-half neighbours: chunks of UE_CAP table entries, every key of the segment probes each
+        for (uint64_t c0 = s; c0 < e; c0 += UE_CAP) {
+            const uint32_t cn = e - c0 < UE_CAP ? (uint32_t)(e - c0) : UE_CAP;
+            for (uint32_t h = tid; h < UE_BUCKETS * 8; h += UE_THREADS) s_hash[h] = UC_EMPTY;
+            for (uint32_t p = tid; p < cn; p += UE_THREADS) {
+                s_umi[p] = (uint32_t)((ukey[c0 + p] >> kl.sh_umi) & umi_mask);
+                s_cnt[p] = run_count(upos, nd, n_keys, c0 + p);
+            }
+            __syncthreads();
+            for (uint32_t p = tid; p < cn; p += UE_THREADS)
+                uc_insert<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, s_umi[p] & sp.lo_mask, p);
+            __syncthreads();
+            for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
+                const uint32_t my_umi = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
+                const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
+                // current best of this key (own key, or the provisional target found so far)
+                const uint32_t cur = corr[k];
+                Best best{0u, 0u, 0xFFFFFFFFu};
+                if (cur == NONE32) {
+                    best.cnt = run_count(upos, nd, n_keys, k);
+                    best.umi = my_umi;
+                } else {
+                    best.cnt = run_count(upos, nd, n_keys, cur);
+                    best.umi = (uint32_t)((ukey[cur] >> kl.sh_umi) & umi_mask);
+                }
+                uc_for_each<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, my_lo, [&](uint32_t q) {
+                    const uint32_t u = s_umi[q];
+                    if ((u & sp.lo_mask) != my_lo) return;
+                    if (hd1(u >> sp.lo_bits, my_hi)) best.offer(s_cnt[q], u, q);
+                });
+                if (best.pos != 0xFFFFFFFFu) corr[k] = (uint32_t)(c0 + best.pos);
+            }
+            __syncthreads();
+        }
+        // the moves of this segment's corrected keys
+        for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
+            const uint32_t target = corr[k];
+            if (target != NONE32) {
+                atomicAdd(&inc1[target], 1u);
+                atomicAdd(&inc_all[target], run_count(upos, nd, n_keys, k));
             }
         }
     }
