@@ -35,6 +35,8 @@ struct WlTables {
     uint16_t *d_tailA = nullptr;  // n
     uint32_t *d_valA = nullptr;   // n or nullptr
     uint32_t *d_offB = nullptr;   // (1<<bitsB)+1
+    uint32_t *d_offE = nullptr;   // exact-lookup index, (1 << (key bits - shiftE)) + 1
+    uint32_t shiftE = 0;
     uint16_t *d_headB = nullptr;  // n
     uint32_t *d_valid = nullptr;      // n_canon valid counts
     uint32_t *d_corrected = nullptr;  // n_canon corrected counts

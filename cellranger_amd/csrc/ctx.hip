@@ -74,6 +74,7 @@ static void free_wl(WlTables &w) {
     hipFree(w.d_tailA);
     hipFree(w.d_valA);
     hipFree(w.d_offB);
+    hipFree(w.d_offE);
     hipFree(w.d_headB);
     hipFree(w.d_valid);
     hipFree(w.d_corrected);

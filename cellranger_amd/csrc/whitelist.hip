@@ -128,9 +128,22 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
         }
     }
 
+    // exact-lookup index over the same sorted tails: ~1-2 keys per bin, at least as fine as the head
+    const uint32_t key_bits = 2 * len;
+    uint32_t bitsE = cr_ceil_log2(m) > 0 ? cr_ceil_log2(m) - 1 : 0;
+    if (bitsE < bitsA) bitsE = bitsA;
+    if (bitsE > key_bits) bitsE = key_bits;
+    if (bitsE > 26) bitsE = 26;
+    const uint32_t shiftE = key_bits - bitsE;
+    std::vector<uint32_t> offE(((size_t)1 << bitsE) + 1, 0);
+    for (uint32_t p = 0; p < m; p++) offE[(size_t)((uint64_t)uniq[p].key >> shiftE) + 1]++;
+    for (size_t i = 1; i < offE.size(); i++) offE[i] += offE[i - 1];
+
     WlTables &w = ctx->wl[lib];
     cr_free_wl(w);
     w.n = m;
+    w.shiftE = shiftE;
+    CR_TRY(upload(ctx, &w.d_offE, offE));
     w.bitsA = bitsA;
     w.bitsB = bitsB;
     CR_TRY(upload(ctx, &w.d_offA, offA));
@@ -238,6 +251,8 @@ int cr_make_views(crgpu_ctx *ctx, WlView *views) {
             v.tailA = w.d_tailA;
             v.valA = w.d_valA;
             v.offB = w.d_offB;
+            v.offE = w.d_offE;
+            v.shiftE = w.shiftE;
             v.headB = w.d_headB;
             v.valid = w.d_valid;
             v.corrected = w.d_corrected;
