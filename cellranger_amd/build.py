@@ -26,7 +26,7 @@ FLAGS = [
     "-Wno-unused-function",
     "-Wno-unused-value",
     "-Wno-unused-result",
-]
+] + os.environ.get("CRGPU_EXTRA_FLAGS", "").split()
 
 
 def sources():

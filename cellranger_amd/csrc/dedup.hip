@@ -382,17 +382,27 @@ __device__ __forceinline__ uint32_t group_hash(uint64_t g) {
     return (uint32_t)g;
 }
 
+// val = (extra hash bits << vbits) | index: the bits of the u32 payload the index does not need carry more
+// hash bits, so that most false collisions of the 32-bit sort key are rejected without touching ukey.
 __global__ __launch_bounds__(256) void k_group_hashes(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
-                                                      uint32_t *__restrict__ hash, uint32_t *__restrict__ val) {
+                                                      uint32_t vbits, uint32_t *__restrict__ hash,
+                                                      uint32_t *__restrict__ val) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
-        hash[k] = group_hash(group_id(kl, ukey[k]));
-        val[k] = (uint32_t)k;
+        uint64_t g = group_id(kl, ukey[k]);
+        g ^= g >> 33;
+        g *= 0xff51afd7ed558ccdull;
+        g ^= g >> 33;
+        g *= 0xc4ceb9fe1a85ec53ull;
+        g ^= g >> 33;
+        hash[k] = (uint32_t)g;
+        const uint32_t extra = vbits >= 32u ? 0u : ((uint32_t)(g >> 32) << vbits);
+        val[k] = extra | (uint32_t)k;
     }
 }
 
 __global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint32_t *__restrict__ hash,
-                                                     const uint32_t *__restrict__ val, uint64_t nd,
+                                                     const uint32_t *__restrict__ val, uint64_t nd, uint32_t vbits,
                                                      const uint64_t *__restrict__ ukey,
                                                      const uint32_t *__restrict__ upos, uint64_t n_keys,
                                                      const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc1,
@@ -408,13 +418,20 @@ __global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint32_t
         uint64_t s = j, e = j + 1;
         while (s > 0 && hash[s - 1] == h) s--;
         while (e < nd && hash[e] == h) e++;
-        const uint32_t me = val[j];
+        const uint32_t vmask = vbits >= 32u ? 0xFFFFFFFFu : ((1u << vbits) - 1u);
+        const uint32_t my_val = val[j];
+        // cheap filter on the extra hash bits before any gather
+        bool any = false;
+        for (uint64_t t = s; t < e; t++) any |= t != j && ((val[t] ^ my_val) & ~vmask) == 0u;
+        if (!any) continue;
+        const uint32_t me = my_val & vmask;
         const uint64_t g = group_id(kl, ukey[me]);
         // counts after moving ONE read of each corrected key (mark_dups.rs:226-232); zero-count keys stay
         const uint32_t my_c1 = run_count(upos, nd, n_keys, me) - (corr[me] != NONE32 ? 1u : 0u) + inc1[me];
         uint32_t mx = my_c1, n_members = 0, n_max = 0;
         for (uint64_t t = s; t < e; t++) {
-            const uint32_t k = val[t];
+            if (((val[t] ^ my_val) & ~vmask) != 0u) continue;  // differs in the extra hash bits
+            const uint32_t k = val[t] & vmask;
             if (group_id(kl, ukey[k]) != g) continue;  // hash collision: a different group
             const uint32_t c1 = run_count(upos, nd, n_keys, k) - (corr[k] != NONE32 ? 1u : 0u) + inc1[k];
             n_members++;
@@ -550,6 +567,7 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
 
     // 4. low support: group the distinct keys by (barcode, library, UMI) through a 32-bit hash sort
     {
+        const uint32_t vbits = cr_ceil_log2(nd ? nd : 1);  // bits the distinct-key index needs inside the payload
         DevBuf h_b, ht_b, v_b, vt_b;
         CR_TRY(dmalloc(ctx, h_b, nd * sizeof(uint32_t)));
         CR_TRY(dmalloc(ctx, ht_b, nd * sizeof(uint32_t)));
@@ -557,7 +575,7 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
         CR_TRY(dmalloc(ctx, vt_b, nd * sizeof(uint32_t)));
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
-            hipLaunchKernelGGL(k_group_hashes, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd,
+            hipLaunchKernelGGL(k_group_hashes, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd, vbits,
                                h_b.as<uint32_t>(), v_b.as<uint32_t>());
             CR_HIP(ctx, hipGetLastError());
         }
@@ -568,7 +586,8 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
             CrTimer t(ctx, CRGPU_T_DEDUP);
             hipLaunchKernelGGL(k_low_support, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl,
                                s_in_tmp ? ht_b.as<uint32_t>() : h_b.as<uint32_t>(),
-                               s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), nd, ukey, upos, n_keys, corr, inc1, low);
+                               s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), nd, vbits, ukey, upos, n_keys, corr, inc1,
+                               low);
             CR_HIP(ctx, hipGetLastError());
         }
     }

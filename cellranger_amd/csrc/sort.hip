@@ -13,7 +13,9 @@
 #include "common.h"
 
 #define SORT_BLOCK 256
+#ifndef SORT_ITEMS
 #define SORT_ITEMS 16  // keys per thread per chunk
+#endif
 #define SORT_CHUNK (SORT_BLOCK * SORT_ITEMS)
 #define SORT_WAVES (SORT_BLOCK / 64)
 #define RADIX_BITS 8
