@@ -187,8 +187,18 @@ def main():
             # algorithmic bytes of the timed launches (bytes per element x elements the ledger counted)
             # over their summed HIP-event durations == per-launch bytes / average launch duration
             achieved = bpe * units / (ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+            # profiles/r01_c_*_pmc_fetch_write.json): measured bytes per element x elements per launch
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_c_cfg3_200M_pmc_fetch_write.json")) as f:
+                    pmc = json.load(f)["derived"]
+                if kname == "k_radix_scatter":
+                    traffic = pmc["k_radix_scatter_hbm_bytes_per_element_weighted"] * units / launches
+            except (OSError, KeyError, ValueError):
+                traffic = None
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms / launches,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": ms / launches,
                     "launches_per_step": launches / args.steps, "bytes_per_element": bpe,
                     "elements_per_launch": units / launches}
         step_gbs = STEP_BYTES[workload] * n / (ms_per_step * 1e-3) / 1e9
