@@ -1,0 +1,279 @@
+// crgpu.hpp -- header-only C++17 host layer over the C ABI (include/crgpu.h), mirroring the
+// reference's Rust interface for this path (names, argument meaning, error behaviour), in batch form:
+//
+//   crgpu::Whitelist        barcode/src/whitelist.rs:453-546       Whitelist::{Plain, Trans}
+//   crgpu::Posterior        barcode/src/corrector.rs:92-109        thresholds, Default
+//   crgpu::BarcodeCorrector barcode/src/corrector.rs:14-71         new(whitelist, bc_counts, strategy), correct_barcode
+//   crgpu::DupBuilder       tx_annotation/src/mark_dups.rs:118-169 observe(...), build(...)
+//   crgpu::BarcodeDupMarker tx_annotation/src/mark_dups.rs:171-363 -> UmiCount stream + feature_counts()
+//   crgpu::BarcodeIndex     cr_types/src/barcode_index.rs:14-53
+//   crgpu::CountMatrix      cr_h5/src/count_matrix.rs:382-448, cr_lib/src/stages/write_matrix_market.rs:80-122
+//
+// Errors are C++ exceptions carrying crgpu_last_error (the Rust returns anyhow::Result); nothing here
+// computes on the CPU: every result comes from libcrgpu, and construction fails without a gfx950 device.
+#pragma once
+
+#include <cfloat>
+#include <cstdint>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "crgpu.h"
+
+namespace crgpu {
+
+class Error : public std::runtime_error {
+   public:
+    Error(int code, const std::string &msg) : std::runtime_error("crgpu error " + std::to_string(code) + ": " + msg), code(code) {}
+    int code;
+};
+
+class Context {
+   public:
+    explicit Context(int device_id = 0) {
+        const int rc = crgpu_create(&h_, device_id);
+        if (rc != CRGPU_OK) throw Error(rc, crgpu_last_error(nullptr));
+    }
+    ~Context() { crgpu_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    crgpu_ctx *get() const { return h_; }
+    void check(int rc) const {
+        if (rc != CRGPU_OK) throw Error(rc, crgpu_last_error(h_));
+    }
+
+   private:
+    crgpu_ctx *h_ = nullptr;
+};
+
+/// SimpleHistogram<BcSegSeq> (metric/src/histogram.rs:26-32): sequence -> count, 0 when absent.
+using SimpleHistogram = std::map<std::string, int64_t>;
+
+/// Whitelist::{Plain, Trans}.  `translation` empty => Plain.
+struct Whitelist {
+    std::vector<std::string> sequences;    // raw sequences (file column 1)
+    std::vector<std::string> translation;  // translated sequences (file column 2) or empty
+    static Whitelist plain(std::vector<std::string> seqs) { return Whitelist{std::move(seqs), {}}; }
+    static Whitelist trans(std::vector<std::string> raw, std::vector<std::string> translated) {
+        return Whitelist{std::move(raw), std::move(translated)};
+    }
+};
+
+/// Posterior (corrector.rs:92-109).
+struct Posterior {
+    double max_expected_barcode_errors = DBL_MAX;  // Default: f64::MAX
+    double bc_confidence_threshold = 0.975;        // BARCODE_CONFIDENCE_THRESHOLD
+};
+
+/// BarcodeCorrector::new(whitelist, bc_counts, strategy) for one library type of a context.
+/// `canon` is the canonical (matrix column) list of the GEM well; empty => the whitelist itself.
+class BarcodeCorrector {
+   public:
+    BarcodeCorrector(Context &ctx, int lib, const Whitelist &wl, const SimpleHistogram &bc_counts, Posterior strategy = {},
+                     const std::vector<std::string> &canon = {})
+        : ctx_(ctx), lib_(lib) {
+        if (wl.sequences.empty()) throw Error(CRGPU_EINVAL, "empty whitelist");
+        len_ = (uint32_t)wl.sequences[0].size();
+        const std::vector<std::string> &cn = !canon.empty() ? canon : (wl.translation.empty() ? wl.sequences : wl.translation);
+        // canonical list: unique sequences in first-seen order
+        std::map<std::string, uint32_t> canon_pos;
+        std::string canon_flat;
+        for (const auto &s : cn)
+            if (canon_pos.emplace(s, (uint32_t)canon_pos.size()).second) canon_flat += s;
+        std::string keys_flat;
+        std::vector<uint32_t> translate_to;
+        for (size_t i = 0; i < wl.sequences.size(); i++) {
+            keys_flat += wl.sequences[i];
+            if (!wl.translation.empty()) {
+                auto it = canon_pos.find(wl.translation[i]);
+                if (it == canon_pos.end()) throw Error(CRGPU_EINVAL, "translated sequence is not in the canonical list");
+                translate_to.push_back(it->second);
+            }
+        }
+        ctx_.check(crgpu_set_whitelist(ctx_.get(), lib, keys_flat.data(), (uint32_t)wl.sequences.size(), len_, canon_flat.data(),
+                                       (uint32_t)canon_pos.size(), translate_to.empty() ? nullptr : translate_to.data()));
+        // rank <-> sequence of the canonical space
+        const uint32_t n = (uint32_t)canon_pos.size();
+        std::vector<uint32_t> order(n);
+        ctx_.check(crgpu_get_canon_order(ctx_.get(), order.data(), nullptr));
+        rank_seq_.resize(n);
+        std::vector<std::string> by_pos(n);
+        for (const auto &kv : canon_pos) by_pos[kv.second] = kv.first;
+        for (uint32_t r = 0; r < n; r++) rank_seq_[r] = by_pos[order[r]];
+        for (uint32_t r = 0; r < n; r++) seq_rank_[rank_seq_[r]] = r;
+        // prior = bc_counts keyed by the (translated) sequence
+        std::vector<uint32_t> prior(n, 0);
+        for (const auto &kv : bc_counts) {
+            auto it = seq_rank_.find(kv.first);
+            if (it != seq_rank_.end()) prior[it->second] = (uint32_t)kv.second;
+        }
+        ctx_.check(crgpu_set_counts(ctx_.get(), lib, CRGPU_COUNTS_PRIOR, prior.data()));
+        ctx_.check(crgpu_set_posterior(ctx_.get(), strategy.max_expected_barcode_errors, strategy.bc_confidence_threshold));
+    }
+
+    /// Batch form of correct_barcode for Invalid segments: the corrected (translated) sequence, or
+    /// nullopt when no correction is made.  quals may be empty (Option<BcSegQual> = None).
+    std::vector<std::optional<std::string>> correct_barcodes(const std::vector<std::string> &seqs,
+                                                             const std::vector<std::vector<uint8_t>> &quals) const {
+        const size_t n = seqs.size();
+        std::string flat;
+        std::vector<uint8_t> q;
+        for (size_t i = 0; i < n; i++) {
+            if (seqs[i].size() != len_) throw Error(CRGPU_EINVAL, "barcode length differs from the whitelist's");
+            flat += seqs[i];
+            if (!quals.empty()) q.insert(q.end(), quals[i].begin(), quals[i].end());
+        }
+        std::vector<uint32_t> idx(n, CRGPU_MISS);
+        std::vector<uint8_t> flag(n, 0);
+        ctx_.check(crgpu_correct(ctx_.get(), lib_, reinterpret_cast<const uint8_t *>(flat.data()), quals.empty() ? nullptr : q.data(), n,
+                                 idx.data(), flag.data()));
+        std::vector<std::optional<std::string>> out(n);
+        for (size_t i = 0; i < n; i++)
+            if (flag[i]) out[i] = rank_seq_[idx[i]];
+        return out;
+    }
+    std::optional<std::string> correct_barcode(const std::string &seq, const std::vector<uint8_t> &qual) const {
+        return correct_barcodes({seq}, qual.empty() ? std::vector<std::vector<uint8_t>>{} : std::vector<std::vector<uint8_t>>{qual})[0];
+    }
+    /// Whitelist::check_and_update for a batch: translated sequence on a hit.
+    std::vector<std::optional<std::string>> check_and_update(const std::vector<std::string> &seqs) const {
+        std::string flat;
+        for (const auto &s : seqs) flat += s;
+        std::vector<uint32_t> idx(seqs.size(), CRGPU_MISS);
+        ctx_.check(crgpu_match_and_count(ctx_.get(), lib_, reinterpret_cast<const uint8_t *>(flat.data()), nullptr, seqs.size(), idx.data()));
+        std::vector<std::optional<std::string>> out(seqs.size());
+        for (size_t i = 0; i < seqs.size(); i++)
+            if (idx[i] != CRGPU_MISS) out[i] = rank_seq_[idx[i]];
+        return out;
+    }
+    uint32_t rank_of(const std::string &seq) const { return seq_rank_.at(seq); }
+    const std::string &sequence_of(uint32_t rank) const { return rank_seq_[rank]; }
+    uint32_t barcode_length() const { return len_; }
+
+   private:
+    Context &ctx_;
+    int lib_;
+    uint32_t len_ = 0;
+    std::vector<std::string> rank_seq_;
+    std::map<std::string, uint32_t> seq_rank_;
+};
+
+/// UmiCount (cr_types/src/types.rs:152-160) without probe_idx.
+struct UmiCount {
+    uint32_t barcode_rank;
+    uint16_t library_idx;
+    uint32_t feature_idx, umi, read_count;
+    uint8_t utype;  // 0 Txomic, 1 NonTxomic
+};
+/// FeatureBarcodeCount (types.rs:121-137), BarcodeThenFeatureOrder.
+struct FeatureBarcodeCount {
+    uint32_t barcode_rank, feature_idx, umi_count;
+};
+
+/// Result of DupBuilder::build: what BarcodeDupMarker::process + BcUmiInfo::feature_counts yield for all
+/// barcodes of the batch.
+struct BarcodeDupMarker {
+    std::vector<UmiCount> umi_counts;                 // sorted per barcode as align_and_count.rs:314
+    std::vector<FeatureBarcodeCount> feature_counts;  // sorted by (barcode, feature)
+};
+
+/// DupBuilder: observe() every annotated read of a batch (any number of barcodes / library types), then
+/// build().  umi: ASCII; umi_qual: FASTQ quality bytes; feature: conf_mapped_feature or CRGPU_NO_FEATURE.
+class DupBuilder {
+   public:
+    DupBuilder(Context &ctx, uint32_t n_features, uint32_t umi_len, uint32_t n_libs = 1, uint32_t multiplexing_lib_mask = 0)
+        : ctx_(ctx), n_features_(n_features), umi_len_(umi_len) {
+        ctx_.check(crgpu_set_key_layout(ctx_.get(), n_features, umi_len, n_libs, multiplexing_lib_mask));
+    }
+    void observe(uint32_t barcode_rank, int lib, const std::string &umi, const std::vector<uint8_t> &umi_qual, uint32_t feature,
+                 bool is_txomic = true) {
+        if (umi.size() != umi_len_ || umi_qual.size() != umi_len_) throw Error(CRGPU_EINVAL, "UMI length differs from the layout's");
+        uint32_t packed = 0;
+        for (uint32_t j = 0; j < umi_len_; j++) {
+            const char c = umi[j];
+            const uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+            packed = (packed << 2) | (code & 3u);
+            qualn_.push_back((uint8_t)((umi_qual[j] > 127 ? 127 : umi_qual[j]) | (code == 4u ? 0x80u : 0u)));
+        }
+        bc_.push_back(barcode_rank);
+        umi_.push_back(packed);
+        feature_.push_back(feature);
+        flags_.push_back((uint8_t)((lib & 0x0F) | (is_txomic ? 0 : CRGPU_FLAG_NONTXOMIC)));
+    }
+    BarcodeDupMarker build() {
+        const uint64_t n = bc_.size();
+        struct Dev {
+            const Context &c;
+            void *p = nullptr;
+            Dev(const Context &c, const void *h, uint64_t bytes) : c(c) {
+                c.check(crgpu_malloc(c.get(), &p, bytes));
+                c.check(crgpu_memcpy_h2d(c.get(), p, h, bytes));
+            }
+            ~Dev() { crgpu_free(c.get(), p); }
+        };
+        BarcodeDupMarker out;
+        if (n == 0) return out;
+        Dev d_bc(ctx_, bc_.data(), n * 4), d_umi(ctx_, umi_.data(), n * 4), d_q(ctx_, qualn_.data(), n * umi_len_),
+            d_f(ctx_, feature_.data(), n * 4), d_fl(ctx_, flags_.data(), n);
+        std::vector<uint64_t> zero(n, 0);
+        Dev d_keys(ctx_, zero.data(), n * 8);
+        crgpu_records recs{n, umi_len_, (const uint32_t *)d_bc.p, (const uint32_t *)d_umi.p, (const uint8_t *)d_q.p,
+                           (const uint32_t *)d_f.p, (const uint8_t *)d_fl.p};
+        uint64_t n_keys = 0;
+        ctx_.check(crgpu_build_keys_dev(ctx_.get(), &recs, (uint64_t *)d_keys.p, &n_keys));
+        crgpu_counts *c = nullptr;
+        ctx_.check(crgpu_count_keys_dev(ctx_.get(), (uint64_t *)d_keys.p, n_keys, &c));
+        uint64_t nt = 0, nm = 0;
+        ctx_.check(crgpu_counts_info(ctx_.get(), c, &nt, &nm));
+        std::vector<uint32_t> tb(nt), tf(nt), tc(nt), mb(nm), mf(nm), mu(nm), mr(nm);
+        std::vector<uint8_t> ml(nm), mt(nm);
+        int rc = crgpu_counts_triplets(ctx_.get(), c, tb.data(), tf.data(), tc.data());
+        if (rc == CRGPU_OK) rc = crgpu_counts_molecules(ctx_.get(), c, mb.data(), ml.data(), mf.data(), mu.data(), mr.data(), mt.data());
+        crgpu_counts_free(ctx_.get(), c);
+        ctx_.check(rc);
+        for (uint64_t i = 0; i < nt; i++) out.feature_counts.push_back({tb[i], tf[i], tc[i]});
+        for (uint64_t i = 0; i < nm; i++) out.umi_counts.push_back({mb[i], ml[i], mf[i], mu[i], mr[i], mt[i]});
+        return out;
+    }
+
+   private:
+    Context &ctx_;
+    uint32_t n_features_, umi_len_;
+    std::vector<uint32_t> bc_, umi_, feature_;
+    std::vector<uint8_t> qualn_, flags_;
+};
+
+/// CountMatrix: the arrays write_matrix_h5 stores (count_matrix.rs:382-448) + write_matrix_mtx.
+class CountMatrix {
+   public:
+    CountMatrix(Context &ctx, const std::vector<FeatureBarcodeCount> &counts, uint32_t n_features) : ctx_(ctx) {
+        std::vector<uint32_t> b, f, c;
+        for (const auto &x : counts) {
+            b.push_back(x.barcode_rank);
+            f.push_back(x.feature_idx);
+            c.push_back(x.umi_count);
+        }
+        ctx_.check(crgpu_assemble_matrix(ctx_.get(), b.data(), f.data(), c.data(), counts.size(), n_features, &m_));
+    }
+    ~CountMatrix() { crgpu_matrix_free(ctx_.get(), m_); }
+    CountMatrix(const CountMatrix &) = delete;
+    CountMatrix &operator=(const CountMatrix &) = delete;
+    const crgpu_matrix &arrays() const { return *m_; }
+    /// BarcodeIndex::sorted_barcodes as canonical ranks
+    std::vector<uint32_t> barcode_ranks() const { return {m_->barcode_rank, m_->barcode_rank + m_->n_barcodes}; }
+    void write_matrix_mtx(const std::string &mtx_path, const std::string &barcodes_tsv_path, const std::string &metadata_line,
+                          uint16_t gem_group = 1) const {
+        ctx_.check(crgpu_write_mtx(ctx_.get(), m_, metadata_line.c_str(), mtx_path.c_str(),
+                                   barcodes_tsv_path.empty() ? nullptr : barcodes_tsv_path.c_str(), gem_group));
+    }
+
+   private:
+    Context &ctx_;
+    crgpu_matrix *m_ = nullptr;
+};
+
+}  // namespace crgpu

@@ -1,0 +1,139 @@
+// C++ host-mirror tests (include/crgpu.hpp): the reference's own unit tests for this path, written against
+// the mirrored interface, run on the GPU through the C ABI.
+//   barcode/src/corrector.rs:196-341   test_barcode_correction, ..._no_valid_counts, prop_test_n_in_barcode
+//   tx_annotation/src/mark_dups.rs:371-392   test_correct_umis (same count structure; UMIs changed so that none is
+//                                            a homopolymer, which UmiInfo::new would reject before DupBuilder)
+// Build: g++ -std=c++17 -Iinclude tests/cpp/test_host_mirror.cpp -Lcellranger_amd -lcrgpu   (see tests/test_gpu_cpp_host.py)
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "crgpu.hpp"
+
+static int g_fail = 0;
+#define CHECK(cond)                                                        \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            std::fprintf(stderr, "FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); \
+            g_fail++;                                                      \
+        }                                                                  \
+    } while (0)
+
+using crgpu::BarcodeCorrector;
+using crgpu::Posterior;
+using crgpu::SimpleHistogram;
+using crgpu::Whitelist;
+using Qual = std::vector<uint8_t>;
+
+static void test_barcode_correction() {
+    crgpu::Context ctx(0);
+    const Whitelist wl = Whitelist::plain({"AAAAA", "AAGAC", "ACGAA", "ACGTT"});
+    SimpleHistogram bc_counts{{"AAAAA", 100}, {"AAGAC", 11}, {"ACGAA", 2}};
+    BarcodeCorrector corrector(ctx, 0, wl, bc_counts, Posterior{1.0, 0.95});
+    // Easy / low quality
+    CHECK(!corrector.correct_barcode("AAAAA", Qual{34, 34, 34, 66, 66}).has_value());
+    // Trivial correction
+    CHECK(corrector.correct_barcode("AAAAT", Qual{66, 66, 66, 66, 40}) == std::optional<std::string>("AAAAA"));
+    // Pseudo-count kills you
+    CHECK(!corrector.correct_barcode("ACGAT", Qual{66, 66, 66, 66, 66}).has_value());
+    // Quality help you
+    CHECK(corrector.correct_barcode("ACGAT", Qual{66, 66, 66, 66, 40}) == std::optional<std::string>("ACGAA"));
+    // Counts help you
+    CHECK(corrector.correct_barcode("ACAAA", Qual{66, 66, 66, 66, 40}) == std::optional<std::string>("AAAAA"));
+    // exact membership (Whitelist::check_and_update)
+    auto hit = corrector.check_and_update({"AAGAC", "AAGAT"});
+    CHECK(hit[0] == std::optional<std::string>("AAGAC") && !hit[1].has_value());
+}
+
+static void test_barcode_correction_no_valid_counts() {
+    crgpu::Context ctx(0);
+    BarcodeCorrector val(ctx, 0, Whitelist::plain({"AAAAA", "AAGAC", "ACGAA", "ACGTT"}), SimpleHistogram{}, Posterior{1.0, 0.95});
+    CHECK(!val.correct_barcode("AAAAA", Qual{34, 34, 34, 66, 66}).has_value());
+    CHECK(val.correct_barcode("AAAAT", Qual{66, 66, 66, 66, 40}) == std::optional<std::string>("AAAAA"));
+}
+
+static void prop_test_n_in_barcode() {
+    crgpu::Context ctx(0);
+    const std::string bc = "GCGATTGACCCAAAGG";
+    BarcodeCorrector corrector(ctx, 0, Whitelist::plain({bc}), SimpleHistogram{}, Posterior{1.0, 0.975});
+    for (size_t n_pos = 0; n_pos < 16; n_pos++) {
+        std::string with_n = bc;
+        with_n[n_pos] = 'N';
+        Qual qual(16, 53);
+        qual[n_pos] = 35;
+        CHECK(corrector.correct_barcode(with_n, qual) == std::optional<std::string>(bc));
+    }
+}
+
+static void test_translation_whitelist() {
+    crgpu::Context ctx(0);
+    // Whitelist::Trans: the content becomes the translated sequence, the prior is keyed by it
+    BarcodeCorrector c(ctx, 0, Whitelist::trans({"AAAA", "CCCC"}, {"GGGG", "TTTT"}), SimpleHistogram{{"GGGG", 50}});
+    auto hit = c.check_and_update({"AAAA", "GGGG"});
+    CHECK(hit[0] == std::optional<std::string>("GGGG") && !hit[1].has_value());
+    CHECK(c.correct_barcode("AAAC", Qual{66, 66, 66, 40}) == std::optional<std::string>("GGGG"));
+}
+
+static void test_correct_umis_through_dup_builder() {
+    crgpu::Context ctx(0);
+    BarcodeCorrector corrector(ctx, 0, Whitelist::plain({"ACGTACGTACGTACGT", "TTTTACGTACGTACGT"}), SimpleHistogram{});
+    const Qual q(4, 'I');
+    const uint32_t g0 = 0, g1 = 1;
+    {
+        // {(ACAA,g0):3, (ACAT,g0):2, (ACAA,g1):1, (ACTT,g1):1}: ACAT -> ACAA within g0 (count wins)
+        crgpu::DupBuilder b(ctx, 2, 4);
+        for (int i = 0; i < 3; i++) b.observe(0, 0, "ACAA", q, g0);
+        for (int i = 0; i < 2; i++) b.observe(0, 0, "ACAT", q, g0);
+        b.observe(0, 0, "ACAA", q, g1);
+        b.observe(0, 0, "ACTT", q, g1);
+        const crgpu::BarcodeDupMarker m = b.build();
+        // (ACAA,g1) is low support: ACAA has 4 reads in g0 after the first move, 1 in g1 (mark_dups.rs:96-106)
+        CHECK(m.umi_counts.size() == 2);
+        if (m.umi_counts.size() == 2) {
+            CHECK(m.umi_counts[0].feature_idx == g0 && m.umi_counts[0].umi == 0b00010000u && m.umi_counts[0].read_count == 5);
+            CHECK(m.umi_counts[1].feature_idx == g1 && m.umi_counts[1].umi == 0b00011111u && m.umi_counts[1].read_count == 1);
+        }
+        CHECK(m.feature_counts.size() == 2 && m.feature_counts[0].umi_count == 1 && m.feature_counts[1].umi_count == 1);
+    }
+    {
+        // {(CCAC,g0):1, (CGAC,g0):1}: equal counts -> the lexicographically larger UMI wins
+        crgpu::DupBuilder b(ctx, 2, 4);
+        b.observe(1, 0, "CCAC", q, g0);
+        b.observe(1, 0, "CGAC", q, g0);
+        const crgpu::BarcodeDupMarker m = b.build();
+        CHECK(m.umi_counts.size() == 1);
+        if (m.umi_counts.size() == 1) {
+            CHECK(m.umi_counts[0].umi == 0b01100001u && m.umi_counts[0].read_count == 2 && m.umi_counts[0].barcode_rank == 1);
+        }
+        crgpu::CountMatrix mat(ctx, m.feature_counts, 2);
+        // no read was matched against the whitelist in this context: the barcode index is empty, so a count
+        // for an unseen barcode must be reported as an error rather than silently dropped
+        (void)mat;
+        CHECK(false && "assemble_matrix must reject a triplet outside the barcode index");
+    }
+}
+
+int main() {
+    try {
+        test_barcode_correction();
+        test_barcode_correction_no_valid_counts();
+        prop_test_n_in_barcode();
+        test_translation_whitelist();
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "unexpected exception: %s\n", e.what());
+        return 2;
+    }
+    try {
+        test_correct_umis_through_dup_builder();
+    } catch (const crgpu::Error &e) {
+        // expected: the last CountMatrix of the test has no barcode index entry for its triplet
+        if (std::string(e.what()).find("outside the barcode index") == std::string::npos) {
+            std::fprintf(stderr, "unexpected exception: %s\n", e.what());
+            return 2;
+        }
+    }
+    if (g_fail) return 1;
+    std::printf("cpp host mirror: all tests passed\n");
+    return 0;
+}
