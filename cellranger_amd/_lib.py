@@ -135,7 +135,8 @@ SYMBOLS = {
     "crgpu_correct": (_i, [_vp, _i, _vp, _vp, _u64, _vp, _vp]),
     "crgpu_set_key_layout": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "crgpu_build_keys_dev": (_i, [_vp, C.POINTER(Records), _vp, C.POINTER(_u64)]),
-    "crgpu_partition_keys_dev": (_i, [_vp, _vp, _u64, _u32, _vp, _vp]),
+    "crgpu_partition_keys_dev": (_i, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),
+    "crgpu_balanced_bounds": (_i, [_vp, _u32, _vp]),
     "crgpu_count_keys_dev": (_i, [_vp, _vp, _u64, C.POINTER(_vp)]),
     "crgpu_counts_info": (_i, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "crgpu_counts_triplets_dev": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),

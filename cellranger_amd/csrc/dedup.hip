@@ -23,7 +23,7 @@
 
 int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_total_out);
 int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
-                          uint32_t n_ranks, uint64_t *counts_out);
+                          uint32_t n_ranks, const uint32_t *bounds, uint64_t *counts_out);
 
 #define NONE32 0xFFFFFFFFu
 
@@ -166,11 +166,42 @@ extern "C" int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, u
 }
 
 extern "C" int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n, uint32_t n_ranks,
-                                        uint64_t *d_keys_out, uint64_t *counts_out) {
+                                        const uint32_t *bounds, uint64_t *d_keys_out, uint64_t *counts_out) {
     if (!ctx || !counts_out) return CRGPU_EINVAL;
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_partition_keys: call crgpu_set_key_layout first");
     CR_REQUIRE(ctx, n == 0 || (d_keys && d_keys_out), CRGPU_EINVAL, "crgpu_partition_keys: NULL buffer");
-    return cr_partition_by_owner(ctx, d_keys, d_keys_out, n, ctx->layout.sh_bc(), n_ranks, counts_out);
+    return cr_partition_by_owner(ctx, d_keys, d_keys_out, n, ctx->layout.sh_bc(), n_ranks, bounds, counts_out);
+}
+
+// Histogram-balanced owner ranges: bounds_out[0] = 0, bounds_out[n_ranks] = n_canon, and every range holds
+// about the same number of reads according to the VALID + CORRECTED tables of all libraries (call it after the
+// tables have been all-reduced so that every rank derives the same bounds).
+extern "C" int crgpu_balanced_bounds(crgpu_ctx *ctx, uint32_t n_ranks, uint32_t *bounds_out) {
+    if (!ctx || !bounds_out) return CRGPU_EINVAL;
+    CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_balanced_bounds: no whitelist set");
+    CR_REQUIRE(ctx, n_ranks >= 1 && n_ranks <= 256, CRGPU_EINVAL, "crgpu_balanced_bounds: n_ranks must be 1..256");
+    const uint32_t W = ctx->n_canon;
+    std::vector<uint64_t> tot(W, 0);
+    std::vector<uint32_t> tmp(W);
+    for (int l = 0; l < CRGPU_MAX_LIB; l++) {
+        if (!ctx->wl[l].set) continue;
+        for (int which = 0; which < 2; which++) {
+            CR_TRY(crgpu_memcpy_d2h(ctx, tmp.data(), which ? ctx->wl[l].d_corrected : ctx->wl[l].d_valid, sizeof(uint32_t) * W));
+            for (uint32_t r = 0; r < W; r++) tot[r] += tmp[r];
+        }
+    }
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < W; r++) total += tot[r];
+    bounds_out[0] = 0;
+    uint64_t acc = 0;
+    uint32_t r = 0;
+    for (uint32_t k = 1; k < n_ranks; k++) {
+        const uint64_t want = total * k / n_ranks;
+        while (r < W && acc + tot[r] <= want) acc += tot[r++];
+        bounds_out[k] = r;
+    }
+    bounds_out[n_ranks] = W;
+    return CRGPU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

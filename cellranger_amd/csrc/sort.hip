@@ -68,11 +68,21 @@ int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_tota
 // mode 0: (key >> shift) & mask           (radix pass)
 // mode 1: ((key >> shift) / width)         (owner rank of the barcode, crgpu_partition_keys_dev:
 //                                           contiguous barcode-rank ranges, like shardio's make_chunks)
+// mode 2: owner = index of the range [bounds[r], bounds[r+1]) that holds (key >> shift); `bounds` has
+//         width+1 ascending entries in device memory (histogram-balanced ranges)
 struct DigitFn {
     uint32_t shift, mask, width, mode;
+    const uint32_t *bounds;
     __device__ __forceinline__ uint32_t operator()(uint64_t key) const {
         const uint64_t v = key >> shift;
-        return mode == 0 ? (uint32_t)(v & mask) : (uint32_t)(v / width);
+        if (mode == 0) return (uint32_t)(v & mask);
+        if (mode == 1) return (uint32_t)(v / width);
+        uint32_t lo = 0, hi = width;  // first r with bounds[r+1] > v
+        while (lo + 1 < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (bounds[mid] <= (uint32_t)v) lo = mid; else hi = mid;
+        }
+        return lo;
     }
 };
 
@@ -266,7 +276,7 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
     uint32_t *vin = d_vals, *vout = d_vals_tmp;
     for (uint32_t shift = lo_bit; shift < hi_bit; shift += RADIX_BITS) {
         const uint32_t bits = hi_bit - shift < RADIX_BITS ? hi_bit - shift : RADIX_BITS;
-        DigitFn dig{shift, (1u << bits) - 1u, 1u, 0u};
+        DigitFn dig{shift, (1u << bits) - 1u, 1u, 0u, nullptr};
         CR_TRY(radix_pass<K>(ctx, in, out, vin, vout, n, dig));
         K *t = in;
         in = out;
@@ -293,14 +303,24 @@ int cr_radix_sort_u32(crgpu_ctx *ctx, uint32_t *d_keys, uint32_t *d_tmp, uint32_
 
 // Stable partition of keys by the owner rank of their barcode: one counting-sort pass.
 int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
-                          uint32_t n_ranks, uint64_t *counts_out) {
+                          uint32_t n_ranks, const uint32_t *bounds, uint64_t *counts_out) {
     CR_REQUIRE(ctx, n_ranks >= 1 && n_ranks <= RADIX, CRGPU_EINVAL, "partition: n_ranks must be 1..256");
     CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "partition: at most 2^32-2 keys per call");
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = 0;
     if (n == 0) return CRGPU_OK;
-    // rank r owns canonical barcode ranks [r*width, (r+1)*width)
+    // rank r owns canonical barcode ranks [r*width, (r+1)*width), or [bounds[r], bounds[r+1]) when given
     const uint32_t width = (ctx->n_canon + n_ranks - 1) / n_ranks;
-    DigitFn dig{sh_bc, 0u, width ? width : 1u, 1u};
+    DigitFn dig{sh_bc, 0u, width ? width : 1u, 1u, nullptr};
+    if (bounds) {
+        CR_REQUIRE(ctx, bounds[0] == 0 && bounds[n_ranks] >= ctx->n_canon, CRGPU_EINVAL,
+                   "partition: bounds must start at 0 and end at or beyond the whitelist size");
+        for (uint32_t r = 0; r < n_ranks; r++)
+            CR_REQUIRE(ctx, bounds[r] <= bounds[r + 1], CRGPU_EINVAL, "partition: bounds must be ascending");
+        uint32_t *d_bounds = ctx->d_scalars + 760;  // 257 u32 inside the 1024-word scalar page
+        CR_HIP(ctx, hipMemcpyAsync(d_bounds, bounds, (n_ranks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's array may be a temporary
+        dig = DigitFn{sh_bc, 0u, n_ranks, 2u, d_bounds};
+    }
     CR_TRY(radix_pass<uint64_t>(ctx, d_in, d_out, nullptr, nullptr, n, dig));
     uint32_t totals[RADIX];
     CR_TRY(crgpu_memcpy_d2h(ctx, totals, digit_totals_buf(ctx), sizeof(totals)));

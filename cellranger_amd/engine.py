@@ -378,10 +378,17 @@ class Context:
         self._check(self.L.crgpu_build_keys_dev(self.h, C.byref(recs), _p(d_keys_out), C.byref(n)))
         return n.value
 
-    def partition_keys(self, d_keys, n, n_ranks, d_keys_out):
+    def partition_keys(self, d_keys, n, n_ranks, d_keys_out, bounds=None):
         counts = np.zeros(n_ranks, np.uint64)
-        self._check(self.L.crgpu_partition_keys_dev(self.h, _p(d_keys), n, n_ranks, _p(d_keys_out), ptr(counts)))
+        b = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.uint32)
+        assert b is None or len(b) == n_ranks + 1
+        self._check(self.L.crgpu_partition_keys_dev(self.h, _p(d_keys), n, n_ranks, ptr(b), _p(d_keys_out), ptr(counts)))
         return counts
+
+    def balanced_bounds(self, n_ranks):
+        b = np.zeros(n_ranks + 1, np.uint32)
+        self._check(self.L.crgpu_balanced_bounds(self.h, n_ranks, ptr(b)))
+        return b
 
     def count_keys(self, d_keys, n_keys):
         h = C.c_void_p()

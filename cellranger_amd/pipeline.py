@@ -88,7 +88,9 @@ class HipBackend:
     def partition(self, keys, n_keys, n_ranks):
         out = self.ctx.empty(max(n_keys, 1), np.uint64)
         self._keep.append(out)
-        counts = self.ctx.partition_keys(keys, n_keys, n_ranks, out)
+        # read-balanced barcode ranges from the (already all-reduced) histograms: identical on every rank
+        bounds = self.ctx.balanced_bounds(n_ranks)
+        counts = self.ctx.partition_keys(keys, n_keys, n_ranks, out, bounds=bounds)
         return out, [int(x) for x in counts]
 
     def keys_tensor(self, keys, n_keys):

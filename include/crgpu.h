@@ -192,10 +192,15 @@ int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_
                          uint64_t *n_keys_out);
 /* owner rank of a key's barcode for the all-to-all: rank r owns the contiguous canonical-rank range
  * [r*w, (r+1)*w), w = ceil(n_canon / n_ranks) -- barcode-range chunks like shardio's make_chunks
- * (align_and_count.rs:505-524).  Stable partition of d_keys (n) into n_ranks contiguous groups in
- * d_keys_out; counts_out[r] = keys owned by rank r (host). */
+ * (align_and_count.rs:505-524) -- or, when `bounds` (host, n_ranks+1 ascending ranks, bounds[0] = 0,
+ * bounds[n_ranks] >= n_canon) is given, the range [bounds[r], bounds[r+1]).  Stable partition of d_keys
+ * (n) into n_ranks contiguous groups in d_keys_out; counts_out[r] = keys owned by rank r (host). */
 int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n, uint32_t n_ranks,
-                             uint64_t *d_keys_out, uint64_t *counts_out);
+                             const uint32_t *bounds, uint64_t *d_keys_out, uint64_t *counts_out);
+/* Read-balanced ranges from the VALID + CORRECTED tables (all libraries), as make_chunks balances
+ * barcode ranges by record count.  Call after those tables were all-reduced: every rank then derives
+ * the same bounds.  bounds_out: n_ranks + 1 entries. */
+int crgpu_balanced_bounds(crgpu_ctx *ctx, uint32_t n_ranks, uint32_t *bounds_out);
 
 /* result of the dedup: (barcode rank, feature, umi_count) triplets sorted by (barcode, feature),
  * i.e. the FeatureBarcodeCount stream in BarcodeThenFeatureOrder (types.rs:121-137), plus the

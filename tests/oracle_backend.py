@@ -102,9 +102,24 @@ class OracleBackend:
         keys = np.ascontiguousarray(keys[keep])
         return keys, len(keys)
 
+    def balanced_bounds(self, n_ranks):
+        tot = np.zeros(self.n_canon, np.int64)
+        for which in (COUNTS_VALID, COUNTS_CORRECTED):
+            for l in range(self.n_libs):
+                tot += self.hist[which][l]
+        cum = np.cumsum(tot)
+        total = int(cum[-1]) if len(cum) else 0
+        bounds = [0]
+        for k in range(1, n_ranks):
+            bounds.append(int(np.searchsorted(cum, total * k // n_ranks, side="right")))
+        bounds.append(self.n_canon)
+        return np.array(bounds, np.uint32)
+
     def partition(self, keys, n_keys, n_ranks):
-        width = (self.n_canon + n_ranks - 1) // n_ranks
-        owner = (keys[:n_keys] >> np.uint64(self.sh_bc)) // np.uint64(width)
+        bounds = self.balanced_bounds(n_ranks)
+        bc = (keys[:n_keys] >> np.uint64(self.sh_bc)).astype(np.int64)
+        owner = np.searchsorted(bounds[1:].astype(np.int64), bc, side="right").astype(np.uint64)
+        owner = np.minimum(owner, np.uint64(n_ranks - 1))
         order = np.argsort(owner, kind="stable")
         return np.ascontiguousarray(keys[:n_keys][order]), [int((owner == r).sum()) for r in range(n_ranks)]
 

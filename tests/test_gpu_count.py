@@ -81,6 +81,16 @@ def test_radix_sort_matches_numpy():
         exp = np.concatenate([keys[owner == r] for r in range(n_ranks)])  # stable
         assert np.array_equal(out, exp)
         assert list(cnt) == [int((owner == r).sum()) for r in range(n_ranks)]
+    # explicit (histogram-balanced style) ranges, including an empty one
+    bounds = np.array([0, 10, 10, 700, 1000], np.uint32)
+    cnt = c.partition_keys(d_in, n, 4, d_out, bounds=bounds)
+    owner = np.searchsorted(bounds[1:].astype(np.int64), (keys >> np.uint64(35)).astype(np.int64), side="right")
+    exp = np.concatenate([keys[owner == r] for r in range(4)])
+    assert np.array_equal(d_out.to_host(), exp) and list(cnt) == [int((owner == r).sum()) for r in range(4)]
+    assert cnt[1] == 0
+    # balanced bounds come from the context's histograms: none yet -> all ranges collapse but stay valid
+    b = c.balanced_bounds(4)
+    assert b[0] == 0 and b[-1] == 1000 and (np.diff(b.astype(np.int64)) >= 0).all()
     c.close()
 
 
