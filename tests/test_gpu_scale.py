@@ -1,0 +1,143 @@
+"""Size-independent properties of the HIP path at sizes the oracle cannot check in seconds
+(50 M reads here; bench.py runs 1 B): conservation laws, sortedness, determinism, batch-split
+invariance, agreement between the two ways of driving the count stage."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 50_000_000
+
+
+def _checksum(*arrays):
+    c = 0
+    for a in arrays:
+        c = zlib.crc32(np.ascontiguousarray(a).view(np.uint8), c)
+    return c
+
+
+@pytest.fixture(scope="module")
+def big():
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+
+    w = S.Workload(n_total=N, seed=S.SEED0 + 3)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+    d = dict(n=N, umi_len=w.umi_len)
+    d["cb"], d["cb_qualn"], d["flags"] = c.empty(N, np.uint32), c.empty((N, 16), np.uint8), c.empty(N, np.uint8)
+    d["umi"], d["umi_qualn"], d["feature"] = c.empty(N, np.uint32), c.empty((N, 12), np.uint8), c.empty(N, np.uint32)
+    d["idx"] = c.empty(N, np.uint32)
+    c.synth(w, 0, N, cb=d["cb"].ptr, cb_qualn=d["cb_qualn"].ptr, umi=d["umi"].ptr, umi_qualn=d["umi_qualn"].ptr,
+            feature=d["feature"].ptr, flags=d["flags"].ptr)
+    yield c, w, d
+    c.close()
+
+
+def _run(c, d):
+    from cellranger_amd._lib import COUNTS_CORRECTED, COUNTS_VALID
+
+    c.reset_counts()
+    c.match_and_count(d["cb"], d["flags"], d["n"], d["idx"])
+    idx_a = d["idx"].to_host()
+    c.correct(d["cb"], d["cb_qualn"], d["flags"], d["n"], d["idx"])
+    idx_b = d["idx"].to_host()
+    valid, corrected = c.get_counts(0, COUNTS_VALID), c.get_counts(0, COUNTS_CORRECTED)
+    recs = c.records(d["n"], d["umi_len"], d["idx"], d["umi"], d["umi_qualn"], d["feature"], d["flags"])
+    keys = c.empty(d["n"], np.uint64)
+    nk = c.build_keys(recs, keys)
+    counts = c.count_keys(keys, nk)
+    bc, ft, ct = counts.triplets()
+    mol = counts.molecules()
+    m = c.assemble_matrix(bc, ft, ct, c.n_features)
+    return dict(idx_a=idx_a, idx_b=idx_b, valid=valid, corrected=corrected, nk=nk, bc=bc, ft=ft, ct=ct, mol=mol, m=m, recs=recs)
+
+
+def test_conservation_sortedness_and_determinism(big):
+    from cellranger_amd._lib import MISS
+
+    c, w, d = big
+    r = _run(c, d)
+    # pass A / pass B bookkeeping: histograms are exactly the per-read results
+    hit_a = r["idx_a"] != MISS
+    assert r["valid"].sum() == hit_a.sum()
+    assert np.array_equal(np.bincount(r["idx_a"][hit_a], minlength=c.n_canon).astype(np.uint32), r["valid"])
+    fixed = (r["idx_b"] != MISS) & ~hit_a
+    assert r["corrected"].sum() == fixed.sum()
+    assert np.array_equal(r["idx_b"][hit_a], r["idx_a"][hit_a])        # pass B never touches a valid read
+    assert 0.90 < hit_a.mean() < 0.94 and 0.05 < fixed.mean() < 0.09   # the cfg2/cfg3 error model
+    # every corrected barcode is a Hamming-1 neighbour of what was read
+    _, canon_sorted = c.canon_order()
+    cb = d["cb"].to_host()
+    sel = np.nonzero(fixed)[0][:2_000_000]
+    x = canon_sorted[r["idx_b"][sel]] ^ cb[sel]
+    y = (x | (x >> np.uint32(1))) & np.uint32(0x55555555)
+    n_diff = np.zeros(len(sel), np.int64)
+    for k in range(16):
+        n_diff += ((y >> np.uint32(2 * k)) & np.uint32(1)).astype(np.int64)
+    has_n = (d["flags"].to_host()[sel] & 0x10) != 0
+    assert ((n_diff == 1) | has_n).all() and (n_diff <= 1).all()
+    # triplets: strictly sorted by (barcode, feature); counts positive; consistent with the molecule table
+    key = r["bc"].astype(np.uint64) << np.uint64(32) | r["ft"].astype(np.uint64)
+    assert (np.diff(key.astype(np.int64)) > 0).all() and (r["ct"] > 0).all()
+    mol = r["mol"]
+    assert r["ct"].sum() == len(mol["bc"])
+    mkey = mol["bc"].astype(np.uint64) << np.uint64(32) | mol["feature"].astype(np.uint64)
+    uk, cnt = np.unique(mkey, return_counts=True)
+    assert np.array_equal(uk, key) and np.array_equal(cnt.astype(np.uint32), r["ct"])
+    # reads are conserved: every key lands on exactly one (corrected) key; molecules exclude low support only
+    assert mol["read_count"].sum() <= r["nk"] and mol["read_count"].sum() > 0.97 * r["nk"]
+    assert (mol["read_count"] > 0).all()
+    # CSC invariants (count_matrix.rs:382-448)
+    m = r["m"]
+    assert m.indptr[0] == 0 and m.indptr[-1] == m.nnz == len(r["ct"]) and (np.diff(m.indptr) >= 0).all()
+    assert (np.diff(m.barcode_rank.astype(np.int64)) > 0).all()
+    seen = (r["valid"] > 0) | (r["corrected"] > 0)
+    assert np.array_equal(m.barcode_rank, np.nonzero(seen)[0].astype(np.uint32))    # BarcodeIndex
+    assert int(m.data.sum()) == len(mol["bc"])
+    # a second run gives bit-identical outputs (no order-dependent atomics leak into results)
+    r2 = _run(c, d)
+    assert _checksum(r["idx_b"], r["valid"], r["corrected"], r["bc"], r["ft"], r["ct"]) == \
+        _checksum(r2["idx_b"], r2["valid"], r2["corrected"], r2["bc"], r2["ft"], r2["ct"])
+    for f in ("bc", "lib", "feature", "umi", "read_count", "utype"):
+        assert np.array_equal(r["mol"][f], r2["mol"][f]), f
+    # the one-call entry point and the device CSC agree with the step-by-step path
+    m1 = c.count(r2["recs"], c.n_features)
+    keys2, nk2 = _rebuild_keys(c, r2["recs"], d["n"])
+    counts2 = c.count_keys(keys2, nk2)  # keep alive: its device triplets feed the device CSC assembly
+    md = c.assemble_matrix_dev(*counts2.triplets_dev(), counts2.n_triplets)
+    rank, indptr, indices, data = md.download()
+    for a, b in ((m1.indptr, m.indptr), (m1.indices, m.indices), (m1.data, m.data), (indptr, m.indptr), (indices, m.indices),
+                 (data, m.data), (rank, m.barcode_rank)):
+        assert np.array_equal(a, b)
+
+
+def _rebuild_keys(c, recs, n):
+    keys = c.empty(n, np.uint64)
+    nk = c.build_keys(recs, keys)
+    return keys, nk
+
+
+def test_batch_split_invariance(big):
+    """The ABI accumulates histograms over batches (the Rust host feeds FASTQ chunks): two half batches followed
+    by pass B give the same indices and tables as one batch."""
+    from cellranger_amd._lib import COUNTS_CORRECTED, COUNTS_VALID
+
+    c, w, d = big
+    n = 10_000_000
+    h = n // 2
+    c.reset_counts()
+    c.match_and_count(d["cb"], d["flags"], n, d["idx"])
+    c.correct(d["cb"], d["cb_qualn"], d["flags"], n, d["idx"])
+    one = d["idx"].to_host(count=n)
+    v1, c1 = c.get_counts(0, COUNTS_VALID), c.get_counts(0, COUNTS_CORRECTED)
+    c.reset_counts()
+    for off in (0, h):  # pass A over both halves first: the prior must be complete before pass B
+        c.match_and_count(d["cb"].ptr + 4 * off, d["flags"].ptr + off, h, d["idx"].ptr + 4 * off)
+    for off in (0, h):
+        c.correct(d["cb"].ptr + 4 * off, d["cb_qualn"].ptr + 16 * off, d["flags"].ptr + off, h, d["idx"].ptr + 4 * off)
+    assert np.array_equal(d["idx"].to_host(count=n), one)
+    assert np.array_equal(c.get_counts(0, COUNTS_VALID), v1) and np.array_equal(c.get_counts(0, COUNTS_CORRECTED), c1)
