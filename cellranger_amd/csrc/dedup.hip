@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                                                     const uint32_t *__restrict__ umi, const uint8_t *__restrict__ umi_q,
                                                     const uint32_t *__restrict__ feature, const uint8_t *__restrict__ flags,
                                                     uint64_t n, uint64_t *__restrict__ keys_out,
+                                                    uint32_t *__restrict__ vals_out,
                                                     unsigned long long *__restrict__ n_out) {
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
     const uint32_t L = kl.umi_len;
@@ -134,12 +135,16 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
       unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_out, lds);
 #pragma unroll
       for (int j = 0; j < KEY_ITEMS; j++)
-        if (mask & (1u << j)) keys_out[o++] = keys[j];
+        if (mask & (1u << j)) {
+            keys_out[o] = keys[j];
+            if (vals_out) vals_out[o] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);  // read ordinal
+            o++;
+        }
     }
 }
 
-extern "C" int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out,
-                                    uint64_t *n_keys_out) {
+static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out, uint32_t *d_vals_out,
+                           uint64_t *n_keys_out) {
     if (!ctx || !recs || !n_keys_out) return CRGPU_EINVAL;
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_build_keys: call crgpu_set_key_layout first");
     CR_REQUIRE(ctx, recs->umi_len == ctx->layout.umi_len, CRGPU_EINVAL, "records umi_len %u != layout umi_len %u",
@@ -156,13 +161,18 @@ extern "C" int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, u
         CR_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(*d_n), ctx->stream));
         hipLaunchKernelGGL(k_build_keys, dim3(cr_grid(recs->n, 256)), dim3(256), 0, ctx->stream, make_kl(ctx->layout),
                            recs->d_bc_idx, recs->d_umi, recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n,
-                           d_keys_out, d_n);
+                           d_keys_out, d_vals_out, d_n);
         CR_HIP(ctx, hipGetLastError());
     }
     unsigned long long h = 0;
     CR_TRY(crgpu_memcpy_d2h(ctx, &h, d_n, sizeof(h)));
     *n_keys_out = h;
     return CRGPU_OK;
+}
+
+extern "C" int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out,
+                                    uint64_t *n_keys_out) {
+    return build_keys_impl(ctx, recs, d_keys_out, nullptr, n_keys_out);
 }
 
 extern "C" int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n, uint32_t n_ranks,
@@ -316,7 +326,7 @@ struct EmitMol {
         // UmiType of the representative read (mark_dups.rs:250-268,326-329): the min (utype, qname)
         // read of the smallest qualifying raw UMI corrected onto k, else of k itself.
         const unsigned long long mr = minraw[k];
-        const uint64_t bit = mr != ~0ull ? (uint64_t)(mr & 1ull) : (ukey[k] & 1ull);
+        const uint64_t bit = (mr != ~0ull ? ukey[mr & 0xFFFFFFFFull] : ukey[k]) & 1ull;
         mkeys[o] = (ukey[k] & ~1ull) | bit;
         const uint32_t end = k + 1 < n_dist ? upos[k + 1] : (uint32_t)n_keys;
         const uint32_t cnt = end - upos[k];
@@ -375,8 +385,7 @@ __device__ __forceinline__ uint32_t run_count(const uint32_t *__restrict__ upos,
 
 // Representative-read bookkeeping (mark_dups.rs:248-268): for a corrected key K the representative
 // is the min-(utype, qname) read of the lexicographically smallest raw UMI R corrected onto K with
-// (R < K or K itself corrected away).  Only its UmiType survives into the UmiCount, so keep
-// min over such R of (R << 1 | min utype bit of R).
+// (R < K or K itself corrected away).  Keep min over such R of (R << 32 | distinct-key index of R).
 __global__ __launch_bounds__(256) void k_rep_utype(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
                                                    const uint32_t *__restrict__ corr,
                                                    unsigned long long *__restrict__ minraw) {
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(256) void k_rep_utype(const KL kl, const uint64_t *
         const uint32_t t = corr[k];
         if (t == NONE32) continue;
         const uint64_t raw = (ukey[k] >> kl.sh_umi) & umi_mask, tgt = (ukey[t] >> kl.sh_umi) & umi_mask;
-        if (raw < tgt || corr[t] != NONE32) atomicMin(&minraw[t], (unsigned long long)((raw << 1) | (ukey[k] & 1ull)));
+        if (raw < tgt || corr[t] != NONE32) atomicMin(&minraw[t], (unsigned long long)((raw << 32) | k));
     }
 }
 
@@ -495,6 +504,53 @@ __global__ __launch_bounds__(256) void k_triplets(const KL kl, const uint64_t *_
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-read DupInfo (mark_dups.rs:61-72, BarcodeDupMarker::process :280-363)
+// ------------------------------------------------------------------------------------------------
+// representative read of a raw key = min (utype, qname) over its reads (mark_dups.rs:137-152): the run is
+// sorted by the utype bit (LSB of the key); among its leading same-bit elements take the smallest ordinal.
+__global__ __launch_bounds__(256) void k_rep_read(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                  const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+                                                  uint32_t *__restrict__ rep_read) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
+        const uint32_t b = upos[k], e = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
+        const uint64_t bit = keys[b] & 1ull;
+        uint32_t best = vals[b];
+        for (uint32_t i = b + 1; i < e && (keys[i] & 1ull) == bit; i++) best = vals[i] < best ? vals[i] : best;
+        rep_read[k] = best;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ vals,
+                                                  const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+                                                  const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc_all,
+                                                  const uint8_t *__restrict__ low,
+                                                  const unsigned long long *__restrict__ minraw,
+                                                  const uint32_t *__restrict__ rep_read, uint32_t *__restrict__ out_umi,
+                                                  uint32_t *__restrict__ out_cnt, uint8_t *__restrict__ out_flags) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
+        const uint32_t b = upos[k], e = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
+        const uint32_t K = corr[k] != NONE32 ? corr[k] : (uint32_t)k;  // the key this run's reads land on
+        const uint32_t endK = (uint64_t)K + 1 < nd ? upos[K + 1] : (uint32_t)n_keys;
+        const uint32_t cntK = endK - upos[K];
+        const uint32_t read_count = (corr[K] == NONE32 ? cntK : 0u) + inc_all[K];  // umigene_counts[corrected_key]
+        const uint32_t umi = (uint32_t)((ukey[K] >> kl.sh_umi) & lowmask(kl.bits_umi));
+        const unsigned long long mr = minraw[K];
+        const uint32_t rep_key = mr != ~0ull ? (uint32_t)(mr & 0xFFFFFFFFull) : K;  // umigene_min_key[corrected_key]
+        const uint32_t rep = rep_read[rep_key];
+        const uint8_t base = (uint8_t)(CRGPU_DUP_HAS | (corr[k] != NONE32 ? CRGPU_DUP_CORRECTED : 0) |
+                                       (low[K] ? CRGPU_DUP_LOW_SUPPORT : 0));
+        for (uint32_t i = b; i < e; i++) {
+            const uint32_t r = vals[i];
+            if (out_umi) out_umi[r] = umi;
+            if (out_cnt) out_cnt[r] = read_count;
+            if (out_flags) out_flags[r] = (uint8_t)(base | ((!low[K] && r == rep) ? CRGPU_DUP_UMI_COUNT : 0));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------------
 struct DevBuf {  // pooled temporary, returned to the context's pool at scope exit
@@ -514,7 +570,13 @@ static int read_u32(crgpu_ctx *ctx, const uint32_t *d, uint32_t *h) {
     return crgpu_memcpy_d2h(ctx, h, d, sizeof(uint32_t));
 }
 
-extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out) {
+struct PerRead {
+    uint32_t *d_vals = nullptr;  // read ordinal of every key (sorted along with the keys)
+    uint32_t *out_umi = nullptr, *out_cnt = nullptr;
+    uint8_t *out_flags = nullptr;
+};
+
+static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out, PerRead pr) {
     if (!ctx || !out) return CRGPU_EINVAL;
     *out = nullptr;
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_count_keys: call crgpu_set_key_layout first");
@@ -542,11 +604,14 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
     uint32_t *d_total = ctx->d_scalars + 16;   // device-side totals
 
     // 1. sort the keys
-    DevBuf tmp;
+    DevBuf tmp, vtmp;
     CR_TRY(dmalloc(ctx, tmp, n_keys * sizeof(uint64_t)));
+    if (pr.d_vals) CR_TRY(dmalloc(ctx, vtmp, n_keys * sizeof(uint32_t)));
     bool in_tmp = false;
-    CR_TRY(cr_radix_sort_u64(ctx, d_keys_inout, tmp.as<uint64_t>(), nullptr, nullptr, n_keys, 0, L.total_bits(), &in_tmp));
+    CR_TRY(cr_radix_sort_u64(ctx, d_keys_inout, tmp.as<uint64_t>(), pr.d_vals, pr.d_vals ? vtmp.as<uint32_t>() : nullptr, n_keys,
+                             0, L.total_bits(), &in_tmp));
     const uint64_t *keys = in_tmp ? tmp.as<uint64_t>() : d_keys_inout;
+    const uint32_t *vals = pr.d_vals ? (in_tmp ? vtmp.as<uint32_t>() : pr.d_vals) : nullptr;
 
     // 2. distinct (barcode, feature, library, UMI) keys and their run starts (DupBuilder::observe)
     DevBuf ukey_b, upos_b;
@@ -638,6 +703,19 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
     CR_TRY(read_u32(ctx, d_total, &nm32));
     const uint64_t nm = nm32;
 
+    // 5b. optional per-read DupInfo
+    if (vals) {
+        DevBuf rep_b;
+        CR_TRY(dmalloc(ctx, rep_b, nd * sizeof(uint32_t)));
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
+                           rep_b.as<uint32_t>());
+        hipLaunchKernelGGL(k_per_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys, corr,
+                           inc_all, low, minraw_b.as<unsigned long long>(), rep_b.as<uint32_t>(), pr.out_umi, pr.out_cnt,
+                           pr.out_flags);
+        CR_HIP(ctx, hipGetLastError());
+    }
+
     // 6. (barcode, feature) triplets = run lengths of the molecule keys at the feature boundary
     DevBuf tpos_b;
     CR_TRY(dmalloc(ctx, tpos_b, (nm + 1) * sizeof(uint32_t)));
@@ -669,6 +747,33 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
     guard.armed = false;
     *out = res;
     return CRGPU_OK;
+}
+
+extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out) {
+    return count_keys_impl(ctx, d_keys_inout, n_keys, out, PerRead());
+}
+
+extern "C" int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
+                                       uint32_t *d_processed_umi_out, uint32_t *d_read_count_out, uint8_t *d_dupflags_out) {
+    if (!ctx || !recs || !out) return CRGPU_EINVAL;
+    *out = nullptr;
+    CR_REQUIRE(ctx, recs->n < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_count_records: at most 2^32-2 records per call");
+    const uint64_t n = recs->n;
+    // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291)
+    if (d_processed_umi_out) CR_HIP(ctx, hipMemsetAsync(d_processed_umi_out, 0, n * sizeof(uint32_t), ctx->stream));
+    if (d_read_count_out) CR_HIP(ctx, hipMemsetAsync(d_read_count_out, 0, n * sizeof(uint32_t), ctx->stream));
+    if (d_dupflags_out) CR_HIP(ctx, hipMemsetAsync(d_dupflags_out, 0, n, ctx->stream));
+    DevBuf keys_b, vals_b;
+    CR_TRY(dmalloc(ctx, keys_b, n * sizeof(uint64_t)));
+    CR_TRY(dmalloc(ctx, vals_b, n * sizeof(uint32_t)));
+    uint64_t n_keys = 0;
+    CR_TRY(build_keys_impl(ctx, recs, keys_b.as<uint64_t>(), vals_b.as<uint32_t>(), &n_keys));
+    PerRead pr;
+    pr.d_vals = vals_b.as<uint32_t>();
+    pr.out_umi = d_processed_umi_out;
+    pr.out_cnt = d_read_count_out;
+    pr.out_flags = d_dupflags_out;
+    return count_keys_impl(ctx, keys_b.as<uint64_t>(), n_keys, out, pr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -395,6 +395,13 @@ class Context:
         self._check(self.L.crgpu_count_keys_dev(self.h, _p(d_keys), n_keys, C.byref(h)))
         return Counts(self, h)
 
+    def count_records(self, recs, d_processed_umi=None, d_read_count=None, d_dupflags=None):
+        """dedup from the records + per-read DupInfo (device output arrays, any may be None)"""
+        h = C.c_void_p()
+        self._check(self.L.crgpu_count_records_dev(self.h, C.byref(recs), C.byref(h), _p(d_processed_umi), _p(d_read_count),
+                                                   _p(d_dupflags)))
+        return Counts(self, h)
+
     def assemble_matrix(self, bc, feature, count, n_features):
         bc = np.ascontiguousarray(bc, np.uint32)
         ft = np.ascontiguousarray(feature, np.uint32)

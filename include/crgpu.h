@@ -207,6 +207,19 @@ int crgpu_balanced_bounds(crgpu_ctx *ctx, uint32_t n_ranks, uint32_t *bounds_out
  * molecule table (UmiCount, types.rs:152-160) sorted per barcode as align_and_count.rs:314 does. */
 typedef struct crgpu_counts crgpu_counts;
 int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out);
+/* Same dedup straight from the records, additionally filling the per-read DupInfo the unchanged Rust host
+ * needs for BAM tags (UB, duplicate flag, xf) and per-barcode metrics (mark_dups.rs:61-72,280-363;
+ * tx_annotation/src/read.rs:536-590).  Output arrays are device, n entries, any may be NULL:
+ *   processed_umi  2-bit corrected UMI (DupInfo::processed_umi)
+ *   read_count     umigene_counts[corrected key] (the UmiCount::read_count of the read's molecule)
+ *   dupflags       CRGPU_DUP_* bits; 0 for reads without DupInfo (invalid barcode / UMI, no feature).
+ * The record's position in the arrays is its qname rank (read headers must be unique, SURVEY 8a'). */
+#define CRGPU_DUP_HAS 0x01u          /* process() returned Some */
+#define CRGPU_DUP_CORRECTED 0x02u    /* DupInfo::is_corrected */
+#define CRGPU_DUP_LOW_SUPPORT 0x04u  /* DupInfo::is_low_support_umi */
+#define CRGPU_DUP_UMI_COUNT 0x08u    /* DupInfo::is_umi_count: the representative read of its molecule */
+int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
+                            uint32_t *d_processed_umi_out, uint32_t *d_read_count_out, uint8_t *d_dupflags_out);
 int crgpu_counts_info(crgpu_ctx *ctx, const crgpu_counts *c, uint64_t *n_triplets, uint64_t *n_molecules);
 /* device views (valid until crgpu_counts_free): bc rank u32[nt], feature u32[nt], count u32[nt] */
 int crgpu_counts_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t **d_bc, uint32_t **d_feature,

@@ -176,9 +176,19 @@ struct FeatureBarcodeCount {
 
 /// Result of DupBuilder::build: what BarcodeDupMarker::process + BcUmiInfo::feature_counts yield for all
 /// barcodes of the batch.
+/// DupInfo (mark_dups.rs:61-72): what BarcodeDupMarker::process returns for one read.
+struct DupInfo {
+    uint32_t processed_umi;  // 2-bit packed corrected UMI
+    uint32_t read_count;     // reads of the read's molecule (UmiCount::read_count)
+    bool is_corrected, is_low_support_umi, is_umi_count;
+};
+
 struct BarcodeDupMarker {
     std::vector<UmiCount> umi_counts;                 // sorted per barcode as align_and_count.rs:314
     std::vector<FeatureBarcodeCount> feature_counts;  // sorted by (barcode, feature)
+    /// process(read): one entry per observe() call, in call order (the order stands in for the qname
+    /// rank: observe reads in read-header order).  nullopt = process() returned None.
+    std::vector<std::optional<DupInfo>> dup_infos;
 };
 
 /// DupBuilder: observe() every annotated read of a batch (any number of barcodes / library types), then
@@ -219,14 +229,13 @@ class DupBuilder {
         if (n == 0) return out;
         Dev d_bc(ctx_, bc_.data(), n * 4), d_umi(ctx_, umi_.data(), n * 4), d_q(ctx_, qualn_.data(), n * umi_len_),
             d_f(ctx_, feature_.data(), n * 4), d_fl(ctx_, flags_.data(), n);
-        std::vector<uint64_t> zero(n, 0);
-        Dev d_keys(ctx_, zero.data(), n * 8);
+        std::vector<uint32_t> pu(n), rc32(n);
+        std::vector<uint8_t> df(n);
+        Dev d_pu(ctx_, pu.data(), n * 4), d_rc(ctx_, rc32.data(), n * 4), d_df(ctx_, df.data(), n);
         crgpu_records recs{n, umi_len_, (const uint32_t *)d_bc.p, (const uint32_t *)d_umi.p, (const uint8_t *)d_q.p,
                            (const uint32_t *)d_f.p, (const uint8_t *)d_fl.p};
-        uint64_t n_keys = 0;
-        ctx_.check(crgpu_build_keys_dev(ctx_.get(), &recs, (uint64_t *)d_keys.p, &n_keys));
         crgpu_counts *c = nullptr;
-        ctx_.check(crgpu_count_keys_dev(ctx_.get(), (uint64_t *)d_keys.p, n_keys, &c));
+        ctx_.check(crgpu_count_records_dev(ctx_.get(), &recs, &c, (uint32_t *)d_pu.p, (uint32_t *)d_rc.p, (uint8_t *)d_df.p));
         uint64_t nt = 0, nm = 0;
         ctx_.check(crgpu_counts_info(ctx_.get(), c, &nt, &nm));
         std::vector<uint32_t> tb(nt), tf(nt), tc(nt), mb(nm), mf(nm), mu(nm), mr(nm);
@@ -235,6 +244,14 @@ class DupBuilder {
         if (rc == CRGPU_OK) rc = crgpu_counts_molecules(ctx_.get(), c, mb.data(), ml.data(), mf.data(), mu.data(), mr.data(), mt.data());
         crgpu_counts_free(ctx_.get(), c);
         ctx_.check(rc);
+        ctx_.check(crgpu_memcpy_d2h(ctx_.get(), pu.data(), d_pu.p, n * 4));
+        ctx_.check(crgpu_memcpy_d2h(ctx_.get(), rc32.data(), d_rc.p, n * 4));
+        ctx_.check(crgpu_memcpy_d2h(ctx_.get(), df.data(), d_df.p, n));
+        out.dup_infos.resize(n);
+        for (uint64_t i = 0; i < n; i++)
+            if (df[i] & CRGPU_DUP_HAS)
+                out.dup_infos[i] = DupInfo{pu[i], rc32[i], (df[i] & CRGPU_DUP_CORRECTED) != 0, (df[i] & CRGPU_DUP_LOW_SUPPORT) != 0,
+                                           (df[i] & CRGPU_DUP_UMI_COUNT) != 0};
         for (uint64_t i = 0; i < nt; i++) out.feature_counts.push_back({tb[i], tf[i], tc[i]});
         for (uint64_t i = 0; i < nm; i++) out.umi_counts.push_back({mb[i], ml[i], mf[i], mu[i], mr[i], mt[i]});
         return out;

@@ -95,6 +95,18 @@ static void test_correct_umis_through_dup_builder() {
             CHECK(m.umi_counts[1].feature_idx == g1 && m.umi_counts[1].umi == 0b00011111u && m.umi_counts[1].read_count == 1);
         }
         CHECK(m.feature_counts.size() == 2 && m.feature_counts[0].umi_count == 1 && m.feature_counts[1].umi_count == 1);
+        // BarcodeDupMarker::process per read (mark_dups.rs:280-363), in observe() order
+        CHECK(m.dup_infos.size() == 7);
+        if (m.dup_infos.size() == 7) {
+            int n_rep = 0;
+            for (const auto &d : m.dup_infos) CHECK(d.has_value());
+            for (const auto &d : m.dup_infos) n_rep += d->is_umi_count;
+            CHECK(n_rep == 2);
+            CHECK(m.dup_infos[0]->is_umi_count && !m.dup_infos[0]->is_corrected && m.dup_infos[0]->read_count == 5);
+            CHECK(m.dup_infos[3]->is_corrected && m.dup_infos[3]->processed_umi == 0b00010000u && !m.dup_infos[3]->is_umi_count);
+            CHECK(m.dup_infos[5]->is_low_support_umi && !m.dup_infos[5]->is_umi_count);
+            CHECK(m.dup_infos[6]->is_umi_count && m.dup_infos[6]->read_count == 1 && !m.dup_infos[6]->is_low_support_umi);
+        }
     }
     {
         // {(CCAC,g0):1, (CGAC,g0):1}: equal counts -> the lexicographically larger UMI wins

@@ -25,7 +25,13 @@ def _run_gpu(c, r, n, w_cb_len, umi_len, n_features, n_libs=1, mux_mask=0):
     m2 = c.count(recs, n_features)
     for a in ("barcode_rank", "indptr", "indices", "data"):
         assert np.array_equal(getattr(m, a), getattr(m2, a))
-    return idx_b, (bc, ft, ct), mol, m
+    # per-read DupInfo entry point: same triplets, plus one record per read
+    d_pu, d_rc, d_fl = c.empty(max(n, 1), np.uint32), c.empty(max(n, 1), np.uint32), c.empty(max(n, 1), np.uint8)
+    counts3 = c.count_records(recs, d_pu, d_rc, d_fl)
+    for a, b in zip(counts3.triplets(), (bc, ft, ct)):
+        assert np.array_equal(a, b)
+    dup = dict(processed_umi=d_pu.to_host(count=n), read_count=d_rc.to_host(count=n), flags=d_fl.to_host(count=n))
+    return idx_b, (bc, ft, ct), mol, m, dup
 
 
 def _compare_with_oracle(c, w, r, n, n_features, n_libs=1, mux_mask=0, whitelists=None):
@@ -34,11 +40,22 @@ def _compare_with_oracle(c, w, r, n, n_features, n_libs=1, mux_mask=0, whitelist
     from cellranger_amd import engine as E
 
     _, canon_sorted = c.canon_order()
-    idx_b, trip, mol, m = _run_gpu(c, r, n, w.cb_len, w.umi_len, n_features, n_libs, mux_mask)
+    idx_b, trip, mol, m, dup = _run_gpu(c, r, n, w.cb_len, w.umi_len, n_features, n_libs, mux_mask)
     if whitelists is None:
         whitelists = [O.Whitelist(E.unpack_seqs(w.wl_packed, w.cb_len))] * n_libs
     res = O.run_pipeline(G.oracle_reads_from_packed(r, w.cb_len, w.umi_len), whitelists, n_lib=n_libs,
-                         multiplexing_lib_mask=mux_mask, n_threads=4)
+                         multiplexing_lib_mask=mux_mask, n_threads=4, want_dupinfo=True)
+    # per-read DupInfo (mark_dups.rs:61-72): every field of every read
+    od = res.dupinfo
+    has = od["has_dupinfo"] != 0
+    assert np.array_equal((dup["flags"] & 1) != 0, has)
+    assert np.array_equal((dup["flags"] & 2) != 0, od["is_corrected"] != 0)
+    assert np.array_equal((dup["flags"] & 4) != 0, od["is_low_support"] != 0)
+    assert np.array_equal((dup["flags"] & 8) != 0, od["is_umi_count"] != 0)
+    assert np.array_equal(dup["processed_umi"][has], od["processed_umi"][has])
+    assert np.array_equal(dup["read_count"][has], od["read_count"][has])
+    assert not dup["read_count"][~has].any() and not dup["processed_umi"][~has].any()
+    assert int(((dup["flags"] & 8) != 0).sum()) == len(mol["bc"])      # one representative read per molecule
     # columns, indptr, indices, data: the arrays write_matrix_h5 stores
     assert np.array_equal(m.barcodes_ascii(), res.barcodes)
     assert np.array_equal(m.indptr, res.indptr)
@@ -162,6 +179,7 @@ def test_empty_and_degenerate_inputs():
     recs = c.records(0, 12, None, None, None, None, None)
     m = c.count(recs, 5)
     assert m.n_barcodes == 0 and m.nnz == 0 and list(m.indptr) == [0]
+    assert c.count_records(recs, None, None, None).n_triplets == 0
     # reads whose barcodes are all invalid / features all NONE: columns exist only for seen barcodes
     n = 1000
     r = w.host_reads(0, n)
@@ -185,7 +203,7 @@ def test_mtx_text_matches_oracle(tmp_path):
     c = G.fresh_ctx()
     c.set_whitelist(0, w.wl_packed, length=16)
     r = w.host_reads(0, n)
-    _, _, _, m = _run_gpu(c, r, n, 16, 12, 30)
+    _, _, _, m, _ = _run_gpu(c, r, n, 16, 12, 30)
     meta = '%metadata_json: {"software_version": "cellranger-amd", "format_version": 2}'
     p_gpu, p_bc = tmp_path / "gpu.mtx", tmp_path / "barcodes.tsv"
     m.write_mtx(p_gpu, p_bc, metadata_line=meta, gem_group=1)
