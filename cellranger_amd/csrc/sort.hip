@@ -13,10 +13,12 @@
 #include "common.h"
 
 #define SORT_BLOCK 256
-#ifndef SORT_ITEMS
-#define SORT_ITEMS 16  // keys per thread per chunk
+#ifndef SORT_ITEMS_U64
+#define SORT_ITEMS_U64 16  // keys per thread per chunk, 64-bit keys
 #endif
-#define SORT_CHUNK (SORT_BLOCK * SORT_ITEMS)
+#ifndef SORT_ITEMS_U32
+#define SORT_ITEMS_U32 24  // 32-bit keys (+ payload): longer chunks keep the per-digit output runs >= 96 bytes
+#endif
 #define SORT_WAVES (SORT_BLOCK / 64)
 #define RADIX_BITS 8
 #define RADIX 256
@@ -65,38 +67,62 @@ int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_tota
 }
 
 // ---- digit extraction -------------------------------------------------------------------------
-// mode 0: (key >> shift) & mask           (radix pass)
-// mode 1: ((key >> shift) / width)         (owner rank of the barcode, crgpu_partition_keys_dev:
-//                                           contiguous barcode-rank ranges, like shardio's make_chunks)
-// mode 2: owner = index of the range [bounds[r], bounds[r+1]) that holds (key >> shift); `bounds` has
-//         width+1 ascending entries in device memory (histogram-balanced ranges)
-struct DigitFn {
-    uint32_t shift, mask, width, mode;
+// RadixDigit   (key >> shift) & mask              (radix pass)
+// OwnerDiv     (key >> shift) / width             (owner rank of the barcode, crgpu_partition_keys_dev:
+//                                                  contiguous barcode-rank ranges, like shardio's make_chunks)
+// OwnerBounds  index of the range [bounds[r], bounds[r+1]) that holds (key >> shift); `bounds` has
+//              width+1 ascending entries in device memory (histogram-balanced ranges)
+struct RadixDigit {
+    uint32_t shift, mask;
+    template <typename K>
+    __device__ __forceinline__ uint32_t operator()(K key) const {
+        return (uint32_t)(key >> shift) & mask;
+    }
+};
+struct OwnerDiv {
+    uint32_t shift, width;
+    template <typename K>
+    __device__ __forceinline__ uint32_t operator()(K key) const {
+        return (uint32_t)((uint64_t)key >> shift) / width;
+    }
+};
+struct OwnerBounds {
+    uint32_t shift, width;
     const uint32_t *bounds;
-    __device__ __forceinline__ uint32_t operator()(uint64_t key) const {
-        const uint64_t v = key >> shift;
-        if (mode == 0) return (uint32_t)(v & mask);
-        if (mode == 1) return (uint32_t)(v / width);
+    template <typename K>
+    __device__ __forceinline__ uint32_t operator()(K key) const {
+        const uint32_t v = (uint32_t)((uint64_t)key >> shift);
         uint32_t lo = 0, hi = width;  // first r with bounds[r+1] > v
         while (lo + 1 < hi) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (bounds[mid] <= (uint32_t)v) lo = mid; else hi = mid;
+            if (bounds[mid] <= v) lo = mid; else hi = mid;
         }
         return lo;
     }
 };
 
-// ---- pass 1: per-block digit histogram ------------------------------------------------------------
 template <typename K>
+struct SortCfg;
+template <>
+struct SortCfg<uint64_t> {
+    static constexpr int ITEMS = SORT_ITEMS_U64;
+};
+template <>
+struct SortCfg<uint32_t> {
+    static constexpr int ITEMS = SORT_ITEMS_U32;
+};
+
+// ---- pass 1: per-block digit histogram ------------------------------------------------------------
+template <typename K, typename DIG>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(const K *__restrict__ keys, uint64_t n, uint64_t tile,
-                                                           DigitFn dig, uint32_t *__restrict__ block_hist,
+                                                           DIG dig, uint32_t *__restrict__ block_hist,
                                                            uint32_t n_blocks) {
     __shared__ uint32_t h[RADIX];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) atomicAdd(&h[dig((uint64_t)keys[i])], 1u);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) atomicAdd(&h[dig(keys[i])], 1u);
     __syncthreads();
     block_hist[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
@@ -119,26 +145,58 @@ __global__ __launch_bounds__(256) void k_scan_digits(uint32_t *__restrict__ bloc
 }
 
 // ---- pass 3: stable scatter ------------------------------------------------------------------------
-// Order inside a chunk: wave-major, then item, then lane, so a wave owns 64*SORT_ITEMS consecutive
-// keys.  The chunk is first ranked by digit inside LDS (ballot multisplit: rank of a key = same-digit
-// keys of earlier waves + of this wave's earlier items + of lower lanes), then copied out so that
-// neighbouring threads write neighbouring addresses: the global stores are contiguous runs per digit
-// (a direct scatter issues ~56 separate 8-byte stores per wave instruction).
-template <typename K, bool HAS_VALS>
+// Order inside a chunk: wave-major, then item, then lane, so a wave owns 64*ITEMS consecutive keys.
+// The chunk is first ranked by digit inside LDS (ballot multisplit: rank of a key = same-digit keys of
+// earlier waves + of this wave's earlier items + of lower lanes), then copied out so that neighbouring
+// threads write neighbouring addresses: the global stores are contiguous runs per digit (a direct
+// scatter issues ~56 separate 8-byte stores per wave instruction).
+//
+// The ranking loop is the ALU-heavy part (the kernel is issue-bound, not HBM-bound, when written
+// naively), so it is kept lean: per digit bit one v_bfe_i32 + one ballot + xnor/and on the two mask
+// halves, ranks from v_mbcnt, and the per-(wave, digit) running count is a plain LDS read by every lane
+// followed by a write from the lowest lane of each digit group (a wave runs in lockstep and its LDS
+// operations complete in order, so no atomic or cross-lane shuffle is needed).
+template <bool FULL>
+__device__ __forceinline__ uint32_t rank_in_wave(uint32_t d, bool ok, uint32_t *__restrict__ wc /* [RADIX] of this wave */) {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+    if (!FULL) {
+        const unsigned long long live = __ballot(ok);
+        lo = (uint32_t)live;
+        hi = (uint32_t)(live >> 32);
+    }
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; b++) {
+        const int32_t nb = (int32_t)(d << (31 - b)) >> 31;  // 0 or -1 (v_bfe_i32)
+        const unsigned long long bal = __ballot(nb != 0);
+        lo &= ~((uint32_t)bal ^ (uint32_t)nb);          // lanes whose bit b equals mine
+        hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)nb);
+    }
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    const uint32_t cnt = (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+    uint32_t prev = 0;
+    if (FULL || ok) {
+        prev = wc[d];
+        if (below == 0) wc[d] = prev + cnt;
+    }
+    return prev + below;
+}
+
+template <typename K, bool HAS_VALS, typename DIG>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
                                                               uint32_t *__restrict__ vals_out, uint64_t n, uint64_t tile,
-                                                              DigitFn dig, const uint32_t *__restrict__ block_offs,
+                                                              DIG dig, const uint32_t *__restrict__ block_offs,
                                                               const uint32_t *__restrict__ digit_totals,
                                                               uint32_t n_blocks) {
-    __shared__ K skeys[SORT_CHUNK];
-    __shared__ uint32_t svals[HAS_VALS ? SORT_CHUNK : 1];
+    constexpr int ITEMS = SortCfg<K>::ITEMS;
+    constexpr uint32_t CHUNK = SORT_BLOCK * ITEMS;
+    __shared__ K skeys[CHUNK];
+    __shared__ uint32_t svals[HAS_VALS ? CHUNK : 1];
     __shared__ uint32_t wcount[SORT_WAVES][RADIX];  // per-wave same-digit counts -> LDS position of (wave, digit)
     __shared__ uint32_t base[RADIX];                // running global offset of each digit for this block
     __shared__ uint32_t gdelta[RADIX];              // global position = LDS position + gdelta[digit]
     __shared__ uint32_t lds[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     {
         const uint32_t digit_base = block_excl_scan_256(digit_totals[tid], lds, nullptr);
@@ -147,41 +205,42 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
 
-    for (uint64_t chunk = lo; chunk < hi; chunk += SORT_CHUNK) {
+    for (uint64_t chunk = lo; chunk < hi; chunk += CHUNK) {
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; w++) wcount[w][tid] = 0;
         __syncthreads();
 
-        K key[SORT_ITEMS];
-        uint32_t val[SORT_ITEMS];
-        uint32_t dr[SORT_ITEMS];  // (digit << 16) | rank inside (wave, digit); rank < 1024
-        const uint64_t wave_base = chunk + (uint64_t)wave * (64 * SORT_ITEMS);
+        K key[ITEMS];
+        uint32_t val[ITEMS];
+        uint32_t dr[ITEMS];  // (digit << 16) | rank inside (wave, digit); rank < 64 * ITEMS
+        const uint32_t chunk_n = hi - chunk < CHUNK ? (uint32_t)(hi - chunk) : CHUNK;
+        const uint32_t wave_off = wave * (64 * ITEMS) + lane;  // chunk-local index of item 0
+        const K *kin = keys_in + chunk + wave_off;
+        const uint32_t *vin = HAS_VALS ? vals_in + chunk + wave_off : nullptr;
+        if (chunk_n == CHUNK) {
 #pragma unroll
-        for (int it = 0; it < SORT_ITEMS; it++) {
-            const uint64_t i = wave_base + (uint64_t)it * 64 + lane;
-            const bool ok = i < hi;
-            key[it] = ok ? keys_in[i] : (K)0;
-            if (HAS_VALS) val[it] = ok ? vals_in[i] : 0u;
-        }
-#pragma unroll
-        for (int it = 0; it < SORT_ITEMS; it++) {
-            const uint64_t i = wave_base + (uint64_t)it * 64 + lane;
-            const bool ok = i < hi;
-            const uint32_t d = ok ? dig((uint64_t)key[it]) : 0u;
-            // lanes holding the same digit: intersect the 8 bit ballots
-            unsigned long long peers = __ballot(ok);
-#pragma unroll
-            for (int b = 0; b < RADIX_BITS; b++) {
-                const unsigned long long bal = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            for (int it = 0; it < ITEMS; it++) {
+                key[it] = kin[it * 64];
+                if (HAS_VALS) val[it] = vin[it * 64];
             }
-            uint32_t prev = 0;
-            if (ok) {
-                const int leader = __ffsll((long long)peers) - 1;
-                if ((int)lane == leader) prev = atomicAdd(&wcount[wave][d], (uint32_t)__popcll(peers));
-                prev = __shfl(prev, leader);
+#pragma unroll
+            for (int it = 0; it < ITEMS; it++) {
+                const uint32_t d = dig(key[it]);
+                dr[it] = (d << 16) | rank_in_wave<true>(d, true, wcount[wave]);
             }
-            dr[it] = (d << 16) | (prev + (uint32_t)__popcll(peers & lt_mask));
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITEMS; it++) {
+                const bool ok = wave_off + it * 64 < chunk_n;
+                key[it] = ok ? kin[it * 64] : (K)0;
+                if (HAS_VALS) val[it] = ok ? vin[it * 64] : 0u;
+            }
+#pragma unroll
+            for (int it = 0; it < ITEMS; it++) {
+                const bool ok = wave_off + it * 64 < chunk_n;
+                const uint32_t d = ok ? dig(key[it]) : 0u;
+                dr[it] = (d << 16) | rank_in_wave<false>(d, ok, wcount[wave]);
+            }
         }
         __syncthreads();
         // one thread per digit: chunk-local start of the digit (exclusive scan over digits), per-wave
@@ -205,19 +264,17 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < SORT_ITEMS; it++) {
-            const uint64_t i = wave_base + (uint64_t)it * 64 + lane;
-            if (i < hi) {
+        for (int it = 0; it < ITEMS; it++) {
+            if (chunk_n == CHUNK || wave_off + it * 64 < chunk_n) {
                 const uint32_t p = wcount[wave][dr[it] >> 16] + (dr[it] & 0xFFFFu);
                 skeys[p] = key[it];
                 if (HAS_VALS) svals[p] = val[it];
             }
         }
         __syncthreads();
-        const uint32_t chunk_n = hi - chunk < SORT_CHUNK ? (uint32_t)(hi - chunk) : SORT_CHUNK;
         for (uint32_t p = tid; p < chunk_n; p += SORT_BLOCK) {
             const K k = skeys[p];
-            const uint32_t pos = p + gdelta[dig((uint64_t)k)];
+            const uint32_t pos = p + gdelta[dig(k)];
             keys_out[pos] = k;
             if (HAS_VALS) vals_out[pos] = svals[p];
         }
@@ -225,12 +282,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
     }
 }
 
+template <typename K>
 static uint32_t sort_blocks(uint64_t n, uint64_t *tile_out) {
-    uint64_t nb = (n + SORT_CHUNK * 4 - 1) / (SORT_CHUNK * 4);
+    const uint64_t chunk = (uint64_t)SORT_BLOCK * SortCfg<K>::ITEMS;
+    uint64_t nb = (n + chunk * 4 - 1) / (chunk * 4);
     if (nb < 1) nb = 1;
     if (nb > SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
     uint64_t tile = (n + nb - 1) / nb;
-    tile = (tile + SORT_CHUNK - 1) / SORT_CHUNK * SORT_CHUNK;
+    tile = (tile + chunk - 1) / chunk * chunk;
     nb = (n + tile - 1) / tile;
     if (nb < 1) nb = 1;
     *tile_out = tile;
@@ -240,16 +299,16 @@ static uint32_t sort_blocks(uint64_t n, uint64_t *tile_out) {
 static uint32_t *digit_totals_buf(crgpu_ctx *ctx) { return ctx->d_scalars + 256; }  // 256 u32 inside the scalar page
 
 // one counting-sort pass keyed by `dig` (stable).
-template <typename K>
+template <typename K, typename DIG>
 static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d_vin, uint32_t *d_vout, uint64_t n,
-                      DigitFn dig) {
+                      DIG dig) {
     uint64_t tile;
-    const uint32_t nb = sort_blocks(n, &tile);
+    const uint32_t nb = sort_blocks<K>(n, &tile);
     uint32_t *d_hist = ctx->d_sort_hist;
     uint32_t *d_tot = digit_totals_buf(ctx);
     {
         CrTimer t(ctx, CRGPU_T_SORT_HIST, n);
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
+        hipLaunchKernelGGL((k_radix_hist<K, DIG>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
     }
     {
         CrTimer t(ctx, CRGPU_T_SCAN);
@@ -257,11 +316,11 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
     }
     CrTimer t(ctx, CRGPU_T_SORT, n);
     if (d_vin)
-        hipLaunchKernelGGL((k_radix_scatter<K, true>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout,
-                           n, tile, dig, d_hist, d_tot, nb);
+        hipLaunchKernelGGL((k_radix_scatter<K, true, DIG>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin,
+                           d_vout, n, tile, dig, d_hist, d_tot, nb);
     else
-        hipLaunchKernelGGL((k_radix_scatter<K, false>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin, d_vout,
-                           n, tile, dig, d_hist, d_tot, nb);
+        hipLaunchKernelGGL((k_radix_scatter<K, false, DIG>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin,
+                           d_vout, n, tile, dig, d_hist, d_tot, nb);
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
 }
@@ -276,8 +335,8 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
     uint32_t *vin = d_vals, *vout = d_vals_tmp;
     for (uint32_t shift = lo_bit; shift < hi_bit; shift += RADIX_BITS) {
         const uint32_t bits = hi_bit - shift < RADIX_BITS ? hi_bit - shift : RADIX_BITS;
-        DigitFn dig{shift, (1u << bits) - 1u, 1u, 0u, nullptr};
-        CR_TRY(radix_pass<K>(ctx, in, out, vin, vout, n, dig));
+        RadixDigit dig{shift, (1u << bits) - 1u};
+        CR_TRY((radix_pass<K, RadixDigit>(ctx, in, out, vin, vout, n, dig)));
         K *t = in;
         in = out;
         out = t;
@@ -308,10 +367,8 @@ int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
     CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "partition: at most 2^32-2 keys per call");
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = 0;
     if (n == 0) return CRGPU_OK;
-    // rank r owns canonical barcode ranks [r*width, (r+1)*width), or [bounds[r], bounds[r+1]) when given
-    const uint32_t width = (ctx->n_canon + n_ranks - 1) / n_ranks;
-    DigitFn dig{sh_bc, 0u, width ? width : 1u, 1u, nullptr};
     if (bounds) {
+        // rank r owns canonical barcode ranks [bounds[r], bounds[r+1])
         CR_REQUIRE(ctx, bounds[0] == 0 && bounds[n_ranks] >= ctx->n_canon, CRGPU_EINVAL,
                    "partition: bounds must start at 0 and end at or beyond the whitelist size");
         for (uint32_t r = 0; r < n_ranks; r++)
@@ -319,9 +376,12 @@ int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
         uint32_t *d_bounds = ctx->d_scalars + 760;  // 257 u32 inside the 1024-word scalar page
         CR_HIP(ctx, hipMemcpyAsync(d_bounds, bounds, (n_ranks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's array may be a temporary
-        dig = DigitFn{sh_bc, 0u, n_ranks, 2u, d_bounds};
+        CR_TRY((radix_pass<uint64_t, OwnerBounds>(ctx, d_in, d_out, nullptr, nullptr, n, OwnerBounds{sh_bc, n_ranks, d_bounds})));
+    } else {
+        // rank r owns canonical barcode ranks [r*width, (r+1)*width)
+        const uint32_t width = (ctx->n_canon + n_ranks - 1) / n_ranks;
+        CR_TRY((radix_pass<uint64_t, OwnerDiv>(ctx, d_in, d_out, nullptr, nullptr, n, OwnerDiv{sh_bc, width ? width : 1u})));
     }
-    CR_TRY(radix_pass<uint64_t>(ctx, d_in, d_out, nullptr, nullptr, n, dig));
     uint32_t totals[RADIX];
     CR_TRY(crgpu_memcpy_d2h(ctx, totals, digit_totals_buf(ctx), sizeof(totals)));
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = totals[r];
