@@ -422,42 +422,155 @@ __device__ __forceinline__ uint32_t group_hash(uint64_t g) {
     return (uint32_t)g;
 }
 
+// ---- candidate filter ---------------------------------------------------------------------------
+// Only a (barcode, library, UMI) group with at least two member keys (the UMI seen under two features)
+// can hold low-support keys, and such groups are rare (a few per cent of the keys).  Sorting every key by
+// group just to find them cost more than the whole UMI correction, so a filter runs first: the distinct
+// keys are sorted by barcode, so a workgroup takes a range of WHOLE barcodes (the barcodes whose first key
+// lies in its tile of LF_TILE keys), hashes each key's group into a two-bit-per-entry LDS table ("seen",
+// "seen again") and marks as candidates the keys whose entry was hit twice: every member of a multi-member
+// group is marked (no false negatives); false positives are removed by the exact comparison later.
+#define LF_TILE 8192u
+#define LF_ENTRY_BITS 18u               // 2^18 two-bit entries = 64 KB of LDS, two workgroups per CU
+#define LF_WORDS (1u << (LF_ENTRY_BITS - 4u))
+__device__ __forceinline__ uint64_t mix64(uint64_t g) {
+    g ^= g >> 33;
+    g *= 0xff51afd7ed558ccdull;
+    g ^= g >> 33;
+    g *= 0xc4ceb9fe1a85ec53ull;
+    g ^= g >> 33;
+    return g;
+}
+#define LF_THREADS 1024u  // a workgroup may own one giant barcode: many threads + batched loads keep that pole short
+#define LF_BATCH 4
+__global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
+                                                                 uint8_t *__restrict__ cand) {
+    __shared__ uint32_t bm[LF_WORDS];
+    __shared__ uint32_t s_first;
+    __shared__ unsigned long long s_end;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_tiles = (nd + LF_TILE - 1) / LF_TILE;
+    const uint32_t emask = (1u << LF_ENTRY_BITS) - 1u;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * LF_TILE;
+        const uint64_t t1 = t0 + LF_TILE < nd ? t0 + LF_TILE : nd;
+        if (tid == 0) s_first = 0xFFFFFFFFu;
+        for (uint32_t w = tid; w < LF_WORDS; w += LF_THREADS) bm[w] = 0u;
+        __syncthreads();
+        // first barcode head of the tile
+        {
+            uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t j = 0; j < LF_TILE / LF_THREADS; j++) {
+                const uint64_t p = t0 + j * LF_THREADS + tid;
+                if (p < t1 && mine == 0xFFFFFFFFu && (p == 0 || (ukey[p] >> kl.sh_bc) != (ukey[p - 1] >> kl.sh_bc)))
+                    mine = (uint32_t)(p - t0);
+            }
+            if (mine != 0xFFFFFFFFu) atomicMin(&s_first, mine);
+        }
+        __syncthreads();
+        const uint32_t first = s_first;
+        if (tid == 0) {
+            // first barcode head at or after the end of the tile: galloping + binary search on the barcode field
+            uint64_t b = nd;
+            if (first != 0xFFFFFFFFu && t1 < nd) {
+                const uint64_t bcv = ukey[t1 - 1] >> kl.sh_bc;
+                uint64_t lo = t1 - 1, step = 1;  // ukey[lo] has barcode bcv
+                while (lo + step < nd && (ukey[lo + step] >> kl.sh_bc) == bcv) {
+                    lo += step;
+                    step <<= 1;
+                }
+                uint64_t hi = lo + step < nd ? lo + step : nd;  // ukey[hi] differs (or hi == nd)
+                while (lo + 1 < hi) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if ((ukey[mid] >> kl.sh_bc) == bcv) lo = mid; else hi = mid;
+                }
+                b = hi;
+            }
+            s_end = b;
+        }
+        __syncthreads();
+        if (first == 0xFFFFFFFFu) continue;  // the whole tile is inside a barcode an earlier tile owns (uniform)
+        const uint64_t a = t0 + first, b = s_end;
+        for (uint64_t k0 = a + tid; k0 < b; k0 += (uint64_t)LF_THREADS * LF_BATCH) {
+            uint64_t key[LF_BATCH];
+#pragma unroll
+            for (int j = 0; j < LF_BATCH; j++) {
+                const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
+                key[j] = k < b ? ukey[k] : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < LF_BATCH; j++) {
+                if (k0 + (uint64_t)j * LF_THREADS >= b) break;
+                const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
+                const uint32_t sh = (e & 15u) * 2u;
+                const uint32_t old = atomicOr(&bm[e >> 4], 1u << sh);
+                if ((old >> sh) & 1u) atomicOr(&bm[e >> 4], 2u << sh);
+            }
+        }
+        __syncthreads();
+        for (uint64_t k0 = a + tid; k0 < b; k0 += (uint64_t)LF_THREADS * LF_BATCH) {
+            uint64_t key[LF_BATCH];
+#pragma unroll
+            for (int j = 0; j < LF_BATCH; j++) {
+                const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
+                key[j] = k < b ? ukey[k] : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < LF_BATCH; j++) {
+                const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
+                if (k >= b) break;
+                const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
+                cand[k] = (uint8_t)((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u);
+            }
+        }
+        __syncthreads();
+    }
+}
+struct CandFlag {
+    const uint8_t *cand;
+    __device__ __forceinline__ bool operator()(uint64_t k) const { return cand[k] != 0; }
+};
+struct EmitIdx {
+    uint32_t *out;
+    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o) const { out[o] = (uint32_t)k; }
+};
+
 // val = (extra hash bits << vbits) | index: the bits of the u32 payload the index does not need carry more
 // hash bits, so that most false collisions of the 32-bit sort key are rejected without touching ukey.
-__global__ __launch_bounds__(256) void k_group_hashes(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
+__global__ __launch_bounds__(256) void k_group_hashes(const KL kl, const uint64_t *__restrict__ ukey,
+                                                      const uint32_t *__restrict__ cand_idx, uint64_t n_cand,
                                                       uint32_t vbits, uint32_t *__restrict__ hash,
                                                       uint32_t *__restrict__ val) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
-        uint64_t g = group_id(kl, ukey[k]);
-        g ^= g >> 33;
-        g *= 0xff51afd7ed558ccdull;
-        g ^= g >> 33;
-        g *= 0xc4ceb9fe1a85ec53ull;
-        g ^= g >> 33;
-        hash[k] = (uint32_t)g;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_cand; j += stride) {
+        const uint32_t k = cand_idx[j];
+        // the high half of the mix: independent of the low bits the candidate filter consumed
+        const uint64_t g = mix64(group_id(kl, ukey[k]) ^ 0x9E3779B97F4A7C15ull);
+        hash[j] = (uint32_t)g;
         const uint32_t extra = vbits >= 32u ? 0u : ((uint32_t)(g >> 32) << vbits);
-        val[k] = extra | (uint32_t)k;
+        val[j] = extra | k;
     }
 }
 
 __global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint32_t *__restrict__ hash,
-                                                     const uint32_t *__restrict__ val, uint64_t nd, uint32_t vbits,
+                                                     const uint32_t *__restrict__ val, uint64_t n_cand, uint64_t nd,
+                                                     uint32_t vbits,
                                                      const uint64_t *__restrict__ ukey,
                                                      const uint32_t *__restrict__ upos, uint64_t n_keys,
                                                      const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc1,
                                                      uint8_t *__restrict__ low) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nd; j += stride) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_cand; j += stride) {
         const uint32_t h = hash[j];
         // almost every run of equal hashes is a singleton: a single (umi, feature) key is its own
         // strict maximum and never low support
         const bool same_prev = j > 0 && hash[j - 1] == h;
-        const bool same_next = j + 1 < nd && hash[j + 1] == h;
+        const bool same_next = j + 1 < n_cand && hash[j + 1] == h;
         if (!same_prev && !same_next) continue;
         uint64_t s = j, e = j + 1;
         while (s > 0 && hash[s - 1] == h) s--;
-        while (e < nd && hash[e] == h) e++;
+        while (e < n_cand && hash[e] == h) e++;
         const uint32_t vmask = vbits >= 32u ? 0xFFFFFFFFu : ((1u << vbits) - 1u);
         const uint32_t my_val = val[j];
         // cheap filter on the extra hash bits before any gather
@@ -643,48 +756,71 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CR_HIP(ctx, hipMemsetAsync(low, 0, nd, ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(minraw_b.p, 0xFF, nd * sizeof(unsigned long long), ctx->stream));
         const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
+        DevBuf heads_b;  // per tile: first / last segment head
+        CR_TRY(dmalloc(ctx, heads_b, 2 * n_tiles * sizeof(uint32_t)));
+        uint32_t *tile_first = heads_b.as<uint32_t>(), *tile_last = tile_first + n_tiles;
         hipLaunchKernelGGL(k_correct_umis_tiled, dim3(cr_grid(n_tiles, 1, 256u * 4u)), dim3(256), 0, ctx->stream, kl, ukey,
-                           upos, nd, n_keys, corr, inc1, inc_all);
+                           upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all);
         if (n_tiles > 1) {
-            const size_t edge_lds = (2 * UE_CAP + UE_BUCKETS * 8) * sizeof(uint32_t);
+            const size_t lds_small = (2 * UES_CAP + UES_BUCKETS * 8) * sizeof(uint32_t);
+            const size_t lds_large = (2 * UE_CAP + UE_BUCKETS * 8) * sizeof(uint32_t);
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void *)k_correct_umis_edges, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)edge_lds);
+                (void)hipFuncSetAttribute((const void *)k_correct_umis_edges<false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large);
                 attr_set = true;
             }
-            hipLaunchKernelGGL(k_correct_umis_edges, dim3(cr_grid(n_tiles - 1, 1, 256u * 2u)), dim3(UE_THREADS), edge_lds,
-                               ctx->stream, kl, ukey, upos, nd, n_keys, corr, inc1, inc_all);
+            hipLaunchKernelGGL(k_correct_umis_edges<true>, dim3(cr_grid(n_tiles - 1, 1, 256u * 6u)), dim3(UES_THREADS),
+                               lds_small, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all);
+            hipLaunchKernelGGL(k_correct_umis_edges<false>, dim3(cr_grid(n_tiles - 1, 1, 256u * 2u)), dim3(UE_THREADS),
+                               lds_large, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all);
         }
         hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd, corr,
                            minraw_b.as<unsigned long long>());
         CR_HIP(ctx, hipGetLastError());
     }
 
-    // 4. low support: group the distinct keys by (barcode, library, UMI) through a 32-bit hash sort
+    // 4. low support: candidate keys (UMI seen under several features of a barcode) -> grouped by
+    //    (barcode, library, UMI) through a 32-bit hash sort -> exact comparison of the phase-1 counts
     {
-        const uint32_t vbits = cr_ceil_log2(nd ? nd : 1);  // bits the distinct-key index needs inside the payload
-        DevBuf h_b, ht_b, v_b, vt_b;
-        CR_TRY(dmalloc(ctx, h_b, nd * sizeof(uint32_t)));
-        CR_TRY(dmalloc(ctx, ht_b, nd * sizeof(uint32_t)));
-        CR_TRY(dmalloc(ctx, v_b, nd * sizeof(uint32_t)));
-        CR_TRY(dmalloc(ctx, vt_b, nd * sizeof(uint32_t)));
+        DevBuf cand_b, cidx_b;
+        CR_TRY(dmalloc(ctx, cand_b, nd));
+        CR_TRY(dmalloc(ctx, cidx_b, nd * sizeof(uint32_t)));
+        uint32_t n_cand32 = 0;
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
-            hipLaunchKernelGGL(k_group_hashes, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd, vbits,
-                               h_b.as<uint32_t>(), v_b.as<uint32_t>());
+            const uint64_t n_ftiles = (nd + LF_TILE - 1) / LF_TILE;
+            hipLaunchKernelGGL(k_group_candidates, dim3(cr_grid(n_ftiles, 1, 256u * 2u)), dim3(LF_THREADS), 0, ctx->stream, kl, ukey,
+                               nd, cand_b.as<uint8_t>());
             CR_HIP(ctx, hipGetLastError());
+            CR_TRY(compact(ctx, CandFlag{cand_b.as<uint8_t>()}, EmitIdx{cidx_b.as<uint32_t>()}, nd, d_block, d_total));
         }
-        bool s_in_tmp = false;
-        CR_TRY(cr_radix_sort_u32(ctx, h_b.as<uint32_t>(), ht_b.as<uint32_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(), nd, 0,
-                                 32, &s_in_tmp));
-        {
-            CrTimer t(ctx, CRGPU_T_DEDUP);
-            hipLaunchKernelGGL(k_low_support, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl,
-                               s_in_tmp ? ht_b.as<uint32_t>() : h_b.as<uint32_t>(),
-                               s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), nd, vbits, ukey, upos, n_keys, corr, inc1,
-                               low);
-            CR_HIP(ctx, hipGetLastError());
+        CR_TRY(read_u32(ctx, d_total, &n_cand32));
+        const uint64_t n_cand = n_cand32;
+        if (n_cand >= 2) {
+            const uint32_t vbits = cr_ceil_log2(nd ? nd : 1);  // bits the distinct-key index needs inside the payload
+            DevBuf h_b, ht_b, v_b, vt_b;
+            CR_TRY(dmalloc(ctx, h_b, n_cand * sizeof(uint32_t)));
+            CR_TRY(dmalloc(ctx, ht_b, n_cand * sizeof(uint32_t)));
+            CR_TRY(dmalloc(ctx, v_b, n_cand * sizeof(uint32_t)));
+            CR_TRY(dmalloc(ctx, vt_b, n_cand * sizeof(uint32_t)));
+            {
+                CrTimer t(ctx, CRGPU_T_DEDUP);
+                hipLaunchKernelGGL(k_group_hashes, dim3(cr_grid(n_cand, 256)), dim3(256), 0, ctx->stream, kl, ukey,
+                                   cidx_b.as<uint32_t>(), n_cand, vbits, h_b.as<uint32_t>(), v_b.as<uint32_t>());
+                CR_HIP(ctx, hipGetLastError());
+            }
+            bool s_in_tmp = false;
+            CR_TRY(cr_radix_sort_u32(ctx, h_b.as<uint32_t>(), ht_b.as<uint32_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(), n_cand,
+                                     0, 32, &s_in_tmp));
+            {
+                CrTimer t(ctx, CRGPU_T_DEDUP);
+                hipLaunchKernelGGL(k_low_support, dim3(cr_grid(n_cand, 256)), dim3(256), 0, ctx->stream, kl,
+                                   s_in_tmp ? ht_b.as<uint32_t>() : h_b.as<uint32_t>(),
+                                   s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), n_cand, nd, vbits, ukey, upos, n_keys,
+                                   corr, inc1, low);
+                CR_HIP(ctx, hipGetLastError());
+            }
         }
     }
 

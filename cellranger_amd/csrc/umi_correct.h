@@ -20,9 +20,14 @@
 //      and derives every key's segment bounds from per-64-key ballots of the segment-head flags.  Segments
 //      completely inside the tile are finished here: <= UC_SMALL members by all pairs, longer ones by the
 //      pigeonhole search.  Keys of segments that cross a tile edge are left to
+//      The kernel also records, per tile, the position of its first and last segment head.
 //  k_correct_umis_edges  one workgroup per tile boundary that falls strictly inside a segment (the first
-//      such boundary owns the segment).  Segments up to UE_CAP keys are staged in LDS whole; larger ones
-//      are processed in chunks of UE_CAP table entries against which every key of the segment is probed.
+//      such boundary owns the segment); the segment's bounds come straight from the per-tile head
+//      positions, no search.  Two instantiations share the work by segment size: up to UES_CAP keys
+//      (256 threads, 24 KB of LDS, six workgroups per CU -- nearly all edge segments are this small and the
+//      kernel is latency bound, so residency is what counts) and above (512 threads, 96 KB).  Segments up
+//      to UE_CAP keys are staged in LDS whole; larger ones are processed in chunks of UE_CAP table entries
+//      against which every key of the segment is probed.
 #pragma once
 
 #define UC_ITEMS 8
@@ -37,8 +42,24 @@
 
 #define UE_THREADS 512
 #define UE_CAP 4096u      // table entries of one edge-segment chunk held in LDS
-#define UE_BUCKETS 2048u  // load <= 0.25
+#define UE_BUCKETS 1024u  // load <= 0.5: 64 KB of LDS in all, two workgroups per CU
 #define UE_POSBITS 12u
+#define UES_THREADS 256
+#define UES_CAP 1024u     // the small-segment instantiation
+#define UES_BUCKETS 512u
+#define UES_POSBITS 10u
+#define UC_NOHEAD 0xFFFFFFFFu
+
+template <bool SMALL>
+struct EdgeCfg;
+template <>
+struct EdgeCfg<true> {
+    static constexpr uint32_t THREADS = UES_THREADS, CAP = UES_CAP, BUCKETS = UES_BUCKETS, POSBITS = UES_POSBITS;
+};
+template <>
+struct EdgeCfg<false> {
+    static constexpr uint32_t THREADS = UE_THREADS, CAP = UE_CAP, BUCKETS = UE_BUCKETS, POSBITS = UE_POSBITS;
+};
 
 __device__ __forceinline__ bool hd1(uint32_t a, uint32_t b) {
     const uint32_t x = a ^ b;
@@ -149,7 +170,8 @@ __device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, co
 
 __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const uint64_t *__restrict__ ukey,
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
-                                                            uint64_t n_keys, uint32_t *__restrict__ corr,
+                                                            uint64_t n_keys, uint32_t *__restrict__ tile_first,
+                                                            uint32_t *__restrict__ tile_last, uint32_t *__restrict__ corr,
                                                             uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all) {
     __shared__ uint32_t s_umi[UC_TILE];
     __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
@@ -210,6 +232,18 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
                 if (m) ce = b * 64 + (__ffsll((long long)m) - 1);
             }
             s_carry_end[tid] = ce;
+        } else if (tid == 64) {
+            // first / last segment head of the tile (positions < tn) for k_correct_umis_edges
+            uint32_t first = UC_NOHEAD, last = UC_NOHEAD;
+            for (uint32_t b = 0; b < UC_BLOCKS && b * 64u < tn; b++) {
+                unsigned long long m = s_heads[b];
+                if (tn - b * 64u < 64u) m &= (1ull << (tn - b * 64u)) - 1ull;  // drop the padding head at tn
+                if (!m) continue;
+                if (first == UC_NOHEAD) first = b * 64u + (uint32_t)(__ffsll((long long)m) - 1);
+                last = b * 64u + 63u - (uint32_t)__clzll((long long)m);
+            }
+            tile_first[tile] = first;
+            tile_last[tile] = last;
         }
         __syncthreads();
         // ---- segment bounds of every key; members of long in-tile segments enter the hash set ----
@@ -266,60 +300,67 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
 }
 
 // Segments that contain a tile boundary strictly inside.  Boundary t (position t*UC_TILE) owns the
-// segment when the previous boundary is not inside the same segment.
-__global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, const uint64_t *__restrict__ ukey,
-                                                                   const uint32_t *__restrict__ upos, uint64_t nd,
-                                                                   uint64_t n_keys, uint32_t *__restrict__ corr,
-                                                                   uint32_t *__restrict__ inc1,
-                                                                   uint32_t *__restrict__ inc_all) {
+// segment when the previous boundary is not inside the same segment, i.e. when tile t-1 holds a head.
+template <bool SMALL>
+__global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
+    const KL kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+    const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_last, uint32_t *__restrict__ corr,
+    uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all) {
+    constexpr uint32_t UE_T = EdgeCfg<SMALL>::THREADS, CAP = EdgeCfg<SMALL>::CAP, BUCKETS = EdgeCfg<SMALL>::BUCKETS,
+                       POSBITS = EdgeCfg<SMALL>::POSBITS;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *s_umi = smem;                // UE_CAP
-    uint32_t *s_cnt = smem + UE_CAP;       // UE_CAP
-    uint32_t *s_hash = smem + 2 * UE_CAP;  // UE_BUCKETS * 8 slots (16-byte aligned: UE_CAP is a multiple of 4)
-    __shared__ unsigned long long s_bounds[2];
+    uint32_t *s_umi = smem;             // CAP
+    uint32_t *s_cnt = smem + CAP;       // CAP
+    uint32_t *s_hash = smem + 2 * CAP;  // BUCKETS * 8 slots (16-byte aligned: CAP is a multiple of 4)
     const uint32_t tid = threadIdx.x;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
     const UmiSplit sp = umi_split(kl.umi_len);
     const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
     for (uint64_t t = (uint64_t)blockIdx.x + 1; t < n_tiles; t += gridDim.x) {
-        const uint64_t x = t * UC_TILE;
-        const uint64_t pre = ukey[x] >> kl.sh_lib;
-        if ((ukey[x - 1] >> kl.sh_lib) != pre) continue;  // the boundary is a segment head: nothing crosses it
-        if (tid == 0) {
-            uint64_t s, e;
-            segment_bounds(ukey, nd, x, kl.sh_lib, s, e);
-            s_bounds[0] = s;
-            s_bounds[1] = e;
+        // every thread reads the same few words: the branches below are uniform across the workgroup
+        const uint32_t tf = tile_first[t];
+        if (tf == 0u) continue;  // the boundary is a segment head: nothing crosses it
+        const uint32_t tl = tile_last[t - 1];
+        if (tl == UC_NOHEAD) continue;  // the previous boundary is inside the same segment and owns it
+        const uint64_t s = (t - 1) * UC_TILE + tl;
+        uint64_t e = nd;
+        if (tf != UC_NOHEAD) {
+            e = t * UC_TILE + tf;
+        } else {
+            for (uint64_t u = t + 1; u < n_tiles; u++) {
+                const uint32_t f = tile_first[u];
+                if (f != UC_NOHEAD) {
+                    e = u * UC_TILE + f;
+                    break;
+                }
+            }
         }
-        __syncthreads();
-        const uint64_t s = s_bounds[0], e = s_bounds[1];
-        __syncthreads();
-        if (x - UC_TILE > s) continue;  // the previous boundary is inside the same segment and owns it
         const uint64_t m = e - s;
-        const uint32_t lib = (uint32_t)(pre & lowmask(kl.bits_lib));
+        if (SMALL ? m > UES_CAP : m <= UES_CAP) continue;  // the other instantiation's segment
+        const uint32_t lib = (uint32_t)((ukey[s] >> kl.sh_lib) & lowmask(kl.bits_lib));
         if ((kl.mux_mask >> lib) & 1u) {  // UmiCorrection::Disable (aligner.rs:315-318)
-            for (uint64_t k = s + tid; k < e; k += UE_THREADS) corr[k] = NONE32;
+            for (uint64_t k = s + tid; k < e; k += UE_T) corr[k] = NONE32;
             continue;
         }
-        if (m <= UE_CAP) {
+        if (m <= CAP) {
             const uint32_t mm = (uint32_t)m;
             const bool use_hash = mm > UC_SMALL;
             if (use_hash)
-                for (uint32_t h = tid; h < UE_BUCKETS * 8; h += UE_THREADS) s_hash[h] = UC_EMPTY;
-            for (uint32_t p = tid; p < mm; p += UE_THREADS) {
+                for (uint32_t h = tid; h < BUCKETS * 8; h += UE_T) s_hash[h] = UC_EMPTY;
+            for (uint32_t p = tid; p < mm; p += UE_T) {
                 const uint64_t k = s + p;
                 s_umi[p] = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
                 s_cnt[p] = run_count(upos, nd, n_keys, k);
             }
             __syncthreads();
             if (use_hash) {
-                for (uint32_t p = tid; p < mm; p += UE_THREADS)
-                    uc_insert<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, s_umi[p] & sp.lo_mask, p);
+                for (uint32_t p = tid; p < mm; p += UE_T)
+                    uc_insert<BUCKETS, POSBITS>(s_hash, 0u, s_umi[p] & sp.lo_mask, p);
                 __syncthreads();
             }
-            for (uint32_t p = tid; p < mm; p += UE_THREADS) {
+            for (uint32_t p = tid; p < mm; p += UE_T) {
                 const uint32_t my_cnt = s_cnt[p];
-                const uint32_t bp = best_neighbour_lds<UE_BUCKETS, UE_POSBITS>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p,
+                const uint32_t bp = best_neighbour_lds<BUCKETS, POSBITS>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p,
                                                                               s_umi[p], my_cnt, sp);
                 const uint32_t target = bp != p ? (uint32_t)(s + bp) : NONE32;
                 corr[s + p] = target;
@@ -333,7 +374,7 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
         }
         // ---- larger than the LDS budget -----------------------------------------------------------------
         // (1) same-high-half neighbours: the run around each key in the sorted global array
-        for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
+        for (uint64_t k = s + tid; k < e; k += UE_T) {
             const uint32_t my_umi = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
             const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
             Best best{run_count(upos, nd, n_keys, k), my_umi, 0u};
@@ -366,19 +407,19 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
             corr[k] = best_k != k ? (uint32_t)best_k : NONE32;  // provisional; refined below
         }
         __syncthreads();
-        // (2) same-low-half neighbours: chunks of UE_CAP table entries, every key of the segment probes each
-        for (uint64_t c0 = s; c0 < e; c0 += UE_CAP) {
-            const uint32_t cn = e - c0 < UE_CAP ? (uint32_t)(e - c0) : UE_CAP;
-            for (uint32_t h = tid; h < UE_BUCKETS * 8; h += UE_THREADS) s_hash[h] = UC_EMPTY;
-            for (uint32_t p = tid; p < cn; p += UE_THREADS) {
+        // (2) same-low-half neighbours: chunks of CAP table entries, every key of the segment probes each
+        for (uint64_t c0 = s; c0 < e; c0 += CAP) {
+            const uint32_t cn = e - c0 < CAP ? (uint32_t)(e - c0) : CAP;
+            for (uint32_t h = tid; h < BUCKETS * 8; h += UE_T) s_hash[h] = UC_EMPTY;
+            for (uint32_t p = tid; p < cn; p += UE_T) {
                 s_umi[p] = (uint32_t)((ukey[c0 + p] >> kl.sh_umi) & umi_mask);
                 s_cnt[p] = run_count(upos, nd, n_keys, c0 + p);
             }
             __syncthreads();
-            for (uint32_t p = tid; p < cn; p += UE_THREADS)
-                uc_insert<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, s_umi[p] & sp.lo_mask, p);
+            for (uint32_t p = tid; p < cn; p += UE_T)
+                uc_insert<BUCKETS, POSBITS>(s_hash, 0u, s_umi[p] & sp.lo_mask, p);
             __syncthreads();
-            for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
+            for (uint64_t k = s + tid; k < e; k += UE_T) {
                 const uint32_t my_umi = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
                 const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
                 // current best of this key (own key, or the provisional target found so far)
@@ -391,7 +432,7 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
                     best.cnt = run_count(upos, nd, n_keys, cur);
                     best.umi = (uint32_t)((ukey[cur] >> kl.sh_umi) & umi_mask);
                 }
-                uc_for_each<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, my_lo, [&](uint32_t q) {
+                uc_for_each<BUCKETS, POSBITS>(s_hash, 0u, my_lo, [&](uint32_t q) {
                     const uint32_t u = s_umi[q];
                     if ((u & sp.lo_mask) != my_lo) return;
                     if (hd1(u >> sp.lo_bits, my_hi)) best.offer(s_cnt[q], u, q);
@@ -401,7 +442,7 @@ __global__ __launch_bounds__(UE_THREADS) void k_correct_umis_edges(const KL kl, 
             __syncthreads();
         }
         // the moves of this segment's corrected keys
-        for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
+        for (uint64_t k = s + tid; k < e; k += UE_T) {
             const uint32_t target = corr[k];
             if (target != NONE32) {
                 atomicAdd(&inc1[target], 1u);

@@ -151,19 +151,20 @@ def test_adversarial_dense_umis_chains_ties_multilib():
 
 
 def test_large_segments_use_binary_search_path():
-    """One barcode, one feature, thousands of distinct UMIs: the > SMALL_SEG path of correct_umis."""
+    """One barcode, one feature, thousands of distinct UMIs: segments that cross tile edges at every size class of
+    k_correct_umis_edges (<= 1024 keys, <= 4096 keys staged whole, larger ones chunked)."""
     import gpu_helpers as G
     from cellranger_amd import synth as S
 
-    n = 150_000
-    w = S.Workload(n_total=n, seed=21, n_wl=100, n_cells=3, n_ambient=0, n_genes=2, umi_len=8, umi_err=0.02,
-                   cb_err=0.0, n_rate=0.0, no_feature_frac=0.0, reads_per_umi=3, sigma=0.1)
-    c = G.fresh_ctx()
-    c.set_whitelist(0, w.wl_packed, length=16)
-    r = w.host_reads(0, n)
-    res, m = _compare_with_oracle(c, w, r, n, 2)
-    assert m.data.max() > 2000
-    c.close()
+    for n, min_mol in ((150_000, 2000), (30_000, 800), (9_000, 200)):
+        w = S.Workload(n_total=n, seed=21, n_wl=100, n_cells=3, n_ambient=0, n_genes=2, umi_len=8, umi_err=0.02,
+                       cb_err=0.0, n_rate=0.0, no_feature_frac=0.0, reads_per_umi=3, sigma=0.1)
+        c = G.fresh_ctx()
+        c.set_whitelist(0, w.wl_packed, length=16)
+        r = w.host_reads(0, n)
+        res, m = _compare_with_oracle(c, w, r, n, 2)
+        assert m.data.max() > min_mol
+        c.close()
 
 
 def test_empty_and_degenerate_inputs():
