@@ -46,7 +46,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3"])
     ap.add_argument("--reads-per-gpu", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=8_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=24_000_000,
+                    help="reads of the CPU-baseline sample (about 10-30 s of oracle work on the box's cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 

@@ -8,6 +8,8 @@
 // Integer / f64 work, HBM- and cache-latency bound: no MFMA.  Built with -ffp-contract=off so the
 // f64 multiply and the running sum are never fused (the reference's rustc flags have no +fma,
 // lib/rust/.cargo/config.toml:5-8).
+#include <cstdlib>
+
 #include "common.h"
 #include "block_utils.h"
 #include "wl_view.h"
@@ -140,6 +142,8 @@ static bool uniform_lib0(const crgpu_ctx *ctx) {
 #define MB_TILE (256 * MB_ITEMS)
 #define MB_MAX_BUCKETS 1024
 #define MB_BPT (MB_MAX_BUCKETS / 256)  // buckets per thread in the tile scan
+#define MB_LKB 8                       // reads whose lookups advance together
+#define MB_CURSOR_STRIDE 32u            // one 128-byte line per bucket cursor: atomics on one line serialise in one L2 channel
 
 struct BinPlan {
     uint32_t lib_slot[CRGPU_MAX_LIB];  // library id -> slot (0xFFFFFFFF = not configured)
@@ -148,7 +152,8 @@ struct BinPlan {
     uint64_t cap;  // staging entries per bucket
 };
 
-template <bool UNIFORM>
+// FROM_IDX: the ranks were already written to idx_out by k_lookup_hot; only the histogram staging runs.
+template <bool UNIFORM, bool FROM_IDX = false>
 __global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const BinPlan plan,
                                                       const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
                                                       uint64_t n, uint32_t *__restrict__ idx_out,
@@ -167,6 +172,83 @@ __global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const 
         __syncthreads();
         uint32_t bv[MB_ITEMS];    // (bucket << 16) | value, 0xFFFFFFFF = no hit
         uint16_t loff[MB_ITEMS];  // arrival order inside (tile, bucket)
+        if constexpr (FROM_IDX) {
+#pragma unroll
+            for (int j = 0; j < MB_ITEMS; j++) {
+                const uint64_t i = tile * MB_TILE + (uint64_t)j * 256 + tid;
+                const uint32_t rank = i < n ? idx_out[i] : CRGPU_MISS;
+                bv[j] = 0xFFFFFFFFu;
+                loff[j] = 0;
+                if (rank != CRGPU_MISS) {
+                    const uint32_t b = rank >> BIN_SHIFT;
+                    loff[j] = (uint16_t)atomicAdd(&bcnt[b], 1u);
+                    bv[j] = (b << 16) | (rank & (BIN_SIZE - 1u));
+                }
+            }
+        } else if constexpr (UNIFORM) {
+            // One library: the lookups of MB_LKB reads advance together, phase by phase (keys -> index bins ->
+            // bin contents), so that the loads of a phase are all in flight at once.  With one read at a
+            // time behind its own branches the kernel was a serial chain of 3 memory latencies per read.
+            const WlView &w = vs.v[0];
+            const uint32_t *__restrict__ tw = reinterpret_cast<const uint32_t *>(w.tailA);
+            const uint32_t tail_mask = (1u << w.bitsB) - 1u;
+#pragma unroll
+            for (int j0 = 0; j0 < MB_ITEMS; j0 += MB_LKB) {
+                uint32_t key[MB_LKB], lo[MB_LKB], hi[MB_LKB];
+                U32x4 d[MB_LKB];
+                bool live[MB_LKB];
+#pragma unroll
+                for (int jj = 0; jj < MB_LKB; jj++) {
+                    const uint64_t i = tile * MB_TILE + (uint64_t)(j0 + jj) * 256 + tid;
+                    const bool ok = i < n;
+                    key[jj] = ok ? cb[i] : 0u;
+                    const uint32_t f = (ok && flags) ? flags[i] : 0u;
+                    live[jj] = ok && !(f & CRGPU_FLAG_CB_HAS_N) && (f & CRGPU_FLAG_LIB_MASK) == 0u;
+                }
+#pragma unroll
+                for (int jj = 0; jj < MB_LKB; jj++) {
+                    // both bounds of the bin in one 8-byte load
+                    const uint32_t bin = (uint32_t)((uint64_t)key[jj] >> w.shiftE);
+                    const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offE + bin);
+                    lo[jj] = b2.a;
+                    hi[jj] = b2.b;
+                }
+#pragma unroll
+                for (int jj = 0; jj < MB_LKB; jj++) {
+                    // the first 8 entries of the bin in one 16-byte load (the tables are padded by 32 bytes)
+                    d[jj] = *reinterpret_cast<const U32x4 *>(tw + (lo[jj] >> 1));
+                }
+#pragma unroll
+                for (int jj = 0; jj < MB_LKB; jj++) {
+                    const int j = j0 + jj;
+                    const uint64_t i = tile * MB_TILE + (uint64_t)j * 256 + tid;
+                    const uint32_t tail = key[jj] & tail_mask;
+                    const uint32_t p0 = lo[jj] & ~1u;
+                    uint32_t found = CRGPU_MISS;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t pos = p0 + k;
+                        const uint32_t t = (d[jj].w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                        if (pos >= lo[jj] && pos < hi[jj] && t == tail) found = pos;
+                    }
+                    if (hi[jj] > p0 + 8u && found == CRGPU_MISS && live[jj]) {  // a bin of more than 7 keys: rare
+                        scan_u16_range<4>(w.tailA, p0 + 8u, hi[jj], [&](uint32_t t, uint32_t pos) {
+                            if (t == tail) found = pos;
+                        });
+                    }
+                    uint32_t rank = CRGPU_MISS;
+                    if (live[jj] && found != CRGPU_MISS) rank = w.valA ? w.valA[found] : found;
+                    bv[j] = 0xFFFFFFFFu;
+                    loff[j] = 0;
+                    if (i < n) idx_out[i] = rank;
+                    if (rank != CRGPU_MISS) {
+                        const uint32_t b = rank >> BIN_SHIFT;
+                        loff[j] = (uint16_t)atomicAdd(&bcnt[b], 1u);
+                        bv[j] = (b << 16) | (rank & (BIN_SIZE - 1u));
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < MB_ITEMS; j++) {
             const uint64_t i = tile * MB_TILE + (uint64_t)j * 256 + tid;
@@ -177,20 +259,15 @@ __global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const 
                 const uint32_t f = flags ? flags[i] : 0u;
                 const uint32_t lib = f & CRGPU_FLAG_LIB_MASK;
                 uint32_t rank = CRGPU_MISS;
-                if (!(f & CRGPU_FLAG_CB_HAS_N)) {
-                    if (UNIFORM) {
-                        if (lib == 0) rank = wl_lookup(vs.v[0], key);
-                    } else {
-                        if (vs.v[lib].n) rank = wl_lookup(vs.v[lib], key);
-                    }
-                }
+                if (!(f & CRGPU_FLAG_CB_HAS_N) && vs.v[lib].n) rank = wl_lookup(vs.v[lib], key);
                 idx_out[i] = rank;
                 if (rank != CRGPU_MISS) {
-                    const uint32_t b = (UNIFORM ? 0u : plan.lib_slot[lib] * plan.buckets_per_lib) + (rank >> BIN_SHIFT);
+                    const uint32_t b = plan.lib_slot[lib] * plan.buckets_per_lib + (rank >> BIN_SHIFT);
                     loff[j] = (uint16_t)atomicAdd(&bcnt[b], 1u);
                     bv[j] = (b << 16) | (rank & (BIN_SIZE - 1u));
                 }
             }
+        }
         }
         __syncthreads();
         // exclusive scan of the tile's bucket counts (MB_BPT consecutive buckets per thread) and one
@@ -212,7 +289,7 @@ __global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const 
                 if (b < NB) {
                     bstart[b] = run;
                     run += c[k];
-                    bcnt[b] = c[k] ? atomicAdd(&cursor[b], c[k]) : 0u;
+                    bcnt[b] = c[k] ? atomicAdd(&cursor[b * MB_CURSOR_STRIDE], c[k]) : 0u;
                 }
             }
         }
@@ -236,12 +313,161 @@ __global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const 
     }
 }
 
+// ---- K1 with a hot-barcode table in LDS -------------------------------------------------------------
+// k_match_binned is bound by the vector L1: two cache-line misses per read (index bin, bin contents) keep
+// every CU's miss queue full (TCP_PENDING_STALL ~75 % of the cycles) while the ALUs idle.  Single-cell
+// reads are anything but uniform over the whitelist, though: a few thousand cell barcodes carry ~90 % of
+// them.  After a first small batch the HOT_CAP most frequent barcodes (by the valid histogram so far) go
+// into an open-addressing table that every workgroup keeps in LDS (128 KB); a read is looked up there
+// first and only the rest goes to the global tables.  Purely a cache: the result of every lookup is the
+// same rank either way.
+#define HOT_SLOTS 16384u   // 8192 buckets of two 8-byte entries (rank << 32 | key)
+#define HOT_BUCKETS (HOT_SLOTS / 2u)
+#define HOT_CAP 8192u      // load factor <= 0.5
+#define HOT_EMPTY 0xFFFFFFFFFFFFFFFFull
+// An entry lives in its home bucket or the next one (four slots); a barcode that finds all four taken is
+// simply not cached.  The lookup is therefore two 16-byte LDS reads and four compares, no loop.
+__device__ __forceinline__ uint32_t hot_hash(uint32_t key) { return (key * 0x9E3779B1u) >> 19; }  // 13 bits
+__device__ __forceinline__ uint32_t hot_probe(const unsigned long long *s_hot, uint32_t key) {
+    const uint32_t b0 = hot_hash(key), b1 = (b0 + 1u) & (HOT_BUCKETS - 1u);
+    const uint4 x = *reinterpret_cast<const uint4 *>(s_hot + 2u * b0);
+    const uint4 y = *reinterpret_cast<const uint4 *>(s_hot + 2u * b1);
+    // an empty slot reads as key 0xFFFFFFFF with rank 0xFFFFFFFF == CRGPU_MISS: taking the minimum keeps a real rank
+    uint32_t r = CRGPU_MISS;
+    r = x.x == key && x.y < r ? x.y : r;
+    r = x.z == key && x.w < r ? x.w : r;
+    r = y.x == key && y.y < r ? y.y : r;
+    r = y.z == key && y.w < r ? y.w : r;
+    return r;
+}
+// monotone bucketing of a count >= 1 into 256 classes (8 per octave)
+__device__ __forceinline__ uint32_t hot_class(uint32_t c) {
+    const uint32_t e = 31u - (uint32_t)__clz((int)c);
+    const uint32_t m = e >= 3u ? (c >> (e - 3u)) & 7u : (c << (3u - e)) & 7u;
+    return e * 8u + m;
+}
+__global__ __launch_bounds__(256) void k_hot_hist(const uint32_t *__restrict__ valid, uint32_t n, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
+        const uint32_t c = valid[r];
+        if (c) atomicAdd(&h[hot_class(c)], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ valid, const uint32_t *__restrict__ keys,
+                                                   uint32_t n, const uint32_t *__restrict__ hist,
+                                                   unsigned long long *__restrict__ image) {
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t s_min;
+    h[threadIdx.x] = hist[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // lowest class such that it and all higher classes together hold at most HOT_CAP barcodes
+        uint32_t acc = 0, b = 256;
+        while (b > 0 && acc + h[b - 1] <= HOT_CAP) {
+            acc += h[b - 1];
+            b--;
+        }
+        s_min = b;
+    }
+    __syncthreads();
+    const uint32_t cmin = s_min;
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
+        const uint32_t c = valid[r];
+        if (!c || hot_class(c) < cmin) continue;
+        const uint32_t key = keys[r];
+        const unsigned long long e = ((unsigned long long)r << 32) | key;
+        const uint32_t b0 = hot_hash(key), b1 = (b0 + 1u) & (HOT_BUCKETS - 1u);
+        const uint32_t slots[4] = {2u * b0, 2u * b0 + 1u, 2u * b1, 2u * b1 + 1u};
+        for (int k = 0; k < 4; k++)
+            if (atomicCAS(&image[slots[k]], HOT_EMPTY, e) == HOT_EMPTY) break;
+    }
+}
+
+// The lookups proper: no barrier inside the loop, every thread keeps LH_ITEMS reads in flight, 16 waves per
+// CU.  (A single kernel that also staged the histogram had to stop all 16 waves of the one workgroup a CU
+// can hold -- the table takes 128 KB -- at five barriers per tile and was latency bound.)
+#define LH_THREADS 1024
+#define LH_ITEMS 8
+__global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
+                                                           const unsigned long long *__restrict__ hot_image,
+                                                           const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
+                                                           uint64_t n, uint32_t *__restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_hot[];  // HOT_SLOTS
+    const uint32_t tid = threadIdx.x;
+    const WlView &w = vs.v[0];
+    const uint32_t *__restrict__ tw = reinterpret_cast<const uint32_t *>(w.tailA);
+    const uint32_t tail_mask = (1u << w.bitsB) - 1u;
+    for (uint32_t s = tid; s < HOT_SLOTS; s += LH_THREADS) s_hot[s] = hot_image[s];
+    __syncthreads();
+    const uint64_t chunk = (uint64_t)LH_THREADS * LH_ITEMS;
+    for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
+        uint32_t key[LH_ITEMS], rank[LH_ITEMS], lo[LH_ITEMS], hi[LH_ITEMS];
+        bool todo[LH_ITEMS];  // live read that the LDS table did not answer
+#pragma unroll
+        for (int j = 0; j < LH_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * LH_THREADS + tid;
+            const bool ok = i < n;
+            key[j] = ok ? cb[i] : 0u;
+            const uint32_t f = (ok && flags) ? flags[i] : 0u;
+            todo[j] = ok && !(f & CRGPU_FLAG_CB_HAS_N) && (f & CRGPU_FLAG_LIB_MASK) == 0u;
+            rank[j] = CRGPU_MISS;
+        }
+#pragma unroll
+        for (int j = 0; j < LH_ITEMS; j++) {
+            const uint32_t r = hot_probe(s_hot, key[j]);
+            if (todo[j] && r != CRGPU_MISS) {
+                rank[j] = r;
+                todo[j] = false;
+            }
+        }
+        // the rest: index bin, then the first 8 entries of the bin, for all items before any compare
+        U32x4 d[LH_ITEMS];
+#pragma unroll
+        for (int j = 0; j < LH_ITEMS; j++) {
+            lo[j] = hi[j] = 0u;
+            if (todo[j]) {
+                const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offE + (uint32_t)((uint64_t)key[j] >> w.shiftE));
+                lo[j] = b2.a;
+                hi[j] = b2.b;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LH_ITEMS; j++)
+            if (todo[j] && hi[j] > lo[j]) d[j] = *reinterpret_cast<const U32x4 *>(tw + (lo[j] >> 1));
+#pragma unroll
+        for (int j = 0; j < LH_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * LH_THREADS + tid;
+            if (todo[j] && hi[j] > lo[j]) {
+                const uint32_t tail = key[j] & tail_mask;
+                const uint32_t p0 = lo[j] & ~1u;
+                uint32_t found = CRGPU_MISS;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t pos = p0 + k;
+                    const uint32_t t = (d[j].w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                    if (pos >= lo[j] && pos < hi[j] && t == tail) found = pos;
+                }
+                if (hi[j] > p0 + 8u && found == CRGPU_MISS)  // a bin of more than 7 keys: rare
+                    scan_u16_range<4>(w.tailA, p0 + 8u, hi[j], [&](uint32_t t, uint32_t pos) {
+                        if (t == tail) found = pos;
+                    });
+                rank[j] = found;  // valA == nullptr on this path: sorted position == rank
+            }
+            if (i < n) idx_out[i] = rank[j];
+        }
+    }
+}
+
 __global__ __launch_bounds__(512) void k_hist_buckets(const WlViewSet vs, const BinPlan plan, uint32_t slices,
                                                       const uint16_t *__restrict__ stage,
                                                       const uint32_t *__restrict__ cursor) {
     extern __shared__ uint32_t cnt[];  // BIN_SIZE counters
     const uint32_t b = blockIdx.x / slices, s = blockIdx.x % slices;
-    const uint32_t total = cursor[b];
+    const uint32_t total = cursor[b * MB_CURSOR_STRIDE];
     // slice boundaries in units of 8 entries (16-byte loads); the last slice takes the ragged tail
     const uint32_t groups = (total + 7u) / 8u;
     const uint32_t g_lo = (uint32_t)((uint64_t)groups * s / slices), g_hi = (uint32_t)((uint64_t)groups * (s + 1) / slices);
@@ -311,7 +537,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     uint16_t *d_stage = nullptr;
     uint32_t *d_cursor = nullptr;
     CR_TRY(cr_pool_alloc(ctx, (void **)&d_stage, (uint64_t)plan.n_buckets * plan.cap * sizeof(uint16_t)));
-    int rc = cr_pool_alloc(ctx, (void **)&d_cursor, plan.n_buckets * sizeof(uint32_t));
+    int rc = cr_pool_alloc(ctx, (void **)&d_cursor, plan.n_buckets * MB_CURSOR_STRIDE * sizeof(uint32_t));
     if (rc != CRGPU_OK) {
         cr_pool_free(ctx, d_stage);
         return rc;
@@ -324,21 +550,65 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
         (void)hipFuncSetAttribute((const void *)k_hist_buckets, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SIZE * 4);
         attr_set = true;
     }
+    // hot-barcode table: one library without translation, and enough reads to pay for the sampling batch
+    // (CRGPU_HOT_MIN_READS lowers the threshold so that the parity tests can drive this path with small inputs)
+    uint64_t hot_min = 16ull << 20;
+    if (const char *env = getenv("CRGPU_HOT_MIN_READS")) hot_min = strtoull(env, nullptr, 10);
+    const bool use_hot = uniform && ctx->wl[0].d_valA == nullptr && n >= hot_min && n >= 4ull * MB_TILE &&
+                         ctx->d_canon_keys != nullptr;
+    uint64_t first = 0;  // reads of the sampling batch (a multiple of MB_TILE)
+    if (use_hot) {
+        first = n / 4 < (4ull << 20) ? n / 4 : (4ull << 20);
+        first = first / MB_TILE * MB_TILE;
+    }
+    const size_t hot_lds = HOT_SLOTS * sizeof(unsigned long long);
+    if (use_hot && !ctx->d_hot_image) {
+        if (hipMalloc((void **)&ctx->d_hot_image, hot_lds + 256 * sizeof(uint32_t)) != hipSuccess) {
+            cr_pool_free(ctx, d_stage);
+            cr_pool_free(ctx, d_cursor);
+            return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc hot table failed");
+        }
+        (void)hipFuncSetAttribute((const void *)k_lookup_hot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds);
+    }
     hipError_t e = hipSuccess;
-    for (uint64_t off = 0; off < n && e == hipSuccess; off += sb) {
-        const uint64_t m = n - off < sb ? n - off : sb;
-        CrTimer t(ctx, CRGPU_T_MATCH, m);
-        e = hipMemsetAsync(d_cursor, 0, plan.n_buckets * sizeof(uint32_t), ctx->stream);
-        const dim3 grid(cr_grid((m + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)), block(256);
-        if (uniform)
-            hipLaunchKernelGGL(k_match_binned<true>, grid, block, 0, ctx->stream, vs, plan, d_cb + off,
-                               d_flags ? d_flags + off : nullptr, m, d_idx_out + off, d_stage, d_cursor);
-        else
-            hipLaunchKernelGGL(k_match_binned<false>, grid, block, 0, ctx->stream, vs, plan, d_cb + off,
-                               d_flags ? d_flags + off : nullptr, m, d_idx_out + off, d_stage, d_cursor);
-        hipLaunchKernelGGL(k_hist_buckets, dim3(plan.n_buckets * slices), dim3(512), BIN_SIZE * 4, ctx->stream, vs, plan, slices,
-                           d_stage, d_cursor);
-        if (e == hipSuccess) e = hipGetLastError();
+    bool hot_ready = false;
+    for (uint64_t off = 0; off < n && e == hipSuccess;) {
+        uint64_t m = n - off < sb ? n - off : sb;
+        if (use_hot && off == 0 && m > first) m = first;
+        {
+            CrTimer t(ctx, CRGPU_T_MATCH, m);
+            e = hipMemsetAsync(d_cursor, 0, plan.n_buckets * MB_CURSOR_STRIDE * sizeof(uint32_t), ctx->stream);
+            if (hot_ready) {
+                hipLaunchKernelGGL(k_lookup_hot, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), hot_lds,
+                                   ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
+                                   d_idx_out + off);
+                hipLaunchKernelGGL((k_match_binned<true, true>), dim3(cr_grid((m + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)),
+                                   dim3(256), 0, ctx->stream, vs, plan, d_cb + off, d_flags ? d_flags + off : nullptr, m,
+                                   d_idx_out + off, d_stage, d_cursor);
+            } else {
+                const dim3 grid(cr_grid((m + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)), block(256);
+                if (uniform)
+                    hipLaunchKernelGGL(k_match_binned<true>, grid, block, 0, ctx->stream, vs, plan, d_cb + off,
+                                       d_flags ? d_flags + off : nullptr, m, d_idx_out + off, d_stage, d_cursor);
+                else
+                    hipLaunchKernelGGL(k_match_binned<false>, grid, block, 0, ctx->stream, vs, plan, d_cb + off,
+                                       d_flags ? d_flags + off : nullptr, m, d_idx_out + off, d_stage, d_cursor);
+            }
+            hipLaunchKernelGGL(k_hist_buckets, dim3(plan.n_buckets * slices), dim3(512), BIN_SIZE * 4, ctx->stream, vs, plan,
+                               slices, d_stage, d_cursor);
+            if (use_hot && off == 0) {
+                // the most frequent barcodes so far -> table image (the histogram includes earlier batches of the caller)
+                uint32_t *d_hh = reinterpret_cast<uint32_t *>(ctx->d_hot_image + HOT_SLOTS);
+                if (e == hipSuccess) e = hipMemsetAsync(ctx->d_hot_image, 0xFF, hot_lds, ctx->stream);
+                if (e == hipSuccess) e = hipMemsetAsync(d_hh, 0, 256 * sizeof(uint32_t), ctx->stream);
+                hipLaunchKernelGGL(k_hot_hist, dim3(128), dim3(256), 0, ctx->stream, ctx->wl[0].d_valid, ctx->n_canon, d_hh);
+                hipLaunchKernelGGL(k_hot_build, dim3(128), dim3(256), 0, ctx->stream, ctx->wl[0].d_valid, ctx->d_canon_keys,
+                                   ctx->n_canon, d_hh, ctx->d_hot_image);
+                hot_ready = true;
+            }
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+        off += m;
     }
     cr_pool_free(ctx, d_stage);
     cr_pool_free(ctx, d_cursor);

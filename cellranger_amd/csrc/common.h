@@ -83,6 +83,8 @@ struct crgpu_ctx {
 
     WlTables wl[CRGPU_MAX_LIB];
     FeaturePattern pat[CRGPU_MAX_LIB];
+    uint32_t *d_canon_keys = nullptr;         // n_canon packed canonical barcodes, ascending (rank -> sequence)
+    unsigned long long *d_hot_image = nullptr;  // K1's hot-barcode table (HOT_SLOTS entries) + 256 u32 of scratch
 
     double max_expected_errors = 1.7976931348623157e308;  // corrector.rs:104 (f64::MAX)
     double confidence_threshold = 0.975;                   // corrector.rs:83

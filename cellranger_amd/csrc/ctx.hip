@@ -94,6 +94,8 @@ extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
         hipFree(p.d_index);
         hipFree(p.d_dist);
     }
+    hipFree(ctx->d_canon_keys);
+    hipFree(ctx->d_hot_image);
     hipFree(ctx->d_ptab);
     hipFree(ctx->d_scalars);
     hipFree(ctx->d_sort_hist);

@@ -75,6 +75,13 @@ __device__ __forceinline__ uint64_t lowmask(uint32_t bits) { return bits >= 64 ?
 // build keys (compacting)
 // ------------------------------------------------------------------------------------------------
 #define KEY_ITEMS 16
+#define KEY_BATCH 4  // reads whose loads are issued together: the kernel is bound by load latency, not bandwidth
+// a row of UMI qualities as LQW dwords (rows of 4k bytes are dword aligned); LQW = 0: byte path
+template <int LQW>
+struct __attribute__((aligned(4))) QRow {
+    uint32_t w[LQW ? LQW : 1];
+};
+template <int LQW>
 __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t *__restrict__ bc_idx,
                                                     const uint32_t *__restrict__ umi, const uint8_t *__restrict__ umi_q,
                                                     const uint32_t *__restrict__ feature, const uint8_t *__restrict__ flags,
@@ -85,51 +92,61 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
     const uint32_t L = kl.umi_len;
     const uint64_t chunk = 256ull * KEY_ITEMS;
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    const uint32_t umi_mask = (uint32_t)lowmask(kl.bits_umi), adj_mask = (uint32_t)lowmask(kl.bits_umi - 2u);
     for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
       uint64_t keys[KEY_ITEMS];
       uint32_t mask = 0;
 #pragma unroll
-      for (int j = 0; j < KEY_ITEMS; j++) {
-        const uint64_t i = c * chunk + (uint64_t)j * 256 + threadIdx.x;
-        bool keep = false;
-        uint64_t key = 0;
-        if (i < n) {
-            const uint32_t b = bc_idx[i];
-            const uint32_t f = feature[i];
-            const uint32_t fl = flags ? flags[i] : 0u;
-            const uint32_t lib = fl & CRGPU_FLAG_LIB_MASK;
-            if (b != CRGPU_MISS && f != CRGPU_NO_FEATURE && f < kl.n_features && lib < kl.n_libs) {
-                const uint32_t u = umi[i] & (uint32_t)lowmask(kl.bits_umi);
-                // UmiInfo::new (umi/src/info.rs:20-37)
-                bool has_n = false, low_q = false;
-                if ((L & 3u) == 0u) {
-                    // rows of 4k bytes are dword aligned: k dword loads instead of 4k byte loads
-                    const uint32_t *qw = reinterpret_cast<const uint32_t *>(umi_q + i * L);
-                    for (uint32_t k = 0; k < (L >> 2); k++) {
-                        const uint32_t w = qw[k];
-                        has_n |= (w & 0x80808080u) != 0u;
+      for (int j0 = 0; j0 < KEY_ITEMS; j0 += KEY_BATCH) {
+        // every field of KEY_BATCH reads is requested before any is looked at (no load sits behind a branch)
+        uint32_t vb[KEY_BATCH], vf[KEY_BATCH], vfl[KEY_BATCH], vu[KEY_BATCH];
+        QRow<LQW> vq[KEY_BATCH];
 #pragma unroll
-                        for (int b = 0; b < 4; b++) low_q |= (uint8_t)(((w >> (8 * b)) & 0x7Fu) - 33u) < 10u;
-                    }
-                } else {
-                    for (uint32_t k = 0; k < L; k++) {
-                        const uint32_t q = umi_q[i * L + k];
-                        has_n |= (q & 0x80u) != 0u;
-                        low_q |= (uint8_t)((q & 0x7Fu) - 33u) < 10u;  // u8 wrapping subtraction, UMI_MIN_QV = 10
-                    }
-                }
-                // is_homopolymer: every adjacent pair equal (true for a 1-base UMI)
-                const uint32_t adj = (u ^ (u >> 2)) & (uint32_t)lowmask(kl.bits_umi - 2u);
-                const bool homopolymer = adj == 0u;
-                if (!(has_n || homopolymer || low_q)) {
-                    keep = true;
-                    key = ((uint64_t)b << kl.sh_bc) | ((uint64_t)f << kl.sh_feat) | ((uint64_t)lib << kl.sh_lib) |
-                          ((uint64_t)u << kl.sh_umi) | ((fl & CRGPU_FLAG_NONTXOMIC) ? 1ull : 0ull);
-                }
+        for (int jj = 0; jj < KEY_BATCH; jj++) {
+            const uint64_t i = c * chunk + (uint64_t)(j0 + jj) * 256 + threadIdx.x;
+            const bool ok = i < n;
+            vb[jj] = ok ? bc_idx[i] : CRGPU_MISS;
+            vf[jj] = ok ? feature[i] : CRGPU_NO_FEATURE;
+            vfl[jj] = (ok && flags) ? flags[i] : 0u;
+            vu[jj] = ok ? umi[i] : 0u;
+            if (LQW) {
+                if (ok) vq[jj] = *reinterpret_cast<const QRow<LQW> *>(umi_q + i * (uint64_t)(4 * LQW));
+                else
+                    for (int k = 0; k < (LQW ? LQW : 1); k++) vq[jj].w[k] = 0u;
             }
         }
-        keys[j] = key;
-        if (keep) mask |= 1u << j;
+#pragma unroll
+        for (int jj = 0; jj < KEY_BATCH; jj++) {
+            const int j = j0 + jj;
+            const uint64_t i = c * chunk + (uint64_t)j * 256 + threadIdx.x;
+            const uint32_t b = vb[jj], f = vf[jj], fl = vfl[jj];
+            const uint32_t lib = fl & CRGPU_FLAG_LIB_MASK;
+            bool keep = b != CRGPU_MISS && f != CRGPU_NO_FEATURE && f < kl.n_features && lib < kl.n_libs;
+            const uint32_t u = vu[jj] & umi_mask;
+            // UmiInfo::new (umi/src/info.rs:20-37)
+            bool has_n = false, low_q = false;
+            if (LQW) {
+#pragma unroll
+                for (int k = 0; k < (LQW ? LQW : 1); k++) {
+                    const uint32_t w = vq[jj].w[k];
+                    has_n |= (w & 0x80808080u) != 0u;
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++) low_q |= (uint8_t)(((w >> (8 * bb)) & 0x7Fu) - 33u) < 10u;
+                }
+            } else if (keep) {
+                for (uint32_t k = 0; k < L; k++) {
+                    const uint32_t q = umi_q[i * L + k];
+                    has_n |= (q & 0x80u) != 0u;
+                    low_q |= (uint8_t)((q & 0x7Fu) - 33u) < 10u;  // u8 wrapping subtraction, UMI_MIN_QV = 10
+                }
+            }
+            // is_homopolymer: every adjacent pair equal (true for a 1-base UMI)
+            const bool homopolymer = ((u ^ (u >> 2)) & adj_mask) == 0u;
+            keep = keep && !(has_n || homopolymer || low_q);
+            keys[j] = ((uint64_t)b << kl.sh_bc) | ((uint64_t)f << kl.sh_feat) | ((uint64_t)lib << kl.sh_lib) |
+                      ((uint64_t)u << kl.sh_umi) | ((fl & CRGPU_FLAG_NONTXOMIC) ? 1ull : 0ull);
+            if (keep) mask |= 1u << j;
+        }
       }
       // one global atomic per 4096-read chunk (same-address atomics saturate near 88 per microsecond)
       unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_out, lds);
@@ -159,9 +176,19 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     {
         CrTimer t(ctx, CRGPU_T_KEYS, recs->n);
         CR_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(*d_n), ctx->stream));
-        hipLaunchKernelGGL(k_build_keys, dim3(cr_grid(recs->n, 256)), dim3(256), 0, ctx->stream, make_kl(ctx->layout),
-                           recs->d_bc_idx, recs->d_umi, recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n,
-                           d_keys_out, d_vals_out, d_n);
+        const KL kl = make_kl(ctx->layout);
+        const dim3 grid(cr_grid(recs->n, 256));
+#define CR_BUILD_KEYS(LQW)                                                                                                 \
+    hipLaunchKernelGGL(k_build_keys<LQW>, grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, recs->d_umi_qualn, \
+                       recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n)
+        switch (recs->umi_len) {
+            case 4: CR_BUILD_KEYS(1); break;
+            case 8: CR_BUILD_KEYS(2); break;
+            case 12: CR_BUILD_KEYS(3); break;
+            case 16: CR_BUILD_KEYS(4); break;
+            default: CR_BUILD_KEYS(0); break;
+        }
+#undef CR_BUILD_KEYS
         CR_HIP(ctx, hipGetLastError());
     }
     unsigned long long h = 0;

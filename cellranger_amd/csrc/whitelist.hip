@@ -33,8 +33,8 @@ static int pack_ascii(crgpu_ctx *ctx, const char *s, uint32_t n, uint32_t len, s
 template <typename T>
 static int upload(crgpu_ctx *ctx, T **d, const std::vector<T> &h) {
     *d = nullptr;
-    // +8 bytes of padding: scan_u16_range reads whole dwords around a bin
-    hipError_t e = hipMalloc((void **)d, std::max<size_t>(h.size(), 1) * sizeof(T) + 8);
+    // +32 bytes of padding: the lookups read whole dwords / 16-byte groups starting inside the table
+    hipError_t e = hipMalloc((void **)d, std::max<size_t>(h.size(), 1) * sizeof(T) + 32);
     if (e != hipSuccess) return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc whitelist table: %s", hipGetErrorString(e));
     if (!h.empty()) CR_HIP(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return CRGPU_OK;
@@ -67,6 +67,7 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
         ctx->n_canon = n_canon;
         ctx->cb_len = len;
         ctx->canon_set = true;
+        CR_TRY(upload(ctx, &ctx->d_canon_keys, sorted));
     } else {
         CR_REQUIRE(ctx, ctx->n_canon == n_canon && ctx->cb_len == len && ctx->canon_sorted == sorted, CRGPU_EINVAL,
                    "all libraries of a context must share one canonical barcode list");

@@ -17,6 +17,14 @@ struct WlView {
     uint32_t shiftE;
 };
 
+// multi-dword loads from 4-byte aligned addresses (one memory instruction, one address per lane)
+struct __attribute__((aligned(4))) U32x2 {
+    uint32_t a, b;
+};
+struct __attribute__((aligned(4))) U32x4 {
+    uint32_t w[4];
+};
+
 // Visit the u16 entries arr[lo, hi) in rounds of 16: the 8 dword loads of a round are independent
 // (one memory latency per round instead of one per entry -- a per-entry load/compare/branch loop is a
 // serial latency chain and made the lookups latency bound).  f(value, position) is called for every

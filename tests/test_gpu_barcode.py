@@ -125,6 +125,20 @@ def test_cfg2_model_1m_reads_bit_exact():
     assert st["corrected"] > 20_000 and st["invalid"] > 1_000 and st["valid"] > 800_000
 
 
+def test_hot_barcode_table_path_bit_exact(monkeypatch):
+    """K1's LDS table of the most frequent barcodes (used from 16 M reads per call) is only a cache: forced on at
+    1 M reads, per-read indices and both histograms still equal the oracle's."""
+    from cellranger_amd import synth as S
+
+    monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")
+    w = S.Workload(n_total=1_000_000, seed=S.SEED0 + 5)
+    st = _compare_barcode_stage(w, 1_000_000)
+    assert st["corrected"] > 20_000 and st["valid"] > 800_000
+    # few cells on a tiny whitelist: nearly every read is answered by the table; TTTT...T (all ones) is a valid key
+    w = S.Workload(n_total=200_000, seed=31, n_wl=64, n_cells=20, n_ambient=30, cb_len=4, umi_len=6, cb_err=0.05)
+    _compare_barcode_stage(w, 200_000)
+
+
 def test_dense_small_whitelists_many_neighbours_and_ties():
     """Short barcodes with a dense whitelist: several Hamming-1 neighbours per read, equal priors,
     thresholds that accept ties' winners -- exercises the f64 accumulation order and tie-breaks."""
