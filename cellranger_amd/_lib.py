@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libcrgpu.so")
+# CRGPU_LIB_PATH: load another build of the same library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("CRGPU_LIB_PATH") or os.path.join(PKG, "libcrgpu.so")
 
 MISS = 0xFFFFFFFF
 NO_FEATURE = 0xFFFFFFFF

@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ 
 // CU.  (A single kernel that also staged the histogram had to stop all 16 waves of the one workgroup a CU
 // can hold -- the table takes 128 KB -- at five barriers per tile and was latency bound.)
 #define LH_THREADS 1024
+#ifndef LH_ITEMS
 #define LH_ITEMS 8
+#endif
 __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                                                            const unsigned long long *__restrict__ hot_image,
                                                            const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
@@ -404,17 +406,29 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
     for (uint32_t s = tid; s < HOT_SLOTS; s += LH_THREADS) s_hot[s] = hot_image[s];
     __syncthreads();
     const uint64_t chunk = (uint64_t)LH_THREADS * LH_ITEMS;
+    // the keys of the next chunk are requested before this chunk's table probes and global lookups
+    uint32_t nkey[LH_ITEMS], nfl[LH_ITEMS];
+#pragma unroll
+    for (int j = 0; j < LH_ITEMS; j++) {
+        const uint64_t i = (uint64_t)blockIdx.x * chunk + (uint64_t)j * LH_THREADS + tid;
+        nkey[j] = i < n ? cb[i] : 0u;
+        nfl[j] = (i < n && flags) ? flags[i] : 0u;
+    }
     for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
         uint32_t key[LH_ITEMS], rank[LH_ITEMS], lo[LH_ITEMS], hi[LH_ITEMS];
         bool todo[LH_ITEMS];  // live read that the LDS table did not answer
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * LH_THREADS + tid;
-            const bool ok = i < n;
-            key[j] = ok ? cb[i] : 0u;
-            const uint32_t f = (ok && flags) ? flags[i] : 0u;
-            todo[j] = ok && !(f & CRGPU_FLAG_CB_HAS_N) && (f & CRGPU_FLAG_LIB_MASK) == 0u;
+            key[j] = nkey[j];
+            todo[j] = i < n && !(nfl[j] & CRGPU_FLAG_CB_HAS_N) && (nfl[j] & CRGPU_FLAG_LIB_MASK) == 0u;
             rank[j] = CRGPU_MISS;
+        }
+#pragma unroll
+        for (int j = 0; j < LH_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)gridDim.x * chunk + (uint64_t)j * LH_THREADS + tid;
+            nkey[j] = i < n ? cb[i] : 0u;
+            nfl[j] = (i < n && flags) ? flags[i] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
@@ -459,6 +473,86 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
             }
             if (i < n) idx_out[i] = rank[j];
         }
+    }
+}
+
+// Histogram staging from the ranks in idx for at most 31 buckets (whitelists of up to ~1 M barcodes, one
+// library): the same tile -> per-bucket runs -> staging regions as k_match_binned, but the position of a
+// rank inside its (tile, bucket) comes from the sort's ballot multisplit instead of 4096 returning LDS
+// atomics on two dozen counters (those serialised on their addresses).  Bucket 31 collects the misses.
+#define SI_BITS 5
+#define SI_MISS_BUCKET 31u
+__global__ __launch_bounds__(256) void k_stage_idx(const BinPlan plan, const uint32_t *__restrict__ idx, uint64_t n,
+                                                   uint16_t *__restrict__ stage, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t wcount[4][32];  // per-wave bucket counts -> tile-local start of (wave, bucket)
+    __shared__ uint32_t gbase[32];      // global base of the tile's run of each bucket
+    __shared__ uint32_t tstart[32];     // tile-local start of each bucket
+    __shared__ uint16_t sval[MB_TILE];
+    __shared__ uint8_t sbkt[MB_TILE];
+    __shared__ uint32_t tile_hits;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t n_tiles = (n + MB_TILE - 1) / MB_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (tid < 128) wcount[tid >> 5][tid & 31u] = 0;
+        __syncthreads();
+        uint32_t dr[MB_ITEMS];  // (bucket << 16) | rank inside (wave, bucket)
+        uint16_t v[MB_ITEMS];
+        const uint64_t wave_base = tile * MB_TILE + (uint64_t)wave * (64 * MB_ITEMS) + lane;  // wave-major order
+        uint32_t r[MB_ITEMS];
+#pragma unroll
+        for (int j = 0; j < MB_ITEMS; j++) {
+            const uint64_t i = wave_base + (uint64_t)j * 64;
+            r[j] = i < n ? idx[i] : CRGPU_MISS;
+        }
+#pragma unroll
+        for (int j = 0; j < MB_ITEMS; j++) {
+            const uint32_t b = r[j] != CRGPU_MISS ? (r[j] >> BIN_SHIFT) : SI_MISS_BUCKET;
+            v[j] = (uint16_t)(r[j] & (BIN_SIZE - 1u));
+            dr[j] = (b << 16) | wave_multisplit_rank<SI_BITS, true>(b, true, wcount[wave]);
+        }
+        __syncthreads();
+        if (tid < 32) {
+            // one lane per bucket: totals, exclusive scan over the hit buckets, one global reservation each
+            uint32_t c[4], tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                c[w] = wcount[w][tid];
+                tot += c[w];
+            }
+            if (tid == SI_MISS_BUCKET) tot = 0;
+            uint32_t x = tot;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (tid >= (uint32_t)d) x += y;
+            }
+            uint32_t run = x - tot;
+            tstart[tid] = run;
+            if (tid == 30) tile_hits = x;  // buckets 0..30 are the hit buckets
+            gbase[tid] = tot ? atomicAdd(&cursor[tid * MB_CURSOR_STRIDE], tot) : 0u;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                wcount[w][tid] = run;
+                run += c[w];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MB_ITEMS; j++) {
+            const uint32_t b = dr[j] >> 16;
+            if (b != SI_MISS_BUCKET) {
+                const uint32_t p = wcount[wave][b] + (dr[j] & 0xFFFFu);
+                sval[p] = v[j];
+                sbkt[p] = (uint8_t)b;
+            }
+        }
+        __syncthreads();
+        const uint32_t hits = tile_hits;
+        for (uint32_t p = tid; p < hits; p += 256) {
+            const uint32_t b = sbkt[p];
+            stage[(uint64_t)b * plan.cap + gbase[b] + (p - tstart[b])] = sval[p];
+        }
+        __syncthreads();
     }
 }
 
@@ -582,9 +676,13 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                 hipLaunchKernelGGL(k_lookup_hot, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), hot_lds,
                                    ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
                                    d_idx_out + off);
-                hipLaunchKernelGGL((k_match_binned<true, true>), dim3(cr_grid((m + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)),
-                                   dim3(256), 0, ctx->stream, vs, plan, d_cb + off, d_flags ? d_flags + off : nullptr, m,
-                                   d_idx_out + off, d_stage, d_cursor);
+                if (plan.n_buckets <= SI_MISS_BUCKET)
+                    hipLaunchKernelGGL(k_stage_idx, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u * 6u)), dim3(256), 0,
+                                       ctx->stream, plan, d_idx_out + off, m, d_stage, d_cursor);
+                else
+                    hipLaunchKernelGGL((k_match_binned<true, true>), dim3(cr_grid((m + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)),
+                                       dim3(256), 0, ctx->stream, vs, plan, d_cb + off, d_flags ? d_flags + off : nullptr, m,
+                                       d_idx_out + off, d_stage, d_cursor);
             } else {
                 const dim3 grid(cr_grid((m + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)), block(256);
                 if (uniform)

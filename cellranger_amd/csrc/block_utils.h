@@ -66,3 +66,34 @@ __device__ __forceinline__ unsigned long long block_reserve_256(uint32_t my_coun
     __syncthreads();
     return base + pre;
 }
+
+// Stable rank of a BITS-bit digit inside a wave (ballot multisplit): returns wc[d] before this call plus
+// the number of lower lanes holding the same digit, and advances wc[d] by the size of the digit's group.
+// wc = this wave's BITS-bit counter array in LDS.  Per digit bit: one v_bfe_i32 + one ballot + xnor/and on
+// the two mask halves; ranks from v_mbcnt; the running count is a plain LDS read by every lane followed by
+// a write from the lowest lane of each group (a wave runs in lockstep and its LDS operations complete in
+// order, so no atomic or cross-lane shuffle is needed).  FULL: every lane holds a live element.
+template <int BITS, bool FULL>
+__device__ __forceinline__ uint32_t wave_multisplit_rank(uint32_t d, bool ok, uint32_t *__restrict__ wc) {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+    if (!FULL) {
+        const unsigned long long live = __ballot(ok);
+        lo = (uint32_t)live;
+        hi = (uint32_t)(live >> 32);
+    }
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+        const int32_t nb = (int32_t)(d << (31 - b)) >> 31;  // 0 or -1 (v_bfe_i32)
+        const unsigned long long bal = __ballot(nb != 0);
+        lo &= ~((uint32_t)bal ^ (uint32_t)nb);          // lanes whose bit b equals mine
+        hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)nb);
+    }
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    const uint32_t cnt = (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+    uint32_t prev = 0;
+    if (FULL || ok) {
+        prev = wc[d];
+        if (below == 0) wc[d] = prev + cnt;
+    }
+    return prev + below;
+}

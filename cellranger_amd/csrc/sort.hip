@@ -156,31 +156,6 @@ __global__ __launch_bounds__(256) void k_scan_digits(uint32_t *__restrict__ bloc
 // halves, ranks from v_mbcnt, and the per-(wave, digit) running count is a plain LDS read by every lane
 // followed by a write from the lowest lane of each digit group (a wave runs in lockstep and its LDS
 // operations complete in order, so no atomic or cross-lane shuffle is needed).
-template <bool FULL>
-__device__ __forceinline__ uint32_t rank_in_wave(uint32_t d, bool ok, uint32_t *__restrict__ wc /* [RADIX] of this wave */) {
-    uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
-    if (!FULL) {
-        const unsigned long long live = __ballot(ok);
-        lo = (uint32_t)live;
-        hi = (uint32_t)(live >> 32);
-    }
-#pragma unroll
-    for (int b = 0; b < RADIX_BITS; b++) {
-        const int32_t nb = (int32_t)(d << (31 - b)) >> 31;  // 0 or -1 (v_bfe_i32)
-        const unsigned long long bal = __ballot(nb != 0);
-        lo &= ~((uint32_t)bal ^ (uint32_t)nb);          // lanes whose bit b equals mine
-        hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)nb);
-    }
-    const uint32_t below = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-    const uint32_t cnt = (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
-    uint32_t prev = 0;
-    if (FULL || ok) {
-        prev = wc[d];
-        if (below == 0) wc[d] = prev + cnt;
-    }
-    return prev + below;
-}
-
 template <typename K, bool HAS_VALS, typename DIG>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
@@ -226,7 +201,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
 #pragma unroll
             for (int it = 0; it < ITEMS; it++) {
                 const uint32_t d = dig(key[it]);
-                dr[it] = (d << 16) | rank_in_wave<true>(d, true, wcount[wave]);
+                dr[it] = (d << 16) | wave_multisplit_rank<RADIX_BITS, true>(d, true, wcount[wave]);
             }
         } else {
 #pragma unroll
@@ -239,7 +214,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             for (int it = 0; it < ITEMS; it++) {
                 const bool ok = wave_off + it * 64 < chunk_n;
                 const uint32_t d = ok ? dig(key[it]) : 0u;
-                dr[it] = (d << 16) | rank_in_wave<false>(d, ok, wcount[wave]);
+                dr[it] = (d << 16) | wave_multisplit_rank<RADIX_BITS, false>(d, ok, wcount[wave]);
             }
         }
         __syncthreads();
