@@ -12,17 +12,25 @@
 #include "block_utils.h"
 #include "common.h"
 
-#define SORT_BLOCK 256
-#ifndef SORT_ITEMS_U64
-#define SORT_ITEMS_U64 16  // keys per thread per chunk, 64-bit keys
+// One workgroup of 1024 threads per CU with a 16 K-key chunk (128 KB of LDS).  What bounds the scatter is
+// the efficiency of its writes: every resident workgroup keeps one partially written cache line open per
+// digit, and a chunk adds CHUNK/256 keys to it.  With many small workgroups (256 threads, 4 K keys, four
+// per CU) the open lines (1024 x 256 x 128 B = 32 MB) do not survive in the 4 MB L2s between two chunks and
+// runs of 128 B go out as partial lines; with one large workgroup per CU the open set is 8 MB and the runs
+// are 512 B.  Measured at 400 M reads: 13.1 -> 10.9 ms per step going from 4 K to 8 K keys at 256 threads.
+#ifndef SORT_BLOCK
+#define SORT_BLOCK 1024
 #endif
-#ifndef SORT_ITEMS_U32
-#define SORT_ITEMS_U32 24  // 32-bit keys (+ payload): longer chunks keep the per-digit output runs >= 96 bytes
+#ifndef SORT_ITEMS
+#define SORT_ITEMS 16      // keys per thread per chunk
 #endif
+#define SORT_ITEMS_KV64 8  // 64-bit keys with a payload: 12 bytes per element in LDS
 #define SORT_WAVES (SORT_BLOCK / 64)
 #define RADIX_BITS 8
 #define RADIX 256
-#define SORT_MAX_BLOCKS 2048
+#ifndef SORT_MAX_BLOCKS
+#define SORT_MAX_BLOCKS 1024
+#endif
 
 // ---- exclusive scan of a small u32 array (block counts of the compactions), single workgroup -----
 __global__ __launch_bounds__(1024) void k_scan_small(uint32_t *__restrict__ data, uint64_t n,
@@ -101,15 +109,13 @@ struct OwnerBounds {
     }
 };
 
-template <typename K>
-struct SortCfg;
-template <>
-struct SortCfg<uint64_t> {
-    static constexpr int ITEMS = SORT_ITEMS_U64;
-};
-template <>
-struct SortCfg<uint32_t> {
-    static constexpr int ITEMS = SORT_ITEMS_U32;
+template <typename K, bool HAS_VALS>
+struct SortCfg {
+    static constexpr int ITEMS = (sizeof(K) == 8 && HAS_VALS) ? SORT_ITEMS_KV64 : SORT_ITEMS;
+    static constexpr uint32_t CHUNK = SORT_BLOCK * ITEMS;
+    // LDS: staged keys (+ payloads), per-wave digit counts, digit bases, global deltas, scan scratch
+    static constexpr size_t LDS_BYTES =
+        (size_t)CHUNK * (sizeof(K) + (HAS_VALS ? 4 : 0)) + (SORT_WAVES + 2) * RADIX * 4 + SORT_WAVES * 4;
 };
 
 // ---- pass 1: per-block digit histogram ------------------------------------------------------------
@@ -118,13 +124,13 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(const K *__restrict__
                                                            DIG dig, uint32_t *__restrict__ block_hist,
                                                            uint32_t n_blocks) {
     __shared__ uint32_t h[RADIX];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < RADIX) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
     for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) atomicAdd(&h[dig(keys[i])], 1u);
     __syncthreads();
-    block_hist[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < RADIX) block_hist[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // ---- pass 2: one workgroup per digit scans that digit's row of block counts ------------------------
@@ -163,26 +169,27 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                                                               DIG dig, const uint32_t *__restrict__ block_offs,
                                                               const uint32_t *__restrict__ digit_totals,
                                                               uint32_t n_blocks) {
-    constexpr int ITEMS = SortCfg<K>::ITEMS;
-    constexpr uint32_t CHUNK = SORT_BLOCK * ITEMS;
-    __shared__ K skeys[CHUNK];
-    __shared__ uint32_t svals[HAS_VALS ? CHUNK : 1];
-    __shared__ uint32_t wcount[SORT_WAVES][RADIX];  // per-wave same-digit counts -> LDS position of (wave, digit)
-    __shared__ uint32_t base[RADIX];                // running global offset of each digit for this block
-    __shared__ uint32_t gdelta[RADIX];              // global position = LDS position + gdelta[digit]
-    __shared__ uint32_t lds[8];
+    constexpr int ITEMS = SortCfg<K, HAS_VALS>::ITEMS;
+    constexpr uint32_t CHUNK = SortCfg<K, HAS_VALS>::CHUNK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    K *skeys = reinterpret_cast<K *>(smem);                                                    // CHUNK
+    uint32_t *svals = reinterpret_cast<uint32_t *>(smem + (size_t)CHUNK * sizeof(K));         // CHUNK if HAS_VALS
+    uint32_t(*wcount)[RADIX] = reinterpret_cast<uint32_t(*)[RADIX]>(svals + (HAS_VALS ? CHUNK : 0));
+    // wcount: per-wave same-digit counts -> LDS position of (wave, digit)
+    uint32_t *base = &wcount[SORT_WAVES][0];  // running global offset of each digit for this block
+    uint32_t *gdelta = base + RADIX;          // global position = LDS position + gdelta[digit]
+    uint32_t *lds = gdelta + RADIX;           // SORT_WAVES words of scan scratch
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     {
-        const uint32_t digit_base = block_excl_scan_256(digit_totals[tid], lds, nullptr);
-        base[tid] = digit_base + block_offs[(uint64_t)tid * n_blocks + blockIdx.x];
+        const uint32_t digit_base = block_excl_scan<SORT_BLOCK>(tid < RADIX ? digit_totals[tid] : 0u, lds, nullptr);
+        if (tid < RADIX) base[tid] = digit_base + block_offs[(uint64_t)tid * n_blocks + blockIdx.x];
     }
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
 
     for (uint64_t chunk = lo; chunk < hi; chunk += CHUNK) {
-#pragma unroll
-        for (int w = 0; w < SORT_WAVES; w++) wcount[w][tid] = 0;
+        for (uint32_t x = tid; x < SORT_WAVES * RADIX; x += SORT_BLOCK) (&wcount[0][0])[x] = 0;
         __syncthreads();
 
         K key[ITEMS];
@@ -221,20 +228,19 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         // one thread per digit: chunk-local start of the digit (exclusive scan over digits), per-wave
         // starts inside it, and the shift from LDS position to global position
         {
-            uint32_t c[SORT_WAVES], tot = 0;
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; w++) {
-                c[w] = wcount[w][tid];
-                tot += c[w];
-            }
-            uint32_t run = block_excl_scan_256(tot, lds, nullptr);  // chunk-local start of digit tid
-            const uint32_t g = base[tid];
-            gdelta[tid] = g - run;
-            base[tid] = g + tot;
-#pragma unroll
-            for (int w = 0; w < SORT_WAVES; w++) {
-                wcount[w][tid] = run;
-                run += c[w];
+            uint32_t tot = 0;
+            if (tid < RADIX)
+                for (int w = 0; w < SORT_WAVES; w++) tot += wcount[w][tid];
+            uint32_t run = block_excl_scan<SORT_BLOCK>(tot, lds, nullptr);  // chunk-local start of digit tid
+            if (tid < RADIX) {
+                const uint32_t g = base[tid];
+                gdelta[tid] = g - run;
+                base[tid] = g + tot;
+                for (int w = 0; w < SORT_WAVES; w++) {
+                    const uint32_t c = wcount[w][tid];
+                    wcount[w][tid] = run;
+                    run += c;
+                }
             }
         }
         __syncthreads();
@@ -257,9 +263,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
     }
 }
 
-template <typename K>
-static uint32_t sort_blocks(uint64_t n, uint64_t *tile_out) {
-    const uint64_t chunk = (uint64_t)SORT_BLOCK * SortCfg<K>::ITEMS;
+static uint32_t sort_blocks(uint64_t n, uint64_t chunk, uint64_t *tile_out) {
     uint64_t nb = (n + chunk * 4 - 1) / (chunk * 4);
     if (nb < 1) nb = 1;
     if (nb > SORT_MAX_BLOCKS) nb = SORT_MAX_BLOCKS;
@@ -278,7 +282,7 @@ template <typename K, typename DIG>
 static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d_vin, uint32_t *d_vout, uint64_t n,
                       DIG dig) {
     uint64_t tile;
-    const uint32_t nb = sort_blocks<K>(n, &tile);
+    const uint32_t nb = sort_blocks(n, d_vin ? SortCfg<K, true>::CHUNK : SortCfg<K, false>::CHUNK, &tile);
     uint32_t *d_hist = ctx->d_sort_hist;
     uint32_t *d_tot = digit_totals_buf(ctx);
     {
@@ -290,12 +294,26 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
         hipLaunchKernelGGL(k_scan_digits, dim3(RADIX), dim3(256), 0, ctx->stream, d_hist, nb, d_tot);
     }
     CrTimer t(ctx, CRGPU_T_SORT, n);
-    if (d_vin)
-        hipLaunchKernelGGL((k_radix_scatter<K, true, DIG>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin,
-                           d_vout, n, tile, dig, d_hist, d_tot, nb);
-    else
-        hipLaunchKernelGGL((k_radix_scatter<K, false, DIG>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_out, d_vin,
-                           d_vout, n, tile, dig, d_hist, d_tot, nb);
+    // more than 64 KB of LDS per workgroup has to be requested per kernel, once
+    static bool attr_kv = false, attr_k = false;
+    const size_t lds_kv = SortCfg<K, true>::LDS_BYTES, lds_k = SortCfg<K, false>::LDS_BYTES;
+    if (d_vin) {
+        if (!attr_kv) {
+            (void)hipFuncSetAttribute((const void *)k_radix_scatter<K, true, DIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_kv);
+            attr_kv = true;
+        }
+        hipLaunchKernelGGL((k_radix_scatter<K, true, DIG>), dim3(nb), dim3(SORT_BLOCK), lds_kv, ctx->stream,
+                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb);
+    } else {
+        if (!attr_k) {
+            (void)hipFuncSetAttribute((const void *)k_radix_scatter<K, false, DIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_k);
+            attr_k = true;
+        }
+        hipLaunchKernelGGL((k_radix_scatter<K, false, DIG>), dim3(nb), dim3(SORT_BLOCK), lds_k, ctx->stream,
+                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb);
+    }
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
 }
