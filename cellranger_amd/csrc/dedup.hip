@@ -795,12 +795,32 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             if (!attr_set) {
                 (void)hipFuncSetAttribute((const void *)k_correct_umis_edges<false>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large);
+                (void)hipFuncSetAttribute((const void *)k_giant_probe, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds_large);
                 attr_set = true;
             }
+            // work list of the segments with more than UE_CAP keys: one item per chunk of UE_CAP keys
+            DevBuf giant_b, best_b;
+            const uint64_t max_items = nd / (UE_CAP / 2) + 16;
+            CR_TRY(dmalloc(ctx, giant_b, max_items * sizeof(GiantItem) + 16));
+            CR_TRY(dmalloc(ctx, best_b, nd * sizeof(unsigned long long)));
+            uint32_t *n_giant = reinterpret_cast<uint32_t *>(giant_b.as<unsigned char>());
+            GiantItem *items = reinterpret_cast<GiantItem *>(giant_b.as<unsigned char>() + 16);
+            unsigned long long *best = best_b.as<unsigned long long>();
+            CR_HIP(ctx, hipMemsetAsync(n_giant, 0, sizeof(uint32_t), ctx->stream));
             hipLaunchKernelGGL(k_correct_umis_edges<true>, dim3(cr_grid(n_tiles - 1, 1, 256u * 6u)), dim3(UES_THREADS),
-                               lds_small, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all);
+                               lds_small, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all,
+                               items, n_giant);
             hipLaunchKernelGGL(k_correct_umis_edges<false>, dim3(cr_grid(n_tiles - 1, 1, 256u * 2u)), dim3(UE_THREADS),
-                               lds_large, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all);
+                               lds_large, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all,
+                               items, n_giant);
+            // the three kernels loop over the device-side item count (usually a few hundred, often zero)
+            hipLaunchKernelGGL(k_giant_init, dim3(512), dim3(UE_THREADS), 0, ctx->stream, kl, ukey, upos, nd, n_keys, items,
+                               n_giant, best);
+            hipLaunchKernelGGL(k_giant_probe, dim3(512), dim3(UE_THREADS), lds_large, ctx->stream, kl, ukey, upos, nd, n_keys,
+                               items, n_giant, best);
+            hipLaunchKernelGGL(k_giant_final, dim3(512), dim3(UE_THREADS), 0, ctx->stream, upos, nd, n_keys, items, n_giant, best,
+                               corr, inc1, inc_all);
         }
         hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd, corr,
                            minraw_b.as<unsigned long long>());

@@ -30,12 +30,21 @@
 //      against which every key of the segment is probed.
 #pragma once
 
-#define UC_ITEMS 8
+// 1024-key tiles: 28 KB of LDS, five workgroups per CU.  The kernel waits at its barriers most of the time
+// (SQ_WAIT_ANY 73 % of the wave cycles), so residency beats tile size: 2048-key tiles (57 KB, two per CU) were
+// 12 % slower on the whole dedup stage even though fewer segments cross a tile edge.
+#ifndef UC_ITEMS
+#define UC_ITEMS 4
+#endif
 #define UC_TILE (256 * UC_ITEMS)
 #define UC_BLOCKS (UC_TILE / 64)
+#ifndef UC_SMALL
 #define UC_SMALL 32
+#endif
 #define UC_OPEN 0xFFFFu
-#define UC_BUCKETS 1024u  // tile hash set: 8-slot buckets (32 B); at most UC_TILE entries => load <= 0.25
+#ifndef UC_BUCKETS
+#define UC_BUCKETS 512u  // tile hash set: 8-slot buckets (32 B); at most UC_TILE entries => load <= 0.25
+#endif
 #define UC_POSBITS 11u    // slot = (fingerprint << POSBITS) | position
 #define UC_EMPTY 0xFFFFFFFFu
 #define UC_NOCORR 0x80000000u  // flag inside the staged count: UMI correction disabled for the key's library
@@ -49,6 +58,10 @@
 #define UES_BUCKETS 512u
 #define UES_POSBITS 10u
 #define UC_NOHEAD 0xFFFFFFFFu
+
+struct GiantItem {
+    uint32_t s, e, c0;  // segment [s, e) and the first key of this item's chunk of UE_CAP keys
+};
 
 template <bool SMALL>
 struct EdgeCfg;
@@ -305,7 +318,8 @@ template <bool SMALL>
 __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
     const KL kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
     const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_last, uint32_t *__restrict__ corr,
-    uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all) {
+    uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all, GiantItem *__restrict__ giant_items,
+    uint32_t *__restrict__ n_giant) {
     constexpr uint32_t UE_T = EdgeCfg<SMALL>::THREADS, CAP = EdgeCfg<SMALL>::CAP, BUCKETS = EdgeCfg<SMALL>::BUCKETS,
                        POSBITS = EdgeCfg<SMALL>::POSBITS;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -372,79 +386,123 @@ __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
             __syncthreads();
             continue;
         }
-        // ---- larger than the LDS budget -----------------------------------------------------------------
-        // (1) same-high-half neighbours: the run around each key in the sorted global array
-        for (uint64_t k = s + tid; k < e; k += UE_T) {
+        // ---- larger than the LDS budget: one work item per chunk of CAP keys for the k_giant_* kernels, so that a
+        // segment of tens of thousands of keys is spread over many workgroups instead of being this one's long pole
+        {
+            __shared__ uint32_t s_item0;
+            const uint32_t n_chunks = (uint32_t)((m + CAP - 1) / CAP);
+            if (tid == 0) s_item0 = atomicAdd(n_giant, n_chunks);
+            __syncthreads();
+            const uint32_t item0 = s_item0;
+            for (uint32_t c = tid; c < n_chunks; c += UE_T)
+                giant_items[item0 + c] = GiantItem{(uint32_t)s, (uint32_t)e, (uint32_t)(s + (uint64_t)c * CAP)};
+            __syncthreads();
+        }
+    }
+}
+
+// ---- giant segments (more than UE_CAP keys) -------------------------------------------------------------------
+// best[k] = (count << 32) | index of the best key found so far for k (its own to start with).  Inside a segment
+// the index order is the UMI order, so the packed value orders exactly like (count, UMI) and atomicMax merges
+// the findings of the workgroups that probe different table chunks.
+__global__ __launch_bounds__(UE_THREADS) void k_giant_init(const KL kl, const uint64_t *__restrict__ ukey,
+                                                           const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+                                                           const GiantItem *__restrict__ items,
+                                                           const uint32_t *__restrict__ n_items_ptr,
+                                                           unsigned long long *__restrict__ best) {
+    const uint32_t n_items = *n_items_ptr;
+    const uint64_t umi_mask = lowmask(kl.bits_umi);
+    const UmiSplit sp = umi_split(kl.umi_len);
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const GiantItem g = items[it];
+        const uint64_t s = g.s, e = g.e;
+        const uint64_t c1 = (uint64_t)g.c0 + UE_CAP < e ? (uint64_t)g.c0 + UE_CAP : e;
+        // same-high-half neighbours: the run around each key in the sorted global array
+        for (uint64_t k = g.c0 + threadIdx.x; k < c1; k += UE_THREADS) {
             const uint32_t my_umi = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
             const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
-            Best best{run_count(upos, nd, n_keys, k), my_umi, 0u};
-            uint64_t best_k = k;
+            unsigned long long b = ((unsigned long long)run_count(upos, nd, n_keys, k) << 32) | (uint32_t)k;
             for (uint64_t q = k; q > s;) {
                 --q;
                 const uint32_t u = (uint32_t)((ukey[q] >> kl.sh_umi) & umi_mask);
                 if ((u >> sp.lo_bits) != my_hi) break;
                 if (hd1(u & sp.lo_mask, my_lo)) {
-                    const uint32_t c = run_count(upos, nd, n_keys, q);
-                    if (c > best.cnt || (c == best.cnt && u > best.umi)) {
-                        best.cnt = c;
-                        best.umi = u;
-                        best_k = q;
-                    }
+                    const unsigned long long c = ((unsigned long long)run_count(upos, nd, n_keys, q) << 32) | (uint32_t)q;
+                    b = c > b ? c : b;
                 }
             }
             for (uint64_t q = k + 1; q < e; q++) {
                 const uint32_t u = (uint32_t)((ukey[q] >> kl.sh_umi) & umi_mask);
                 if ((u >> sp.lo_bits) != my_hi) break;
                 if (hd1(u & sp.lo_mask, my_lo)) {
-                    const uint32_t c = run_count(upos, nd, n_keys, q);
-                    if (c > best.cnt || (c == best.cnt && u > best.umi)) {
-                        best.cnt = c;
-                        best.umi = u;
-                        best_k = q;
-                    }
+                    const unsigned long long c = ((unsigned long long)run_count(upos, nd, n_keys, q) << 32) | (uint32_t)q;
+                    b = c > b ? c : b;
                 }
             }
-            corr[k] = best_k != k ? (uint32_t)best_k : NONE32;  // provisional; refined below
+            best[k] = b;
+        }
+    }
+}
+
+// same-low-half neighbours: the item's chunk of UE_CAP keys becomes an LDS table, every key of the segment probes it
+__global__ __launch_bounds__(UE_THREADS) void k_giant_probe(const KL kl, const uint64_t *__restrict__ ukey,
+                                                            const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+                                                            const GiantItem *__restrict__ items,
+                                                            const uint32_t *__restrict__ n_items_ptr,
+                                                            unsigned long long *__restrict__ best) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *s_umi = smem;                // UE_CAP
+    uint32_t *s_cnt = smem + UE_CAP;       // UE_CAP
+    uint32_t *s_hash = smem + 2 * UE_CAP;  // UE_BUCKETS * 8 slots
+    const uint32_t n_items = *n_items_ptr;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t umi_mask = lowmask(kl.bits_umi);
+    const UmiSplit sp = umi_split(kl.umi_len);
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const GiantItem g = items[it];
+        const uint64_t s = g.s, e = g.e, c0 = g.c0;
+        const uint32_t cn = e - c0 < UE_CAP ? (uint32_t)(e - c0) : UE_CAP;
+        for (uint32_t h = tid; h < UE_BUCKETS * 8; h += UE_THREADS) s_hash[h] = UC_EMPTY;
+        for (uint32_t p = tid; p < cn; p += UE_THREADS) {
+            s_umi[p] = (uint32_t)((ukey[c0 + p] >> kl.sh_umi) & umi_mask);
+            s_cnt[p] = run_count(upos, nd, n_keys, c0 + p);
         }
         __syncthreads();
-        // (2) same-low-half neighbours: chunks of CAP table entries, every key of the segment probes each
-        for (uint64_t c0 = s; c0 < e; c0 += CAP) {
-            const uint32_t cn = e - c0 < CAP ? (uint32_t)(e - c0) : CAP;
-            for (uint32_t h = tid; h < BUCKETS * 8; h += UE_T) s_hash[h] = UC_EMPTY;
-            for (uint32_t p = tid; p < cn; p += UE_T) {
-                s_umi[p] = (uint32_t)((ukey[c0 + p] >> kl.sh_umi) & umi_mask);
-                s_cnt[p] = run_count(upos, nd, n_keys, c0 + p);
-            }
-            __syncthreads();
-            for (uint32_t p = tid; p < cn; p += UE_T)
-                uc_insert<BUCKETS, POSBITS>(s_hash, 0u, s_umi[p] & sp.lo_mask, p);
-            __syncthreads();
-            for (uint64_t k = s + tid; k < e; k += UE_T) {
-                const uint32_t my_umi = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
-                const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
-                // current best of this key (own key, or the provisional target found so far)
-                const uint32_t cur = corr[k];
-                Best best{0u, 0u, 0xFFFFFFFFu};
-                if (cur == NONE32) {
-                    best.cnt = run_count(upos, nd, n_keys, k);
-                    best.umi = my_umi;
-                } else {
-                    best.cnt = run_count(upos, nd, n_keys, cur);
-                    best.umi = (uint32_t)((ukey[cur] >> kl.sh_umi) & umi_mask);
+        for (uint32_t p = tid; p < cn; p += UE_THREADS)
+            uc_insert<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, s_umi[p] & sp.lo_mask, p);
+        __syncthreads();
+        for (uint64_t k = s + tid; k < e; k += UE_THREADS) {
+            const uint32_t my_umi = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
+            const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
+            unsigned long long b = 0ull;
+            uc_for_each<UE_BUCKETS, UE_POSBITS>(s_hash, 0u, my_lo, [&](uint32_t q) {
+                const uint32_t u = s_umi[q];
+                if ((u & sp.lo_mask) != my_lo) return;
+                if (hd1(u >> sp.lo_bits, my_hi)) {
+                    const unsigned long long c = ((unsigned long long)s_cnt[q] << 32) | (uint32_t)(c0 + q);
+                    b = c > b ? c : b;
                 }
-                uc_for_each<BUCKETS, POSBITS>(s_hash, 0u, my_lo, [&](uint32_t q) {
-                    const uint32_t u = s_umi[q];
-                    if ((u & sp.lo_mask) != my_lo) return;
-                    if (hd1(u >> sp.lo_bits, my_hi)) best.offer(s_cnt[q], u, q);
-                });
-                if (best.pos != 0xFFFFFFFFu) corr[k] = (uint32_t)(c0 + best.pos);
-            }
-            __syncthreads();
+            });
+            if (b) atomicMax(&best[k], b);
         }
-        // the moves of this segment's corrected keys
-        for (uint64_t k = s + tid; k < e; k += UE_T) {
-            const uint32_t target = corr[k];
-            if (target != NONE32) {
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(UE_THREADS) void k_giant_final(const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+                                                            const GiantItem *__restrict__ items,
+                                                            const uint32_t *__restrict__ n_items_ptr,
+                                                            const unsigned long long *__restrict__ best,
+                                                            uint32_t *__restrict__ corr, uint32_t *__restrict__ inc1,
+                                                            uint32_t *__restrict__ inc_all) {
+    const uint32_t n_items = *n_items_ptr;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const GiantItem g = items[it];
+        const uint64_t c1 = (uint64_t)g.c0 + UE_CAP < g.e ? (uint64_t)g.c0 + UE_CAP : g.e;
+        for (uint64_t k = g.c0 + threadIdx.x; k < c1; k += UE_THREADS) {
+            const uint32_t target = (uint32_t)best[k];
+            corr[k] = target != (uint32_t)k ? target : NONE32;
+            if (target != (uint32_t)k) {
                 atomicAdd(&inc1[target], 1u);
                 atomicAdd(&inc_all[target], run_count(upos, nd, n_keys, k));
             }
