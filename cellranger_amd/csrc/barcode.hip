@@ -717,6 +717,9 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
 // ------------------------------------------------------------------------------------------------
 // K2: posterior correction of the reads that missed
 // ------------------------------------------------------------------------------------------------
+#ifndef K2_SCAN_DWORDS
+#define K2_SCAN_DWORDS 8  // entries of a pigeonhole bin per round = 2 * this (the bins hold ~11 entries)
+#endif
 #define MISS_ITEMS 64
 // Compact the indices of the reads that missed.  One global atomic per 16384-read chunk: same-address
 // atomics saturate near 88 per microsecond on this chip, so the reservation is aggregated over the
@@ -729,10 +732,21 @@ __global__ __launch_bounds__(256) void k_collect_miss(const uint32_t *__restrict
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
         unsigned long long mask = 0;
-#pragma unroll 16
-        for (int j = 0; j < MISS_ITEMS; j++) {
-            const uint64_t i = c * chunk + (uint64_t)j * 256 + threadIdx.x;
-            if (i < n && idx[i] == CRGPU_MISS) mask |= 1ull << j;
+        // unconditional loads from clamped addresses, 16 in flight: a load behind an `i < n` branch is not
+        // issued before the previous one has been compared
+#pragma unroll
+        for (int j0 = 0; j0 < MISS_ITEMS; j0 += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                const uint64_t i = c * chunk + (uint64_t)(j0 + jj) * 256 + threadIdx.x;
+                v[jj] = idx[i < n ? i : n - 1];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                const uint64_t i = c * chunk + (uint64_t)(j0 + jj) * 256 + threadIdx.x;
+                if (i < n && v[jj] == CRGPU_MISS) mask |= 1ull << (j0 + jj);
+            }
         }
         unsigned long long o = block_reserve_256((uint32_t)__popcll(mask), n_miss, lds);
         while (mask) {
@@ -802,10 +816,11 @@ __global__ __launch_bounds__(256) void k_correct(const WlViewSet vs, const uint3
             const uint32_t tail = key & ((1u << w.bitsB) - 1u);
             const uint32_t hA = w.bitsA >> 1;
             // the four bin bounds are independent loads
-            const uint32_t a_lo = w.offA[head], a_hi = w.offA[head + 1];
-            const uint32_t b_lo = w.offB[tail], b_hi = w.offB[tail + 1];
+            const U32x2 a2 = *reinterpret_cast<const U32x2 *>(w.offA + head);
+            const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offB + tail);
+            const uint32_t a_lo = a2.a, a_hi = a2.b, b_lo = b2.a, b_hi = b2.b;
             // mutation in the tail: same head -> bin A
-            scan_u16_range(w.tailA, a_lo, a_hi, [&](uint32_t t, uint32_t) {
+            scan_u16_range<K2_SCAN_DWORDS>(w.tailA, a_lo, a_hi, [&](uint32_t t, uint32_t) {
                 const int bo = one_base_diff(t, tail);
                 if (bo >= 0) {
                     const uint32_t pos = len - 1u - (uint32_t)(bo >> 1);
@@ -813,7 +828,7 @@ __global__ __launch_bounds__(256) void k_correct(const WlViewSet vs, const uint3
                 }
             });
             // mutation in the head: same tail -> bin B
-            scan_u16_range(w.headB, b_lo, b_hi, [&](uint32_t h, uint32_t) {
+            scan_u16_range<K2_SCAN_DWORDS>(w.headB, b_lo, b_hi, [&](uint32_t h, uint32_t) {
                 const int bo = one_base_diff(h, head);
                 if (bo >= 0) {
                     const uint32_t pos = hA - 1u - (uint32_t)(bo >> 1);

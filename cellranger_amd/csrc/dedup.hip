@@ -245,60 +245,97 @@ extern "C" int crgpu_balanced_bounds(crgpu_ctx *ctx, uint32_t n_ranks, uint32_t 
 // generic two-pass stream compaction driven by a flag functor: out position of every flagged item
 // ------------------------------------------------------------------------------------------------
 #define CP_BLOCK 256
+#define CP_ITEMS 8  // items per thread per round: their flag loads are all issued before the first compare
+#define CP_ROUND (CP_BLOCK * CP_ITEMS)
+#define CP_WAVES (CP_BLOCK / 64)
 
+// Flags are evaluated at clamped indices and masked afterwards, so that the loads of a round are not chained
+// behind `i < hi` branches (one load in flight per wave left these passes at ~2 TB/s).
 template <typename Flag>
 __global__ __launch_bounds__(CP_BLOCK) void k_cp_count(Flag flag, uint64_t n, uint64_t tile, uint32_t *__restrict__ block_counts) {
-    __shared__ uint32_t ws[CP_BLOCK / 64];
+    __shared__ uint32_t ws[CP_WAVES];
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
     uint32_t c = 0;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += CP_BLOCK) c += flag(i) ? 1u : 0u;
+    for (uint64_t base = lo; base < hi; base += CP_ROUND) {
+        bool f[CP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * CP_BLOCK + threadIdx.x;
+            f[j] = flag(i < hi ? i : hi - 1);
+        }
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * CP_BLOCK + threadIdx.x;
+            c += (f[j] && i < hi) ? 1u : 0u;
+        }
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
     if ((threadIdx.x & 63u) == 0) ws[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = 0;
-        for (int w = 0; w < CP_BLOCK / 64; w++) t += ws[w];
+        for (int w = 0; w < CP_WAVES; w++) t += ws[w];
         block_counts[blockIdx.x] = t;
     }
 }
 
+// Stable: inside a round the output order is (item slot, wave, lane) == ascending input index.
 template <typename Flag, typename Emit>
 __global__ __launch_bounds__(CP_BLOCK) void k_cp_write(Flag flag, Emit emit, uint64_t n, uint64_t tile,
                                                        const uint32_t *__restrict__ block_offs) {
-    __shared__ uint32_t ws[CP_BLOCK / 64];
-    __shared__ uint32_t run_s;
+    __shared__ uint32_t ws[CP_ITEMS * CP_WAVES];  // flagged items of (item slot, wave), then their exclusive prefix
+    __shared__ uint32_t round_total;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
-    if (threadIdx.x == 0) run_s = block_offs[blockIdx.x];
-    __syncthreads();
-    for (uint64_t base = lo; base < hi; base += CP_BLOCK) {
-        const uint64_t i = base + threadIdx.x;
-        const bool f = i < hi && flag(i);
-        const unsigned long long m = __ballot(f);
-        if (lane == 0) ws[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t off = run_s;
-        for (uint32_t w = 0; w < wave; w++) off += ws[w];
-        if (f) emit(i, off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t t = 0;
-            for (int w = 0; w < CP_BLOCK / 64; w++) t += ws[w];
-            run_s += t;
+    uint32_t run = block_offs[blockIdx.x];
+    for (uint64_t base = lo; base < hi; base += CP_ROUND) {
+        bool f[CP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * CP_BLOCK + threadIdx.x;
+            f[j] = flag(i < hi ? i : hi - 1);
         }
+        uint32_t below[CP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * CP_BLOCK + threadIdx.x;
+            f[j] = f[j] && i < hi;
+            const unsigned long long m = __ballot(f[j]);
+            below[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) ws[j * CP_WAVES + wave] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (threadIdx.x < CP_ITEMS * CP_WAVES) {  // 32 lanes of wave 0: exclusive scan in (slot, wave) order
+            const uint32_t v = ws[threadIdx.x];
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < CP_ITEMS * CP_WAVES; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (threadIdx.x >= (uint32_t)d) x += y;
+            }
+            ws[threadIdx.x] = x - v;
+            if (threadIdx.x == CP_ITEMS * CP_WAVES - 1) round_total = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * CP_BLOCK + threadIdx.x;
+            if (f[j]) emit(i, run + ws[j * CP_WAVES + wave] + below[j]);
+        }
+        run += round_total;
         __syncthreads();
     }
 }
 
 static uint32_t cp_blocks(uint64_t n, uint64_t *tile_out) {
-    uint64_t nb = (n + CP_BLOCK * 16 - 1) / (CP_BLOCK * 16);
+    uint64_t nb = (n + CP_ROUND * 4 - 1) / (CP_ROUND * 4);
     if (nb < 1) nb = 1;
     if (nb > 4096) nb = 4096;
     uint64_t tile = (n + nb - 1) / nb;
-    tile = (tile + CP_BLOCK - 1) / CP_BLOCK * CP_BLOCK;
+    tile = (tile + CP_ROUND - 1) / CP_ROUND * CP_ROUND;
     nb = (n + tile - 1) / tile;
     if (nb < 1) nb = 1;
     *tile_out = tile;
@@ -322,7 +359,8 @@ struct HeadFlag {  // first element of a run of equal (key >> shift)
     const uint64_t *keys;
     uint32_t shift;
     __device__ __forceinline__ bool operator()(uint64_t i) const {
-        return i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift);
+        const uint64_t prev = keys[i ? i - 1 : 0];  // no load behind a branch
+        return (i == 0) | ((keys[i] >> shift) != (prev >> shift));
     }
 };
 struct EmitRun {  // distinct key + start position of its run
@@ -338,8 +376,9 @@ struct MolFlag {  // distinct key that yields a UmiCount (mark_dups.rs:322-325 w
     const uint32_t *corr, *inc1;
     const uint8_t *low;
     __device__ __forceinline__ bool operator()(uint64_t k) const {
-        const bool landed = corr[k] == NONE32 || inc1[k] > 0u;  // some read's corrected key is k
-        return landed && !low[k];
+        const uint32_t c = corr[k], i1 = inc1[k], l = low[k];  // three independent loads
+        const bool landed = (c == NONE32) | (i1 > 0u);          // some read's corrected key is k
+        return landed & (l == 0u);
     }
 };
 struct EmitMol {

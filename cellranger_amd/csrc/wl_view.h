@@ -25,21 +25,22 @@ struct __attribute__((aligned(4))) U32x4 {
     uint32_t w[4];
 };
 
-// Visit the u16 entries arr[lo, hi) in rounds of 16: the 8 dword loads of a round are independent
-// (one memory latency per round instead of one per entry -- a per-entry load/compare/branch loop is a
-// serial latency chain and made the lookups latency bound).  f(value, position) is called for every
-// entry of the range.  arr must be 4-byte aligned and padded by 2 entries.
+// Visit the u16 entries arr[lo, hi) in rounds of 2*DWORDS entries fetched with 16-byte loads (one memory
+// latency per round instead of one per entry -- a per-entry load/compare/branch loop is a serial latency
+// chain and made the lookups latency bound).  f(value, position) is called for every entry of the range.
+// arr must be 4-byte aligned and padded by 32 bytes.
 template <uint32_t DWORDS = 8, typename F>
 __device__ __forceinline__ void scan_u16_range(const uint16_t *__restrict__ arr, uint32_t lo, uint32_t hi, F f) {
+    static_assert(DWORDS % 4 == 0, "rounds are made of 16-byte loads");
     const uint32_t *__restrict__ w = reinterpret_cast<const uint32_t *>(arr);
     for (uint32_t p = lo & ~1u; p < hi; p += 2u * DWORDS) {
-        uint32_t d[DWORDS];
+        U32x4 v[DWORDS / 4];  // unconditional: the tables are padded by 32 bytes
 #pragma unroll
-        for (uint32_t k = 0; k < DWORDS; k++) d[k] = (p + 2u * k < hi) ? w[(p >> 1) + k] : 0u;
+        for (uint32_t k = 0; k < DWORDS / 4; k++) v[k] = *reinterpret_cast<const U32x4 *>(w + (p >> 1) + 4u * k);
 #pragma unroll
         for (uint32_t k = 0; k < 2u * DWORDS; k++) {
             const uint32_t pos = p + k;
-            if (pos >= lo && pos < hi) f((d[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu, pos);
+            if (pos >= lo && pos < hi) f((v[k >> 3].w[(k >> 1) & 3u] >> (16u * (k & 1u))) & 0xFFFFu, pos);
         }
     }
 }
@@ -52,12 +53,25 @@ __device__ __forceinline__ uint32_t wl_lookup(const WlView &w, uint32_t key) {
     // (the low bitsB bits) inside the bin is an exact test
     const uint32_t bin = (uint32_t)((uint64_t)key >> w.shiftE);
     const uint32_t tail = key & ((1u << w.bitsB) - 1u);
-    const uint32_t lo = w.offE[bin];
-    const uint32_t hi = w.offE[bin + 1];
+    // both bounds of the bin in one 8-byte load, then its first 8 entries in one 16-byte load (the tables
+    // are padded by 32 bytes): two memory instructions and two cache lines per lookup
+    const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offE + bin);
+    const uint32_t lo = b2.a, hi = b2.b;
     uint32_t found = 0xFFFFFFFFu;
-    scan_u16_range<4>(w.tailA, lo, hi, [&](uint32_t t, uint32_t pos) {
-        if (t == tail) found = pos;
-    });
+    if (hi > lo) {
+        const uint32_t p0 = lo & ~1u;
+        const U32x4 d = *reinterpret_cast<const U32x4 *>(reinterpret_cast<const uint32_t *>(w.tailA) + (lo >> 1));
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t pos = p0 + k;
+            const uint32_t t = (d.w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+            if (pos >= lo && pos < hi && t == tail) found = pos;
+        }
+        if (hi > p0 + 8u && found == 0xFFFFFFFFu)  // a bin of more than 7 keys: rare
+            scan_u16_range<4>(w.tailA, p0 + 8u, hi, [&](uint32_t t, uint32_t pos) {
+                if (t == tail) found = pos;
+            });
+    }
     if (found == 0xFFFFFFFFu) return found;
     return w.valA ? w.valA[found] : found;
 }
