@@ -73,8 +73,8 @@ __device__ __forceinline__ unsigned long long block_reserve_256(uint32_t my_coun
 // the two mask halves; ranks from v_mbcnt; the running count is a plain LDS read by every lane followed by
 // a write from the lowest lane of each group (a wave runs in lockstep and its LDS operations complete in
 // order, so no atomic or cross-lane shuffle is needed).  FULL: every lane holds a live element.
-template <int BITS, bool FULL>
-__device__ __forceinline__ uint32_t wave_multisplit_rank(uint32_t d, bool ok, uint32_t *__restrict__ wc) {
+template <int BITS, bool FULL, typename C = uint32_t>
+__device__ __forceinline__ uint32_t wave_multisplit_rank(uint32_t d, bool ok, C *__restrict__ wc) {
     uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
     if (!FULL) {
         const unsigned long long live = __ballot(ok);
@@ -93,7 +93,7 @@ __device__ __forceinline__ uint32_t wave_multisplit_rank(uint32_t d, bool ok, ui
     uint32_t prev = 0;
     if (FULL || ok) {
         prev = wc[d];
-        if (below == 0) wc[d] = prev + cnt;
+        if (below == 0) wc[d] = (C)(prev + cnt);
     }
     return prev + below;
 }

@@ -61,7 +61,7 @@ extern "C" int crgpu_create(crgpu_ctx **out, int device_id) {
     if (hipMalloc(&ctx->d_ptab, sizeof(ptab)) != hipSuccess ||
         hipMemcpy(ctx->d_ptab, ptab, sizeof(ptab), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->d_scalars, 4096) != hipSuccess || hipMemset(ctx->d_scalars, 0, 4096) != hipSuccess ||
-        hipMalloc(&ctx->d_sort_hist, sizeof(uint32_t) * 256 * 2048) != hipSuccess) {
+        hipMalloc(&ctx->d_sort_hist, sizeof(uint32_t) * (256 * 2048 + 512)) != hipSuccess) {
         crgpu_destroy(ctx);
         return cr_fail(nullptr, CRGPU_ENOMEM, "crgpu_create: device allocation failed");
     }
