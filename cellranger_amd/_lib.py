@@ -52,6 +52,7 @@ class MatrixView(C.Structure):
         ("indptr", C.c_void_p),
         ("indices", C.c_void_p),
         ("data", C.c_void_p),
+        ("gem_group", C.c_void_p),
     ]
 
 
@@ -144,9 +145,11 @@ SYMBOLS = {
     "crgpu_counts_triplets_dev": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "crgpu_counts_triplets": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "crgpu_counts_molecules": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "crgpu_counts_molecule_info": (_i, [_vp, _vp, C.c_uint16, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "crgpu_counts_free": (None, [_vp, _vp]),
     "crgpu_assemble_matrix": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_matrix_free": (None, [_vp, C.POINTER(MatrixView)]),
+    "crgpu_concat_matrices": (_i, [_vp, _vp, _vp, _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_write_mtx": (_i, [_vp, C.POINTER(MatrixView), C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint16]),
     "crgpu_assemble_matrix_dev": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(MatrixDevView))]),
     "crgpu_matrix_dev_free": (None, [_vp, C.POINTER(MatrixDevView)]),

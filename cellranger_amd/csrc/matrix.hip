@@ -15,7 +15,51 @@ struct MatrixImpl {
     std::vector<uint32_t> rank, seq;
     std::vector<int64_t> indptr;
     std::vector<int32_t> indices, data;
+    std::vector<uint16_t> gem_group;
 };
+
+// BarcodeIndex (cr_types/src/barcode_index.rs:20-53) as a map rank -> column, 0xFFFFFFFF for unseen barcodes
+static int column_of_rank(crgpu_ctx *ctx, std::vector<uint32_t> &col_of_rank) {
+    const uint32_t W = ctx->n_canon;
+    std::vector<uint8_t> seen(W, 0);
+    std::vector<uint32_t> tmp(W);
+    for (int l = 0; l < CRGPU_MAX_LIB; l++) {
+        if (!ctx->wl[l].set) continue;
+        for (int which = 0; which < 2; which++) {
+            CR_TRY(crgpu_memcpy_d2h(ctx, tmp.data(), which ? ctx->wl[l].d_corrected : ctx->wl[l].d_valid, sizeof(uint32_t) * W));
+            for (uint32_t r = 0; r < W; r++) seen[r] |= tmp[r] != 0;
+        }
+    }
+    col_of_rank.assign(W, 0xFFFFFFFFu);
+    uint32_t c = 0;
+    for (uint32_t r = 0; r < W; r++)
+        if (seen[r]) col_of_rank[r] = c++;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_counts_molecule_info(crgpu_ctx *ctx, const crgpu_counts *c, uint16_t gem_group, uint16_t *gem_group_out,
+                                          uint64_t *barcode_idx_out, uint32_t *feature_idx_out, uint16_t *library_idx_out,
+                                          uint32_t *umi_out, uint32_t *count_out, uint32_t *umi_type_out) {
+    if (!ctx || !c) return CRGPU_EINVAL;
+    CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_counts_molecule_info: no whitelist set");
+    uint64_t nt = 0, nm = 0;
+    CR_TRY(crgpu_counts_info(ctx, c, &nt, &nm));
+    if (!nm) return CRGPU_OK;
+    std::vector<uint32_t> bc(nm);
+    std::vector<uint8_t> lib(nm), ut(nm);
+    CR_TRY(crgpu_counts_molecules(ctx, c, bc.data(), lib.data(), feature_idx_out, umi_out, count_out, ut.data()));
+    std::vector<uint32_t> col;
+    CR_TRY(column_of_rank(ctx, col));
+    for (uint64_t i = 0; i < nm; i++) {
+        CR_REQUIRE(ctx, col[bc[i]] != 0xFFFFFFFFu, CRGPU_ESTATE,
+                   "crgpu_counts_molecule_info: a molecule's barcode has no read in the context's histograms");
+        if (gem_group_out) gem_group_out[i] = gem_group;
+        if (barcode_idx_out) barcode_idx_out[i] = col[bc[i]];
+        if (library_idx_out) library_idx_out[i] = lib[i];
+        if (umi_type_out) umi_type_out[i] = ut[i];
+    }
+    return CRGPU_OK;
+}
 
 extern "C" int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const uint32_t *feature, const uint32_t *count,
                                      uint64_t n_triplets, uint32_t n_features, crgpu_matrix **out) {
@@ -91,6 +135,47 @@ extern "C" int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const u
     m->view.indptr = m->indptr.data();
     m->view.indices = m->indices.data();
     m->view.data = m->data.data();
+    m->view.gem_group = nullptr;
+    *out = &m->view;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_concat_matrices(crgpu_ctx *ctx, const crgpu_matrix *const *mats, const uint16_t *gem_groups,
+                                     uint32_t n_mats, crgpu_matrix **out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    *out = nullptr;
+    CR_REQUIRE(ctx, n_mats >= 1 && mats && gem_groups, CRGPU_EINVAL, "crgpu_concat_matrices: nothing to merge");
+    for (uint32_t i = 0; i < n_mats; i++) {
+        CR_REQUIRE(ctx, mats[i] != nullptr, CRGPU_EINVAL, "crgpu_concat_matrices: NULL matrix %u", i);
+        CR_REQUIRE(ctx, mats[i]->gem_group == nullptr, CRGPU_EINVAL, "crgpu_concat_matrices: matrix %u is already a merge", i);
+        CR_REQUIRE(ctx, mats[i]->n_features == mats[0]->n_features && mats[i]->cb_len == mats[0]->cb_len, CRGPU_EINVAL,
+                   "crgpu_concat_matrices: matrix %u has another feature space or barcode length", i);
+        CR_REQUIRE(ctx, i == 0 || gem_groups[i] > gem_groups[i - 1], CRGPU_EINVAL,
+                   "crgpu_concat_matrices: gem groups must be strictly ascending");
+    }
+    MatrixImpl *m = new (std::nothrow) MatrixImpl();
+    if (!m) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
+    m->indptr.push_back(0);
+    for (uint32_t i = 0; i < n_mats; i++) {
+        const crgpu_matrix &a = *mats[i];
+        const int64_t shift = (int64_t)m->data.size();
+        m->rank.insert(m->rank.end(), a.barcode_rank, a.barcode_rank + a.n_barcodes);
+        m->seq.insert(m->seq.end(), a.barcode_seq, a.barcode_seq + a.n_barcodes);
+        m->gem_group.insert(m->gem_group.end(), a.n_barcodes, gem_groups[i]);
+        for (uint64_t c = 0; c < a.n_barcodes; c++) m->indptr.push_back(shift + a.indptr[c + 1]);
+        m->indices.insert(m->indices.end(), a.indices, a.indices + a.nnz);
+        m->data.insert(m->data.end(), a.data, a.data + a.nnz);
+    }
+    m->view.n_barcodes = m->rank.size();
+    m->view.nnz = m->data.size();
+    m->view.n_features = mats[0]->n_features;
+    m->view.cb_len = mats[0]->cb_len;
+    m->view.barcode_rank = m->rank.data();
+    m->view.barcode_seq = m->seq.data();
+    m->view.indptr = m->indptr.data();
+    m->view.indices = m->indices.data();
+    m->view.data = m->data.data();
+    m->view.gem_group = m->gem_group.data();
     *out = &m->view;
     return CRGPU_OK;
 }
@@ -123,7 +208,7 @@ extern "C" int crgpu_write_mtx(crgpu_ctx *ctx, const crgpu_matrix *m, const char
         for (uint64_t c = 0; c < m->n_barcodes; c++) {
             for (uint32_t p = 0; p < m->cb_len; p++) buf[p] = acgt[(m->barcode_seq[c] >> (2 * (m->cb_len - 1 - p))) & 3u];
             buf[m->cb_len] = 0;
-            fprintf(f, "%s-%u\n", buf, (unsigned)gem_group);  // Barcode Display: "{content}-{gem_group}" (barcode/src/lib.rs:197-201)
+            fprintf(f, "%s-%u\n", buf, (unsigned)(m->gem_group ? m->gem_group[c] : gem_group));  // Barcode Display: "{content}-{gem_group}" (barcode/src/lib.rs:197-201)
         }
         fclose(f);
     }

@@ -132,6 +132,7 @@ class Matrix:
         self.indptr = arr(m.indptr, np.int64, self.n_barcodes + 1)
         self.indices = arr(m.indices, np.int32, self.nnz)
         self.data = arr(m.data, np.int32, self.nnz)
+        self.gem_group = arr(m.gem_group, np.uint16, self.n_barcodes) if m.gem_group else None
 
     def barcodes_ascii(self):
         return unpack_seqs(self.barcode_seq, self.cb_len)
@@ -210,6 +211,18 @@ class Counts:
             self.ctx._check(self.ctx.L.crgpu_counts_molecules(self.ctx.h, self.h, ptr(out["bc"]), ptr(out["lib"]),
                                                               ptr(out["feature"]), ptr(out["umi"]),
                                                               ptr(out["read_count"]), ptr(out["utype"])))
+        return out
+
+    def molecule_info(self, gem_group=1):
+        """the datasets MoleculeInfoWriter::fill appends (cr_h5/src/molecule_info.rs:972-998)"""
+        n = self.n_molecules
+        out = dict(gem_group=np.zeros(n, np.uint16), barcode_idx=np.zeros(n, np.uint64), feature_idx=np.zeros(n, np.uint32),
+                   library_idx=np.zeros(n, np.uint16), umi=np.zeros(n, np.uint32), count=np.zeros(n, np.uint32),
+                   umi_type=np.zeros(n, np.uint32))
+        if n:
+            self.ctx._check(self.ctx.L.crgpu_counts_molecule_info(
+                self.ctx.h, self.h, gem_group, ptr(out["gem_group"]), ptr(out["barcode_idx"]), ptr(out["feature_idx"]),
+                ptr(out["library_idx"]), ptr(out["umi"]), ptr(out["count"]), ptr(out["umi_type"])))
         return out
 
     def free(self):
@@ -401,6 +414,14 @@ class Context:
         self._check(self.L.crgpu_count_records_dev(self.h, C.byref(recs), C.byref(h), _p(d_processed_umi), _p(d_read_count),
                                                    _p(d_dupflags)))
         return Counts(self, h)
+
+    def concat_matrices(self, mats, gem_groups):
+        """merged matrix of several GEM wells: column concatenation in (gem_group, barcode) order"""
+        arr = (C.c_void_p * len(mats))(*[C.cast(m._mv, C.c_void_p) for m in mats])
+        gg = np.ascontiguousarray(gem_groups, dtype=np.uint16)
+        mv = C.POINTER(MatrixView)()
+        self._check(self.L.crgpu_concat_matrices(self.h, arr, ptr(gg), len(mats), C.byref(mv)))
+        return Matrix(self, mv)
 
     def assemble_matrix(self, bc, feature, count, n_features):
         bc = np.ascontiguousarray(bc, np.uint32)

@@ -124,6 +124,12 @@ class HipBackend:
         self._keep.append(m)
         return m
 
+    def csc_tensors(self, m):
+        """(barcode rank [V], indptr [V+1] i64, indices [nnz], data [nnz]) of a device CSC as aliasing tensors"""
+        v = m._mv.contents
+        return (self._tensor(v.d_barcode_rank, m.n_barcodes, "<i4"), self._tensor(v.d_indptr, m.n_barcodes + 1, "<i8"),
+                self._tensor(v.d_indices, m.nnz, "<i4"), self._tensor(v.d_data, m.nnz, "<i4"))
+
 
 class CountPipeline:
     """barcode-correct -> UMI-dedup -> matrix for one shard of reads per rank."""
@@ -191,6 +197,59 @@ class CountPipeline:
         self.be.match_and_count(shard)
         self._allreduce_hist(COUNTS_VALID)
         self.be.correct(shard)
+
+    def run_wells(self, shard):
+        """BASELINE configs[4]: every rank holds ONE WHOLE GEM well (gem group = rank + 1).  The wells are independent
+        (no C1/C2: barcodes of different gem groups never meet), each rank runs the single-GPU path; the only exchange
+        is the gather of the per-well CSC blocks.  Rank 0 returns the merged matrix as a dict of tensors
+        (barcode_rank, gem_group, indptr, indices, data): column concatenation in (gem_group, barcode) order
+        (barcode/src/lib.rs:119-124); other ranks return None."""
+        import torch
+
+        self.be.match_and_count(shard)
+        self.be.correct(shard)
+        keys, n_keys = self.be.build_keys(shard)
+        counts = self.be.count_keys(keys, n_keys)
+        b, f, c = self.be.triplet_arrays(counts)
+        m = self.be.assemble(b, f, c, counts.n_triplets)
+        rank_t, indptr_t, indices_t, data_t = self.be.csc_tensors(m)
+        dev = rank_t.device
+        if self.dist is None:
+            V = int(rank_t.numel())
+            return dict(barcode_rank=rank_t, gem_group=torch.ones(V, dtype=torch.int32, device=dev), indptr=indptr_t,
+                        indices=indices_t, data=data_t)
+        self.be.before_collective()
+        mine = torch.tensor([rank_t.numel(), indices_t.numel()], dtype=torch.int64, device=dev)
+        sizes = torch.zeros(2 * self.world, dtype=torch.int64, device=dev)
+        self.dist.all_gather_into_tensor(sizes, mine)
+        sizes = [int(x) for x in sizes.tolist()]
+        Vs, NZs = sizes[0::2], sizes[1::2]
+
+        def gather(src, per_rank, dtype):
+            n = int(src.numel())
+            total = sum(per_rank) if self.rank == 0 else 0
+            dst = torch.empty(total, dtype=dtype, device=dev)
+            self.dist.all_to_all_single(dst, src.contiguous(), output_split_sizes=per_rank if self.rank == 0 else [0] * self.world,
+                                        input_split_sizes=[n] + [0] * (self.world - 1))
+            return dst
+
+        ranks = gather(rank_t, Vs, torch.int32)
+        ends = gather(indptr_t[1:], Vs, torch.int64)  # column ends relative to the well's own block
+        indices = gather(indices_t, NZs, torch.int32)
+        data = gather(data_t, NZs, torch.int32)
+        self.be.after_collective()
+        if self.rank != 0:
+            return None
+        shift = torch.zeros(sum(Vs), dtype=torch.int64, device=dev)
+        gg = torch.zeros(sum(Vs), dtype=torch.int32, device=dev)
+        v0 = nz0 = 0
+        for r in range(self.world):
+            shift[v0:v0 + Vs[r]] = nz0
+            gg[v0:v0 + Vs[r]] = r + 1
+            v0 += Vs[r]
+            nz0 += NZs[r]
+        indptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), ends + shift])
+        return dict(barcode_rank=ranks, gem_group=gg, indptr=indptr, indices=indices, data=data)
 
     def run(self, shard):
         """Full path.  Returns the device CSC on rank 0 (None elsewhere)."""

@@ -226,6 +226,15 @@ int crgpu_counts_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t **
                               uint32_t **d_count);
 int crgpu_counts_triplets(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint32_t *feature_out,
                           uint32_t *count_out);
+/* The molecule table as the datasets MoleculeInfoWriter::fill appends (cr_h5/src/molecule_info.rs:972-998), one
+ * entry per UmiCount in the order ALIGN_AND_COUNT emits them (barcodes ascending, inside a barcode sorted as
+ * align_and_count.rs:314): gem_group (constant), barcode_idx = position of the barcode in the BarcodeIndex of this
+ * context (== matrix column), feature_idx, library_idx, umi (2-bit), count (reads), umi_type (UmiType::to_u32: 0 Txomic,
+ * 1 NonTxomic).  n_molecules entries each (crgpu_counts_info), host pointers, any may be NULL.  probe_idx is not
+ * produced (probe alignments are not an input of this path). */
+int crgpu_counts_molecule_info(crgpu_ctx *ctx, const crgpu_counts *c, uint16_t gem_group, uint16_t *gem_group_out,
+                               uint64_t *barcode_idx_out, uint32_t *feature_idx_out, uint16_t *library_idx_out,
+                               uint32_t *umi_out, uint32_t *count_out, uint32_t *umi_type_out);
 /* molecule table: bc rank, library, feature, 2-bit umi, read_count, utype (0 Txomic,1 NonTxomic) */
 int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint8_t *lib_out,
                            uint32_t *feature_out, uint32_t *umi_out, uint32_t *read_count_out,
@@ -246,12 +255,18 @@ typedef struct {
     const int64_t *indptr;         /* V + 1 */
     const int32_t *indices;        /* nnz  (written as int64 on disk, count_matrix.rs:399) */
     const int32_t *data;           /* nnz */
+    const uint16_t *gem_group;     /* V gem groups of a merged matrix (crgpu_concat_matrices), else NULL */
 } crgpu_matrix;
 /* triplets may come from several ranks (concatenated in any order of disjoint barcodes; they are
  * re-sorted by barcode here).  Host arrays. */
 int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const uint32_t *feature, const uint32_t *count,
                           uint64_t n_triplets, uint32_t n_features, crgpu_matrix **out);
 void crgpu_matrix_free(crgpu_ctx *ctx, crgpu_matrix *m);
+/* Several GEM wells of one sample (BASELINE configs[4]: one well per GPU): the merged matrix is the column
+ * concatenation in (gem_group, barcode) order -- Barcode orders by gem group first (barcode/src/lib.rs:119-124).
+ * gem_groups[i] is the group of mats[i], strictly ascending; all matrices share n_features and cb_len. */
+int crgpu_concat_matrices(crgpu_ctx *ctx, const crgpu_matrix *const *mats, const uint16_t *gem_groups, uint32_t n_mats,
+                          crgpu_matrix **out);
 /* write_matrix_mtx body (cr_lib/src/stages/write_matrix_market.rs:80-122), uncompressed text;
  * metadata_line is the full "%metadata_json: ..." line.  gem_group suffixes barcodes.tsv rows. */
 int crgpu_write_mtx(crgpu_ctx *ctx, const crgpu_matrix *m, const char *metadata_line, const char *mtx_path,

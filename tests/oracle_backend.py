@@ -170,6 +170,10 @@ class OracleBackend:
         arrs = [np.zeros(n, np.uint32) for _ in range(3)]
         return arrs, [torch.from_numpy(a.view(np.int32)) for a in arrs]
 
+    def csc_tensors(self, m):
+        return (torch.from_numpy(m.barcode_rank.view(np.int32)), torch.from_numpy(m.indptr.astype(np.int64)),
+                torch.from_numpy(m.indices.astype(np.int32)), torch.from_numpy(m.data.astype(np.int32)))
+
     def assemble(self, bc, ft, ct, n_triplets):
         seen = np.zeros(self.n_canon, bool)
         for which in (COUNTS_VALID, COUNTS_CORRECTED):

@@ -1,0 +1,110 @@
+"""Down-scaled parity cases of BASELINE.json configs[3] (Feature Barcoding: reads matched against a feature
+reference, then counted) and configs[4] (several GEM wells, one per GPU, merged matrix), through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg4_feature_barcoding_match_then_count_bit_exact():
+    """Antibody-Capture style library: the feature of a read is not given by an aligner but found by matching a
+    15-base capture against the feature reference (exact, else posterior-corrected with the feature distribution:
+    feature_extraction.rs:34-117), then barcode correction, UMI dedup and the matrix as for any library."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import NO_FEATURE
+
+    n, n_feat, L = 100_000, 48, 15
+    rng = np.random.default_rng(44)
+    w = S.Workload(n_total=n, seed=44, n_wl=3000, n_cells=60, n_ambient=300, n_genes=n_feat, reads_per_umi=3)
+    r = w.host_reads(0, n)
+    true_feat = r["feature"].copy()
+    feats = np.unique(rng.integers(0, 1 << 30, size=4 * n_feat, dtype=np.uint64))[:n_feat].astype(np.uint32)
+    feat_ascii = E.unpack_seqs(rng.permutation(feats), L)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seq = np.where((true_feat != NO_FEATURE)[:, None], feat_ascii[np.minimum(true_feat, n_feat - 1)], acgt[rng.integers(0, 4, (n, L))])
+    u = rng.random(n)
+    for i in np.nonzero(u < 0.12)[0]:  # one substitution, sometimes an N
+        seq[i, rng.integers(0, L)] = ord("N") if u[i] < 0.02 else acgt[rng.integers(0, 4)]
+    qual = rng.choice(np.array([35, 44, 58, 70], np.uint8), size=(n, L))
+    # feature distribution from the exact matches, as MAKE_SHARD collects it (make_shard_metrics.rs:338-352)
+    lut = {bytes(f): i for i, f in enumerate(feat_ascii)}
+    exact = np.array([lut.get(bytes(s), -1) for s in seq])
+    dist = O.compute_feature_dist(np.bincount(exact[exact >= 0], minlength=n_feat), np.zeros(n_feat, np.uint32))
+
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    c.set_feature_pattern(0, feat_ascii, np.arange(n_feat, dtype=np.uint32), dist)
+    code = np.full(256, 0, np.uint32)
+    code[acgt] = np.arange(4)
+    pk = np.zeros(n, np.uint32)
+    for j in range(L):
+        pk = (pk << np.uint32(2)) | code[seq[:, j]]
+    qn = (qual | np.where(seq == ord("N"), 0x80, 0)).astype(np.uint8)
+    d_feature = c.empty(n, np.uint32)
+    c.match_features(0, c.upload(pk), c.upload(qn), n, d_feature)
+    got_feat = d_feature.to_host()
+    exp_feat = np.array([O.find_closest_feature(feat_ascii, dist, bytes(seq[i]), bytes(qual[i])) for i in range(n)])
+    exp_feat = np.where(exp_feat < 0, NO_FEATURE, exp_feat).astype(np.uint32)
+    assert np.array_equal(got_feat, exp_feat)
+    assert (exp_feat != NO_FEATURE).mean() > 0.8 and (exp_feat != np.where(exact < 0, NO_FEATURE, exact)).sum() > 1000
+
+    # barcode stage + count stage with the matched features (device resident end to end)
+    idx_a, idx_b, corr, dev = G.gpu_barcode_stage(c, r, n)
+    c.set_key_layout(n_feat, w.umi_len, 1, 0)
+    recs = c.records(n, w.umi_len, dev["idx"], c.upload(r["umi"]), c.upload(r["umi_qualn"]), d_feature, dev["flags"])
+    m = c.count(recs, n_feat)
+    r2 = dict(r)
+    r2["feature"] = exp_feat
+    res = O.run_pipeline(G.oracle_reads_from_packed(r2, w.cb_len, w.umi_len), [O.Whitelist(E.unpack_seqs(w.wl_packed, 16))],
+                         n_threads=4)
+    assert np.array_equal(m.barcodes_ascii(), res.barcodes)
+    assert np.array_equal(m.indptr, res.indptr) and np.array_equal(m.indices, res.indices) and np.array_equal(m.data, res.data)
+    assert m.nnz > 1000
+    c.close()
+
+
+def test_cfg5_wells_counted_separately_then_merged(tmp_path):
+    """Two GEM wells of one sample, each counted on its own (same whitelist, different cells and molecules), merged
+    through crgpu_concat_matrices: columns in (gem_group, barcode) order, barcodes.tsv rows carry the well suffix."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+
+    n = 120_000
+    w = S.Workload(n_total=2 * n, seed=55, n_wl=20_000, n_cells=80, n_ambient=2000, n_genes=300)
+    wl = O.Whitelist(E.unpack_seqs(w.wl_packed, 16))
+    mats, oracle = [], []
+    ctxs = []
+    for well in range(2):
+        c = G.fresh_ctx()
+        ctxs.append(c)
+        c.set_whitelist(0, w.wl_packed, length=16)
+        c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+        r = w.host_reads(well * n, n)
+        idx_a, idx_b, corr, dev = G.gpu_barcode_stage(c, r, n)
+        recs = c.records(n, w.umi_len, dev["idx"], c.upload(r["umi"]), c.upload(r["umi_qualn"]), c.upload(r["feature"]), dev["flags"])
+        mats.append(c.count(recs, w.n_genes))
+        oracle.append(O.run_pipeline(G.oracle_reads_from_packed(r, 16, w.umi_len), [wl], n_threads=4))
+    merged = ctxs[0].concat_matrices(mats, [1, 2])
+    exp_barcodes = np.concatenate([o.barcodes for o in oracle])
+    exp_indptr = np.concatenate([oracle[0].indptr, oracle[1].indptr[1:] + oracle[0].indptr[-1]])
+    assert np.array_equal(merged.barcodes_ascii(), exp_barcodes)
+    assert np.array_equal(merged.gem_group, np.repeat([1, 2], [len(o.barcodes) for o in oracle]).astype(np.uint16))
+    assert np.array_equal(merged.indptr, exp_indptr)
+    assert np.array_equal(merged.indices, np.concatenate([o.indices for o in oracle]))
+    assert np.array_equal(merged.data, np.concatenate([o.data for o in oracle]))
+    p_mtx, p_bc = tmp_path / "m.mtx", tmp_path / "barcodes.tsv"
+    merged.write_mtx(p_mtx, p_bc)
+    rows = open(p_bc).read().split()
+    assert rows[0] == bytes(exp_barcodes[0]).decode() + "-1" and rows[-1] == bytes(exp_barcodes[-1]).decode() + "-2"
+    assert len(rows) == len(exp_barcodes) and merged.nnz > 1000
+    # not a merge of merges, and the groups must ascend
+    from cellranger_amd._lib import CrgpuError
+    with pytest.raises(CrgpuError):
+        ctxs[0].concat_matrices(mats, [2, 1])
+    for c in ctxs:
+        c.close()

@@ -20,6 +20,7 @@ def _run_gpu(c, r, n, w_cb_len, umi_len, n_features, n_libs=1, mux_mask=0):
     counts = c.count_keys(d_keys, nk)
     bc, ft, ct = counts.triplets()
     mol = counts.molecules()
+    mol["info"] = counts.molecule_info(gem_group=1)
     m = c.assemble_matrix(bc, ft, ct, n_features)
     # the one-call convenience entry point must agree
     m2 = c.count(recs, n_features)
@@ -69,6 +70,13 @@ def _compare_with_oracle(c, w, r, n, n_features, n_libs=1, mux_mask=0, whitelist
     assert np.array_equal(mol["umi"], res.mol["umi"])
     assert np.array_equal(mol["read_count"], res.mol["read_count"])
     assert np.array_equal(mol["utype"], res.mol["utype"])
+    # molecule_info.h5 datasets (MoleculeInfoWriter::fill, cr_h5/src/molecule_info.rs:972-998)
+    info = mol["info"]
+    assert np.array_equal(info["barcode_idx"], res.mol_bc_col.astype(np.uint64))
+    assert np.array_equal(info["library_idx"], res.mol_lib.astype(np.uint16))
+    assert np.array_equal(info["feature_idx"], res.mol["feature_idx"]) and np.array_equal(info["umi"], res.mol["umi"])
+    assert np.array_equal(info["count"], res.mol["read_count"])
+    assert np.array_equal(info["umi_type"], res.mol["utype"].astype(np.uint32)) and (info["gem_group"] == 1).all()
     return res, m
 
 

@@ -85,6 +85,14 @@ def test_pipeline_collective_path_on_one_rank_rccl_group():
             be.reset()
             m = pipe.run(shard)
         _check_against_oracle(c, w, r, m)
+        # one-well-per-rank mode (BASELINE configs[4]): the CSC gather on the 1-rank group returns the same matrix
+        be.reset()
+        merged = pipe.run_wells(shard)
+        rank, indptr, indices, data = m.download()
+        assert np.array_equal(merged["barcode_rank"].cpu().numpy().view(np.uint32), rank)
+        assert np.array_equal(merged["indptr"].cpu().numpy(), indptr)
+        assert np.array_equal(merged["indices"].cpu().numpy(), indices) and np.array_equal(merged["data"].cpu().numpy(), data)
+        assert (merged["gem_group"].cpu().numpy() == 1).all()
         c.close()
     finally:
         dist.destroy_process_group()
