@@ -5,10 +5,17 @@
 // (cr_lib/src/barcode_sort.rs:97-162, par_proc.rs:131-152); integer work, HBM bound: every pass
 // streams the keys once for the digit histogram and once for the scatter.
 //
-// One pass = 3 launches:
+// 64-bit keys without payload (the molecule-key sort): "onesweep" -- k_global_hist counts the digits of ALL
+// passes in one read of the keys, then one k_radix_scatter<..., ONESWEEP> launch per pass whose chunks get
+// their global offsets from a decoupled look-back (no per-pass histogram read).  CRGPU_SORT=classic selects
+// the path below for these keys too.
+// Other sorts (32-bit hashes + payload, keys + read ordinals, the partition by owner rank): one pass = 3 launches:
 //   k_radix_hist     per-block digit histogram           -> block_hist[digit][block]
 //   k_scan_digits    one workgroup per digit: exclusive scan over blocks + digit total
 //   k_radix_scatter  stable scatter; each block derives its digit bases from the digit totals
+#include <cstdlib>
+#include <cstring>
+
 #include "block_utils.h"
 #include "common.h"
 
@@ -118,7 +125,7 @@ struct SortCfg {
     // global deltas, scan scratch
     static constexpr size_t lds_bytes(int bits) {
         return (size_t)CHUNK * (sizeof(K) + (HAS_VALS ? 4 : 0)) + (size_t)SORT_WAVES * (1u << bits) * 2 +
-               2 * (size_t)(1u << bits) * 4 + SORT_WAVES * 4;
+               2 * (size_t)(1u << bits) * 4 + SORT_WAVES * 4 + 16;
     }
 };
 
@@ -167,13 +174,25 @@ __global__ __launch_bounds__(256) void k_scan_digits(uint32_t *__restrict__ bloc
 // halves, ranks from v_mbcnt, and the per-(wave, digit) running count is a plain LDS read by every lane
 // followed by a write from the lowest lane of each digit group (a wave runs in lockstep and its LDS
 // operations complete in order, so no atomic or cross-lane shuffle is needed).
-template <typename K, bool HAS_VALS, typename DIG, int BITS>
+//
+// ONESWEEP: no per-block histogram pass.  Chunks are handed out by a ticket counter (so every chunk's
+// predecessors are already running or done), `digit_totals` holds the EXCLUSIVE prefix of the global digit
+// counts of this pass (k_global_hist counts all passes in one read of the keys), and the number of same-digit
+// keys in earlier chunks comes from a decoupled look-back over `status`: one 64-bit word per (chunk, digit),
+// flag in the top two bits (1 = this chunk's count, 2 = inclusive prefix up to this chunk), published with
+// agent-scope atomic stores.  A chunk publishes its counts before it starts waiting, and waits only on lower
+// tickets, so the chain always makes progress.
+#define OS_AGG (1ull << 62)
+#define OS_INC (2ull << 62)
+#define OS_VAL ((1ull << 62) - 1ull)
+template <typename K, bool HAS_VALS, typename DIG, int BITS, bool ONESWEEP = false>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
                                                               uint32_t *__restrict__ vals_out, uint64_t n, uint64_t tile,
                                                               DIG dig, const uint32_t *__restrict__ block_offs,
                                                               const uint32_t *__restrict__ digit_totals,
-                                                              uint32_t n_blocks) {
+                                                              uint32_t n_blocks, unsigned long long *__restrict__ status,
+                                                              uint32_t *__restrict__ ticket) {
     constexpr int ITEMS = SortCfg<K, HAS_VALS>::ITEMS;
     constexpr uint32_t CHUNK = SortCfg<K, HAS_VALS>::CHUNK;
     constexpr uint32_t RADIX_T = 1u << BITS;
@@ -188,14 +207,27 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
     uint32_t *lds = gdelta + RADIX_T;         // SORT_WAVES words of scan scratch
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-    {
+    uint32_t *s_chunk = lds + SORT_WAVES;     // ONESWEEP: the ticket of the current chunk
+
+    if (!ONESWEEP) {
         const uint32_t digit_base = block_excl_scan<SORT_BLOCK>(tid < RADIX_T ? digit_totals[tid] : 0u, lds, nullptr);
         if (tid < RADIX_T) base[tid] = digit_base + block_offs[(uint64_t)tid * n_blocks + blockIdx.x];
     }
-    const uint64_t lo = (uint64_t)blockIdx.x * tile;
-    const uint64_t hi = lo + tile < n ? lo + tile : n;
+    const uint64_t lo = ONESWEEP ? 0 : (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = ONESWEEP ? n : (lo + tile < n ? lo + tile : n);
+    const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
 
-    for (uint64_t chunk = lo; chunk < hi; chunk += CHUNK) {
+    for (uint64_t chunk = lo;; chunk += CHUNK) {
+        uint64_t cidx = 0;
+        if (ONESWEEP) {
+            if (tid == 0) *s_chunk = atomicAdd(ticket, 1u);
+            __syncthreads();
+            cidx = *s_chunk;
+            if (cidx >= n_chunks) break;  // uniform
+            chunk = cidx * CHUNK;
+        } else if (chunk >= hi) {
+            break;
+        }
         for (uint32_t x = tid; x < SORT_WAVES * RADIX_T; x += SORT_BLOCK) (&wcount[0][0])[x] = 0;
         __syncthreads();
 
@@ -238,11 +270,31 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             uint32_t tot = 0;
             if (tid < RADIX_T)
                 for (int w = 0; w < SORT_WAVES; w++) tot += wcount[w][tid];
+            unsigned long long *row = ONESWEEP ? status + cidx * RADIX_T : nullptr;
+            if (ONESWEEP && tid < RADIX_T)  // let the successors go on as early as possible
+                __hip_atomic_store(&row[tid], (cidx == 0 ? OS_INC : OS_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t run = block_excl_scan<SORT_BLOCK>(tot, lds, nullptr);  // chunk-local start of digit tid
             if (tid < RADIX_T) {
-                const uint32_t g = base[tid];
+                uint32_t g;
+                if (ONESWEEP) {
+                    unsigned long long excl = 0;
+                    if (cidx > 0) {
+                        for (uint64_t p = cidx - 1;; p--) {
+                            unsigned long long sv;
+                            while (((sv = __hip_atomic_load(&status[p * RADIX_T + tid], __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0ull)
+                                __builtin_amdgcn_s_sleep(1);
+                            excl += sv & OS_VAL;
+                            if ((sv >> 62) == 2ull) break;
+                        }
+                        __hip_atomic_store(&row[tid], OS_INC | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    g = digit_totals[tid] + (uint32_t)excl;
+                } else {
+                    g = base[tid];
+                    base[tid] = g + tot;
+                }
                 gdelta[tid] = g - run;
-                base[tid] = g + tot;
                 for (int w = 0; w < SORT_WAVES; w++) {
                     const uint32_t c = wcount[w][tid];
                     wcount[w][tid] = (uint16_t)run;
@@ -313,7 +365,7 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
             attr_kv = true;
         }
         hipLaunchKernelGGL((k_radix_scatter<K, true, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), lds_kv, ctx->stream,
-                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb);
+                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb, nullptr, nullptr);
     } else {
         if (!attr_k) {
             (void)hipFuncSetAttribute((const void *)k_radix_scatter<K, false, DIG, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -321,9 +373,119 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
             attr_k = true;
         }
         hipLaunchKernelGGL((k_radix_scatter<K, false, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), lds_k, ctx->stream,
-                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb);
+                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb, nullptr, nullptr);
     }
     CR_HIP(ctx, hipGetLastError());
+    return CRGPU_OK;
+}
+
+// ---- onesweep: all passes' digit histograms in one read of the keys -------------------------------------
+#define OS_MAX_PASSES 8
+struct SweepPlan {
+    uint32_t n_passes;
+    uint32_t shift[OS_MAX_PASSES], mask[OS_MAX_PASSES];
+};
+template <typename K>
+__global__ __launch_bounds__(SORT_BLOCK) void k_global_hist(const K *__restrict__ keys, uint64_t n, SweepPlan plan,
+                                                            uint32_t *__restrict__ ghist /* [pass][RADIX_MAX] */) {
+    __shared__ uint32_t h[OS_MAX_PASSES * RADIX_MAX];
+    for (uint32_t x = threadIdx.x; x < plan.n_passes * RADIX_MAX; x += SORT_BLOCK) h[x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * SORT_BLOCK * 4;
+    for (uint64_t base = (uint64_t)blockIdx.x * SORT_BLOCK * 4; base < n; base += stride) {
+        K k[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t i = base + (uint64_t)j * SORT_BLOCK + threadIdx.x;
+            k[j] = keys[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (base + (uint64_t)j * SORT_BLOCK + threadIdx.x >= n) continue;
+            for (uint32_t p = 0; p < plan.n_passes; p++)
+                atomicAdd(&h[p * RADIX_MAX + ((uint32_t)(k[j] >> plan.shift[p]) & plan.mask[p])], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < plan.n_passes * RADIX_MAX; x += SORT_BLOCK)
+        if (h[x]) atomicAdd(&ghist[x], h[x]);
+}
+// one workgroup per pass: exclusive prefix over the digits, in place
+__global__ __launch_bounds__(RADIX_MAX) void k_scan_global_hist(uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t lds[RADIX_MAX / 64];
+    uint32_t *row = ghist + (uint64_t)blockIdx.x * RADIX_MAX;
+    const uint32_t v = row[threadIdx.x];
+    row[threadIdx.x] = block_excl_scan<RADIX_MAX>(v, lds, nullptr);
+}
+
+static bool onesweep_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("CRGPU_SORT");
+        on = (e && strcmp(e, "classic") == 0) ? 0 : 1;  // CRGPU_SORT=classic: histogram pass per radix pass (A/B, fallback)
+    }
+    return on == 1;
+}
+
+// keys only, 64-bit: global histograms once, then one look-back scatter per pass
+static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, const SweepPlan &plan,
+                             const uint32_t *widths, bool *result_in_tmp) {
+    typedef SortCfg<uint64_t, false> Cfg;
+    const uint64_t n_chunks = (n + Cfg::CHUNK - 1) / Cfg::CHUNK;
+    void *d_small = nullptr, *d_status = nullptr;
+    const size_t small_bytes = (size_t)OS_MAX_PASSES * RADIX_MAX * 4 + OS_MAX_PASSES * 128;  // histograms + tickets (a line each)
+    CR_TRY(cr_pool_alloc(ctx, &d_small, small_bytes));
+    int rc = cr_pool_alloc(ctx, &d_status, n_chunks * RADIX_MAX * sizeof(unsigned long long));
+    if (rc != CRGPU_OK) {
+        cr_pool_free(ctx, d_small);
+        return rc;
+    }
+    uint32_t *ghist = (uint32_t *)d_small;
+    uint32_t *tickets = ghist + OS_MAX_PASSES * RADIX_MAX;
+    hipError_t e = hipMemsetAsync(d_small, 0, small_bytes, ctx->stream);
+    {
+        CrTimer t(ctx, CRGPU_T_SORT_HIST, n);
+        hipLaunchKernelGGL(k_global_hist<uint64_t>, dim3(256), dim3(SORT_BLOCK), 0, ctx->stream, d_keys, n, plan, ghist);
+        hipLaunchKernelGGL(k_scan_global_hist, dim3(plan.n_passes), dim3(RADIX_MAX), 0, ctx->stream, ghist);
+    }
+    static bool attr8 = false, attr9 = false;
+    uint64_t *in = d_keys, *out = d_tmp;
+    for (uint32_t p = 0; p < plan.n_passes && e == hipSuccess; p++) {
+        const bool wide = widths[p] == 9;
+        const size_t lds = Cfg::lds_bytes(wide ? 9 : 8);
+        const uint32_t radix = wide ? 512u : 256u;
+        RadixDigit dig{plan.shift[p], plan.mask[p]};
+        CrTimer t(ctx, CRGPU_T_SORT, n);
+        e = hipMemsetAsync(d_status, 0, n_chunks * radix * sizeof(unsigned long long), ctx->stream);
+        const dim3 grid((unsigned)(n_chunks < 512 ? n_chunks : 512));  // one workgroup fits per CU; the rest queue up for tickets
+        if (wide) {
+            if (!attr9) {
+                (void)hipFuncSetAttribute((const void *)k_radix_scatter<uint64_t, false, RadixDigit, 9, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr9 = true;
+            }
+            hipLaunchKernelGGL((k_radix_scatter<uint64_t, false, RadixDigit, 9, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
+                               out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, 0u,
+                               (unsigned long long *)d_status, tickets + p * 32);
+        } else {
+            if (!attr8) {
+                (void)hipFuncSetAttribute((const void *)k_radix_scatter<uint64_t, false, RadixDigit, 8, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr8 = true;
+            }
+            hipLaunchKernelGGL((k_radix_scatter<uint64_t, false, RadixDigit, 8, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
+                               out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, 0u,
+                               (unsigned long long *)d_status, tickets + p * 32);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        uint64_t *t2 = in;
+        in = out;
+        out = t2;
+        *result_in_tmp = !*result_in_tmp;
+    }
+    cr_pool_free(ctx, d_status);
+    cr_pool_free(ctx, d_small);
+    if (e != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "onesweep sort: %s", hipGetErrorString(e));
     return CRGPU_OK;
 }
 
@@ -341,6 +503,20 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
     uint32_t n9 = 0;
     if (p9 < p8 && total > 8 * p9) n9 = total - 8 * p9;  // 61 bits: 7 passes, 5 of them 9 bits wide
     const uint32_t passes = p9 < p8 ? p9 : p8;
+    if (sizeof(K) == 8 && !d_vals && onesweep_enabled() && passes <= OS_MAX_PASSES) {
+        SweepPlan plan;
+        uint32_t widths[OS_MAX_PASSES];
+        plan.n_passes = 0;
+        for (uint32_t pass = 0, sh = lo_bit; pass < passes && sh < hi_bit; pass++) {
+            const uint32_t width = pass >= passes - n9 ? 9u : 8u;
+            const uint32_t bits = hi_bit - sh < width ? hi_bit - sh : width;
+            plan.shift[plan.n_passes] = sh;
+            plan.mask[plan.n_passes] = (1u << bits) - 1u;
+            widths[plan.n_passes++] = width;
+            sh += width;
+        }
+        return onesweep_sort_u64(ctx, (uint64_t *)d_keys, (uint64_t *)d_tmp, n, plan, widths, result_in_tmp);
+    }
     uint32_t shift = lo_bit;
     for (uint32_t pass = 0; pass < passes && shift < hi_bit; pass++) {
         const bool wide = pass >= passes - n9;
