@@ -266,35 +266,16 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         __syncthreads();
         // one thread per digit: chunk-local start of the digit (exclusive scan over digits), per-wave
         // starts inside it, and the shift from LDS position to global position
+        uint32_t tot = 0, run0 = 0;
         {
-            uint32_t tot = 0;
             if (tid < RADIX_T)
                 for (int w = 0; w < SORT_WAVES; w++) tot += wcount[w][tid];
-            unsigned long long *row = ONESWEEP ? status + cidx * RADIX_T : nullptr;
             if (ONESWEEP && tid < RADIX_T)  // let the successors go on as early as possible
-                __hip_atomic_store(&row[tid], (cidx == 0 ? OS_INC : OS_AGG) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&status[cidx * RADIX_T + tid], (cidx == 0 ? OS_INC : OS_AGG) | tot, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             uint32_t run = block_excl_scan<SORT_BLOCK>(tot, lds, nullptr);  // chunk-local start of digit tid
+            run0 = run;
             if (tid < RADIX_T) {
-                uint32_t g;
-                if (ONESWEEP) {
-                    unsigned long long excl = 0;
-                    if (cidx > 0) {
-                        for (uint64_t p = cidx - 1;; p--) {
-                            unsigned long long sv;
-                            while (((sv = __hip_atomic_load(&status[p * RADIX_T + tid], __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0ull)
-                                __builtin_amdgcn_s_sleep(1);
-                            excl += sv & OS_VAL;
-                            if ((sv >> 62) == 2ull) break;
-                        }
-                        __hip_atomic_store(&row[tid], OS_INC | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    g = digit_totals[tid] + (uint32_t)excl;
-                } else {
-                    g = base[tid];
-                    base[tid] = g + tot;
-                }
-                gdelta[tid] = g - run;
                 for (int w = 0; w < SORT_WAVES; w++) {
                     const uint32_t c = wcount[w][tid];
                     wcount[w][tid] = (uint16_t)run;
@@ -310,6 +291,54 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                 skeys[p] = key[it];
                 if (HAS_VALS) svals[p] = val[it];
             }
+        }
+        // global start of every digit's run.  ONESWEEP: the look-back comes as late as possible (after the LDS
+        // scatter above) so that the predecessors have had time to publish
+        if (tid < RADIX_T) {
+            uint32_t g;
+            if (ONESWEEP) {
+                unsigned long long excl = 0;
+                if (cidx > 0) {
+                    auto wait_for = [&](uint64_t c, unsigned long long sv) {
+                        while ((sv >> 62) == 0ull) {
+                            __builtin_amdgcn_s_sleep(1);
+                            sv = __hip_atomic_load(&status[c * RADIX_T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        return sv;
+                    };
+                    // steady state: the predecessor already has its inclusive prefix (one load).  Otherwise (start
+                    // of a pass, when all resident chunks begin together) walk back eight chunks per round trip
+                    uint64_t p = cidx - 1;
+                    unsigned long long sv = wait_for(p, __hip_atomic_load(&status[p * RADIX_T + tid], __ATOMIC_RELAXED,
+                                                                          __HIP_MEMORY_SCOPE_AGENT));
+                    excl = sv & OS_VAL;
+                    bool done = (sv >> 62) == 2ull;
+                    while (!done) {
+                        const uint32_t nb = p < 8 ? (uint32_t)p : 8u;  // p > 0: chunk 0 always carries an inclusive prefix
+                        unsigned long long v[8];
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++)
+                            v[j] = j < nb ? __hip_atomic_load(&status[(p - 1 - j) * RADIX_T + tid], __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT)
+                                          : 0ull;
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) {
+                            if (done || j >= nb) continue;
+                            const unsigned long long x = wait_for(p - 1 - j, v[j]);
+                            excl += x & OS_VAL;
+                            done = (x >> 62) == 2ull;
+                        }
+                        p -= nb;
+                    }
+                    __hip_atomic_store(&status[cidx * RADIX_T + tid], OS_INC | (excl + tot), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                g = digit_totals[tid] + (uint32_t)excl;
+            } else {
+                g = base[tid];
+                base[tid] = g + tot;
+            }
+            gdelta[tid] = g - run0;
         }
         __syncthreads();
         for (uint32_t p = tid; p < chunk_n; p += SORT_BLOCK) {
