@@ -531,7 +531,9 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
     const uint32_t p8 = (total + 7) / 8, p9 = (total + 8) / 9;
     uint32_t n9 = 0;
     if (p9 < p8 && total > 8 * p9) n9 = total - 8 * p9;  // 61 bits: 7 passes, 5 of them 9 bits wide
-    const uint32_t passes = p9 < p8 ? p9 : p8;
+    if (const char *e = getenv("CRGPU_SORT_DIGITS"))     // "8": 8-bit digits only (A/B)
+        if (atoi(e) == 8) n9 = 0;
+    const uint32_t passes = n9 ? p9 : p8;
     if (sizeof(K) == 8 && !d_vals && onesweep_enabled() && passes <= OS_MAX_PASSES) {
         SweepPlan plan;
         uint32_t widths[OS_MAX_PASSES];
