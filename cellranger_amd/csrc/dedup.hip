@@ -293,10 +293,12 @@ __global__ __launch_bounds__(CP_BLOCK) void k_cp_write(Flag flag, Emit emit, uin
     uint32_t run = block_offs[blockIdx.x];
     for (uint64_t base = lo; base < hi; base += CP_ROUND) {
         bool f[CP_ITEMS];
+        typename Emit::Pre pre[CP_ITEMS];  // what the emit needs from memory, requested together with the flags
 #pragma unroll
         for (int j = 0; j < CP_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * CP_BLOCK + threadIdx.x;
             f[j] = flag(i < hi ? i : hi - 1);
+            pre[j] = emit.pre(i < hi ? i : hi - 1);
         }
         uint32_t below[CP_ITEMS];
 #pragma unroll
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_cp_write(Flag flag, Emit emit, uin
 #pragma unroll
         for (int j = 0; j < CP_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * CP_BLOCK + threadIdx.x;
-            if (f[j]) emit(i, run + ws[j * CP_WAVES + wave] + below[j]);
+            if (f[j]) emit(i, run + ws[j * CP_WAVES + wave] + below[j], pre[j]);
         }
         run += round_total;
         __syncthreads();
@@ -367,8 +369,10 @@ struct EmitRun {  // distinct key + start position of its run
     const uint64_t *keys;
     uint64_t *ukey;
     uint32_t *upos;
-    __device__ __forceinline__ void operator()(uint64_t i, uint32_t o) const {
-        ukey[o] = keys[i];
+    typedef uint64_t Pre;
+    __device__ __forceinline__ Pre pre(uint64_t i) const { return keys[i]; }
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t o, Pre key) const {
+        ukey[o] = key;
         upos[o] = (uint32_t)i;
     }
 };
@@ -388,22 +392,38 @@ struct EmitMol {
     uint64_t n_keys, n_dist;
     uint64_t *mkeys;
     uint32_t *mreads;
-    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o) const {
+    struct Pre {
+        unsigned long long mr;
+        uint64_t key;
+        uint32_t p0, p1, corr, inc_all;
+    };
+    __device__ __forceinline__ Pre pre(uint64_t k) const {
+        Pre p;
+        p.mr = minraw[k];
+        p.key = ukey[k];
+        p.p0 = upos[k];
+        p.p1 = upos[k + 1 < n_dist ? k + 1 : k];
+        p.corr = corr[k];
+        p.inc_all = inc_all[k];
+        return p;
+    }
+    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o, const Pre &p) const {
         // UmiType of the representative read (mark_dups.rs:250-268,326-329): the min (utype, qname)
         // read of the smallest qualifying raw UMI corrected onto k, else of k itself.
-        const unsigned long long mr = minraw[k];
-        const uint64_t bit = (mr != ~0ull ? ukey[mr & 0xFFFFFFFFull] : ukey[k]) & 1ull;
-        mkeys[o] = (ukey[k] & ~1ull) | bit;
-        const uint32_t end = k + 1 < n_dist ? upos[k + 1] : (uint32_t)n_keys;
-        const uint32_t cnt = end - upos[k];
+        const uint64_t bit = (p.mr != ~0ull ? ukey[p.mr & 0xFFFFFFFFull] : p.key) & 1ull;
+        mkeys[o] = (p.key & ~1ull) | bit;
+        const uint32_t end = k + 1 < n_dist ? p.p1 : (uint32_t)n_keys;
+        const uint32_t cnt = end - p.p0;
         // umigene_counts after both moves (mark_dups.rs:226-246): own reads stay only if not corrected away
-        mreads[o] = (corr[k] == NONE32 ? cnt : 0u) + inc_all[k];
+        mreads[o] = (p.corr == NONE32 ? cnt : 0u) + p.inc_all;
     }
 };
 struct EmitTriplet {
     const uint64_t *mkeys;
     uint32_t *tpos;
-    __device__ __forceinline__ void operator()(uint64_t i, uint32_t o) const { tpos[o] = (uint32_t)i; }
+    struct Pre {};
+    __device__ __forceinline__ Pre pre(uint64_t) const { return Pre(); }
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t o, Pre) const { tpos[o] = (uint32_t)i; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -455,13 +475,24 @@ __device__ __forceinline__ uint32_t run_count(const uint32_t *__restrict__ upos,
 __global__ __launch_bounds__(256) void k_rep_utype(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
                                                    const uint32_t *__restrict__ corr,
                                                    unsigned long long *__restrict__ minraw) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 8;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
-        const uint32_t t = corr[k];
-        if (t == NONE32) continue;
-        const uint64_t raw = (ukey[k] >> kl.sh_umi) & umi_mask, tgt = (ukey[t] >> kl.sh_umi) & umi_mask;
-        if (raw < tgt || corr[t] != NONE32) atomicMin(&minraw[t], (unsigned long long)((raw << 32) | k));
+    // 8 keys per thread per round: the corr loads are all issued before the first one is looked at (only ~2 % of
+    // the keys are corrected and take the second, dependent round of loads)
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x * 8; base < nd; base += stride) {
+        uint32_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint64_t k = base + (uint64_t)j * blockDim.x + threadIdx.x;
+            t[j] = corr[k < nd ? k : nd - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint64_t k = base + (uint64_t)j * blockDim.x + threadIdx.x;
+            if (k >= nd || t[j] == NONE32) continue;
+            const uint64_t raw = (ukey[k] >> kl.sh_umi) & umi_mask, tgt = (ukey[t[j]] >> kl.sh_umi) & umi_mask;
+            if (raw < tgt || corr[t[j]] != NONE32) atomicMin(&minraw[t[j]], (unsigned long long)((raw << 32) | k));
+        }
     }
 }
 
@@ -599,7 +630,9 @@ struct CandFlag {
 };
 struct EmitIdx {
     uint32_t *out;
-    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o) const { out[o] = (uint32_t)k; }
+    struct Pre {};
+    __device__ __forceinline__ Pre pre(uint64_t) const { return Pre(); }
+    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o, Pre) const { out[o] = (uint32_t)k; }
 };
 
 // val = (extra hash bits << vbits) | index: the bits of the u32 payload the index does not need carry more
@@ -861,7 +894,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             hipLaunchKernelGGL(k_giant_final, dim3(512), dim3(UE_THREADS), 0, ctx->stream, upos, nd, n_keys, items, n_giant, best,
                                corr, inc1, inc_all);
         }
-        hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, nd, corr,
+        hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256 * 8)), dim3(256), 0, ctx->stream, kl, ukey, nd, corr,
                            minraw_b.as<unsigned long long>());
         CR_HIP(ctx, hipGetLastError());
     }
@@ -1015,7 +1048,9 @@ struct SeenFlag {  // barcode has a non-zero valid or corrected count in some li
 };
 struct EmitCol {
     uint32_t *rank;
-    __device__ __forceinline__ void operator()(uint64_t r, uint32_t o) const { rank[o] = (uint32_t)r; }
+    struct Pre {};
+    __device__ __forceinline__ Pre pre(uint64_t) const { return Pre(); }
+    __device__ __forceinline__ void operator()(uint64_t r, uint32_t o, Pre) const { rank[o] = (uint32_t)r; }
 };
 
 __global__ __launch_bounds__(256) void k_csc(const uint32_t *__restrict__ col_rank, uint64_t n_cols,
