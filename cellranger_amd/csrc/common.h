@@ -103,6 +103,7 @@ struct crgpu_ctx {
         bool in_use;
     };
     std::vector<PoolBlock> pool;
+    uint64_t pool_budget = 64ull << 30;  // bytes the pool may hold before it starts re-using larger blocks (set at create)
 
     // timing ledger
     bool timing = false;

@@ -54,6 +54,10 @@ extern "C" int crgpu_create(crgpu_ctx **out, int device_id) {
         delete ctx;
         return cr_fail(nullptr, CRGPU_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) ctx->pool_budget = (uint64_t)total_b / 2;
+    }
     // probability(q) = 10^(-(q-33)/10) computed on the HOST with libm pow, exactly as the
     // reference does per call (corrector.rs:167-171), for every 7-bit quality character.
     double ptab[128];
@@ -188,12 +192,24 @@ int cr_pool_alloc(crgpu_ctx *ctx, void **out, uint64_t bytes) {
     *out = nullptr;
     if (bytes == 0) bytes = 8;
     bytes = (bytes + 255) & ~255ull;
-    // best fit among the free blocks that waste at most 25 %
+    // A free block of exactly this size if there is one.  Otherwise a new block, as long as the pool stays below
+    // its budget: a step asks for the same sizes in the same order every time, so after ONE step every request
+    // finds its own block (with a waste-tolerant best fit a request could take the block a later request needed,
+    // and the second and third steps still paid multi-millisecond hipMallocs).  Above the budget: best fit among
+    // the free blocks that waste at most 25 %.
     int best = -1;
+    uint64_t pooled = 0;
     for (size_t i = 0; i < ctx->pool.size(); i++) {
         const auto &b = ctx->pool[i];
-        if (b.in_use || b.bytes < bytes || b.bytes - bytes > bytes / 4 + 4096) continue;
-        if (best < 0 || b.bytes < ctx->pool[best].bytes) best = (int)i;
+        pooled += b.bytes;
+        if (!b.in_use && b.bytes == bytes && best < 0) best = (int)i;
+    }
+    if (best < 0 && pooled + bytes > ctx->pool_budget) {
+        for (size_t i = 0; i < ctx->pool.size(); i++) {
+            const auto &b = ctx->pool[i];
+            if (b.in_use || b.bytes < bytes || b.bytes - bytes > bytes / 4 + 4096) continue;
+            if (best < 0 || b.bytes < ctx->pool[best].bytes) best = (int)i;
+        }
     }
     if (best >= 0) {
         ctx->pool[best].in_use = true;
