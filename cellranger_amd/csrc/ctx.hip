@@ -1,6 +1,9 @@
 // ctx.hip -- context, memory helpers and the HIP-event timing ledger of libcrgpu.
 #include <cmath>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 static thread_local std::string g_thread_err;
@@ -217,6 +220,8 @@ int cr_pool_alloc(crgpu_ctx *ctx, void **out, uint64_t bytes) {
         return CRGPU_OK;
     }
     void *p = nullptr;
+    static const bool pool_debug = getenv("CRGPU_POOL_DEBUG") != nullptr;
+    if (pool_debug) fprintf(stderr, "[crgpu pool] hipMalloc %llu bytes (%zu blocks cached)\n", (unsigned long long)bytes, ctx->pool.size());
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         // memory pressure: drop every cached free block and retry once

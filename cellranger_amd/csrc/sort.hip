@@ -15,6 +15,7 @@
 //   k_radix_scatter  stable scatter; each block derives its digit bases from the digit totals
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "block_utils.h"
 #include "common.h"
@@ -185,6 +186,9 @@ __global__ __launch_bounds__(256) void k_scan_digits(uint32_t *__restrict__ bloc
 #define OS_AGG (1ull << 62)
 #define OS_INC (2ull << 62)
 #define OS_VAL ((1ull << 62) - 1ull)
+#ifndef OS_GROUP
+#define OS_GROUP 8u  // consecutive chunks handed to one XCD
+#endif
 template <typename K, bool HAS_VALS, typename DIG, int BITS, bool ONESWEEP = false>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
@@ -220,7 +224,22 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
     for (uint64_t chunk = lo;; chunk += CHUNK) {
         uint64_t cidx = 0;
         if (ONESWEEP) {
-            if (tid == 0) *s_chunk = atomicAdd(ticket, 1u);
+            // n_blocks carries the number of XCDs here.  Each XCD hands out its own share of the chunks: groups of
+            // OS_GROUP consecutive chunks go round-robin over the XCDs, so that the boundary lines of neighbouring
+            // chunks are mostly written through one L2, which merges them (chunks of one global ticket sequence land
+            // on arbitrary XCDs and every run boundary went to HBM as two partial lines).  The look-back still
+            // follows the global chunk order; a chunk's predecessors are either earlier tickets of its own XCD or
+            // chunks of other XCDs that their counters reach without waiting on anything later.
+            if (tid == 0) {
+                uint32_t xcc = 0;
+                if (n_blocks > 1) {
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    xcc &= 0xFu;
+                    if (xcc >= n_blocks) xcc %= n_blocks;
+                }
+                const uint32_t k = atomicAdd(ticket + xcc * 32u, 1u);
+                *s_chunk = n_blocks > 1 ? ((k / OS_GROUP) * n_blocks + xcc) * OS_GROUP + (k % OS_GROUP) : k;
+            }
             __syncthreads();
             cidx = *s_chunk;
             if (cidx >= n_chunks) break;  // uniform
@@ -299,10 +318,20 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             if (ONESWEEP) {
                 unsigned long long excl = 0;
                 if (cidx > 0) {
+                    // Watchdog: the chain cannot stall as long as every XCD receives workgroups (each of them takes its
+                    // XCD's chunks in ascending order).  Should that ever not hold, a waiter gives up after ~2^22 polls,
+                    // raises the abort word behind the tickets, everybody stops waiting, and the host reports an error
+                    // instead of a hung GPU.
+                    uint32_t *abort_word = ticket + 16 * 32 - 1;
                     auto wait_for = [&](uint64_t c, unsigned long long sv) {
+                        uint32_t polls = 0;
                         while ((sv >> 62) == 0ull) {
                             __builtin_amdgcn_s_sleep(1);
                             sv = __hip_atomic_load(&status[c * RADIX_T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((++polls & 0xFFFu) == 0u) {
+                                if (polls >= (1u << 22)) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return OS_INC;
+                            }
                         }
                         return sv;
                     };
@@ -447,6 +476,33 @@ __global__ __launch_bounds__(RADIX_MAX) void k_scan_global_hist(uint32_t *__rest
     row[threadIdx.x] = block_excl_scan<RADIX_MAX>(v, lds, nullptr);
 }
 
+__global__ void k_xcc_probe(uint32_t *out) {
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = x & 0xFu;
+}
+// number of XCDs whose ids are 0..n-1 and all receive workgroups; 1 = do not split the tickets
+static uint32_t probe_xccs(crgpu_ctx *ctx) {
+    const uint32_t nb = 1024;
+    uint32_t *d = nullptr;
+    if (cr_pool_alloc(ctx, (void **)&d, nb * sizeof(uint32_t)) != CRGPU_OK) return 1;
+    hipLaunchKernelGGL(k_xcc_probe, dim3(nb), dim3(64), 0, ctx->stream, d);
+    std::vector<uint32_t> h(nb);
+    const int rc = crgpu_memcpy_d2h(ctx, h.data(), d, nb * sizeof(uint32_t));
+    cr_pool_free(ctx, d);
+    if (rc != CRGPU_OK) return 1;
+    uint32_t seen = 0, mx = 0;
+    for (uint32_t v : h) {
+        seen |= 1u << v;
+        mx = v > mx ? v : mx;
+    }
+    const uint32_t n = mx + 1;
+    if (n > 16 || seen != (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u)) return 1;
+    if (const char *e = getenv("CRGPU_SORT_XCC"))  // "0": one global ticket sequence (A/B)
+        if (atoi(e) == 0) return 1;
+    return n;
+}
+
 static bool onesweep_enabled() {
     static int on = -1;
     if (on < 0) {
@@ -462,7 +518,10 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     typedef SortCfg<uint64_t, false> Cfg;
     const uint64_t n_chunks = (n + Cfg::CHUNK - 1) / Cfg::CHUNK;
     void *d_small = nullptr, *d_status = nullptr;
-    const size_t small_bytes = (size_t)OS_MAX_PASSES * RADIX_MAX * 4 + OS_MAX_PASSES * 128;  // histograms + tickets (a line each)
+    static uint32_t n_xcc = 0;
+    if (!n_xcc) n_xcc = probe_xccs(ctx);
+    // histograms + per pass 16 ticket counters, a cache line each
+    const size_t small_bytes = (size_t)OS_MAX_PASSES * RADIX_MAX * 4 + OS_MAX_PASSES * 16 * 128;
     CR_TRY(cr_pool_alloc(ctx, &d_small, small_bytes));
     int rc = cr_pool_alloc(ctx, &d_status, n_chunks * RADIX_MAX * sizeof(unsigned long long));
     if (rc != CRGPU_OK) {
@@ -486,7 +545,9 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         RadixDigit dig{plan.shift[p], plan.mask[p]};
         CrTimer t(ctx, CRGPU_T_SORT, n);
         e = hipMemsetAsync(d_status, 0, n_chunks * radix * sizeof(unsigned long long), ctx->stream);
-        const dim3 grid((unsigned)(n_chunks < 512 ? n_chunks : 512));  // one workgroup fits per CU; the rest queue up for tickets
+        // one workgroup fits per CU, the rest queue up for tickets.  With per-XCD tickets every XCD must receive
+        // workgroups whatever the dispatcher's rotation: always the full grid (idle workgroups leave after one atomic)
+        const dim3 grid((unsigned)(n_xcc > 1 || n_chunks > 512 ? 512 : n_chunks));
         if (wide) {
             if (!attr9) {
                 (void)hipFuncSetAttribute((const void *)k_radix_scatter<uint64_t, false, RadixDigit, 9, true>,
@@ -494,8 +555,8 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
                 attr9 = true;
             }
             hipLaunchKernelGGL((k_radix_scatter<uint64_t, false, RadixDigit, 9, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
-                               out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, 0u,
-                               (unsigned long long *)d_status, tickets + p * 32);
+                               out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
+                               (unsigned long long *)d_status, tickets + p * 16 * 32);
         } else {
             if (!attr8) {
                 (void)hipFuncSetAttribute((const void *)k_radix_scatter<uint64_t, false, RadixDigit, 8, true>,
@@ -503,8 +564,8 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
                 attr8 = true;
             }
             hipLaunchKernelGGL((k_radix_scatter<uint64_t, false, RadixDigit, 8, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
-                               out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, 0u,
-                               (unsigned long long *)d_status, tickets + p * 32);
+                               out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
+                               (unsigned long long *)d_status, tickets + p * 16 * 32);
         }
         if (e == hipSuccess) e = hipGetLastError();
         uint64_t *t2 = in;
@@ -512,9 +573,17 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         out = t2;
         *result_in_tmp = !*result_in_tmp;
     }
+    uint32_t aborted = 0;
+    if (e == hipSuccess) {
+        // abort words: the last ticket word of every pass
+        std::vector<uint32_t> tk(OS_MAX_PASSES * 16 * 32);
+        if (crgpu_memcpy_d2h(ctx, tk.data(), tickets, tk.size() * sizeof(uint32_t)) == CRGPU_OK)
+            for (uint32_t p = 0; p < plan.n_passes; p++) aborted |= tk[p * 16 * 32 + 16 * 32 - 1];
+    }
     cr_pool_free(ctx, d_status);
     cr_pool_free(ctx, d_small);
     if (e != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "onesweep sort: %s", hipGetErrorString(e));
+    if (aborted) return cr_fail(ctx, CRGPU_EHIP, "onesweep sort: look-back watchdog fired (set CRGPU_SORT=classic)");
     return CRGPU_OK;
 }
 
