@@ -394,11 +394,16 @@ __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ 
 #ifndef LH_ITEMS
 #define LH_ITEMS 8
 #endif
+#ifndef LH_QITEMS
+#define LH_QITEMS 4                  // item slots packed into the cold queue at a time
+#endif
+#define LH_QUEUE (64 * LH_QITEMS)    // entries of a wave's queue: every lane of every slot could be cold
 __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                                                            const unsigned long long *__restrict__ hot_image,
                                                            const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
                                                            uint64_t n, uint32_t *__restrict__ idx_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_hot[];  // HOT_SLOTS
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_hot[];  // HOT_SLOTS, then the cold queues
+    uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_hot + HOT_SLOTS);          // LH_THREADS / 64 queues of LH_QUEUE
     const uint32_t tid = threadIdx.x;
     const WlView &w = vs.v[0];
     const uint32_t *__restrict__ tw = reinterpret_cast<const uint32_t *>(w.tailA);
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
         nfl[j] = (i < n && flags) ? flags[i] : 0u;
     }
     for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
-        uint32_t key[LH_ITEMS], rank[LH_ITEMS], lo[LH_ITEMS], hi[LH_ITEMS];
+        uint32_t key[LH_ITEMS], rank[LH_ITEMS];
         bool todo[LH_ITEMS];  // live read that the LDS table did not answer
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
@@ -438,39 +443,58 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                 todo[j] = false;
             }
         }
-        // the rest: index bin, then the first 8 entries of the bin, for all items before any compare
-        U32x4 d[LH_ITEMS];
+        // The rest (~20 % of the reads: ambient barcodes, the smaller cells, sequencing errors) goes to the global
+        // tables.  Executing that path once per item slot costs every lane its instructions although only a fifth
+        // of them need it, so each wave first packs the keys of its cold lanes densely into a private LDS queue
+        // (a wave runs in lockstep and its LDS operations complete in order: no barrier), looks them up 64 at a
+        // time, and hands the ranks back through the same queue.
+        uint32_t *q = s_queue + (tid >> 6) * LH_QUEUE;
+        const uint32_t lane = tid & 63u;
 #pragma unroll
-        for (int j = 0; j < LH_ITEMS; j++) {
-            lo[j] = hi[j] = 0u;
-            if (todo[j]) {
-                const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offE + (uint32_t)((uint64_t)key[j] >> w.shiftE));
-                lo[j] = b2.a;
-                hi[j] = b2.b;
+        for (int h = 0; h < LH_ITEMS; h += LH_QITEMS) {
+            uint32_t dj[LH_QITEMS], tot = 0;
+#pragma unroll
+            for (int jj = 0; jj < LH_QITEMS; jj++) {
+                const unsigned long long m = __ballot(todo[h + jj]);
+                dj[jj] = tot + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                tot += (uint32_t)__popcll(m);
+                if (todo[h + jj]) q[dj[jj]] = key[h + jj];
             }
-        }
+            __builtin_amdgcn_wave_barrier();  // keep the compiler from moving queue reads above these writes
+            for (uint32_t r0 = 0; r0 < tot; r0 += 64) {  // uniform: tot comes from ballots
+                const uint32_t dpos = r0 + lane;
+                if (dpos < tot) {
+                    const uint32_t k = q[dpos];
+                    const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offE + (uint32_t)((uint64_t)k >> w.shiftE));
+                    const uint32_t lo = b2.a, hi = b2.b;
+                    uint32_t found = CRGPU_MISS;
+                    if (hi > lo) {
+                        const U32x4 d = *reinterpret_cast<const U32x4 *>(tw + (lo >> 1));
+                        const uint32_t tail = k & tail_mask;
+                        const uint32_t p0 = lo & ~1u;
 #pragma unroll
-        for (int j = 0; j < LH_ITEMS; j++)
-            if (todo[j] && hi[j] > lo[j]) d[j] = *reinterpret_cast<const U32x4 *>(tw + (lo[j] >> 1));
+                        for (uint32_t e = 0; e < 8; e++) {
+                            const uint32_t pos = p0 + e;
+                            const uint32_t t = (d.w[e >> 1] >> (16u * (e & 1u))) & 0xFFFFu;
+                            if (pos >= lo && pos < hi && t == tail) found = pos;
+                        }
+                        if (hi > p0 + 8u && found == CRGPU_MISS)  // a bin of more than 7 keys: rare
+                            scan_u16_range<4>(w.tailA, p0 + 8u, hi, [&](uint32_t t, uint32_t pos) {
+                                if (t == tail) found = pos;
+                            });
+                    }
+                    q[dpos] = found;  // valA == nullptr on this path: sorted position == rank
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int jj = 0; jj < LH_QITEMS; jj++)
+                if (todo[h + jj]) rank[h + jj] = q[dj[jj]];
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * LH_THREADS + tid;
-            if (todo[j] && hi[j] > lo[j]) {
-                const uint32_t tail = key[j] & tail_mask;
-                const uint32_t p0 = lo[j] & ~1u;
-                uint32_t found = CRGPU_MISS;
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++) {
-                    const uint32_t pos = p0 + k;
-                    const uint32_t t = (d[j].w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
-                    if (pos >= lo[j] && pos < hi[j] && t == tail) found = pos;
-                }
-                if (hi[j] > p0 + 8u && found == CRGPU_MISS)  // a bin of more than 7 keys: rare
-                    scan_u16_range<4>(w.tailA, p0 + 8u, hi[j], [&](uint32_t t, uint32_t pos) {
-                        if (t == tail) found = pos;
-                    });
-                rank[j] = found;  // valA == nullptr on this path: sorted position == rank
-            }
             if (i < n) idx_out[i] = rank[j];
         }
     }
@@ -655,14 +679,15 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
         first = n / 4 < (4ull << 20) ? n / 4 : (4ull << 20);
         first = first / MB_TILE * MB_TILE;
     }
-    const size_t hot_lds = HOT_SLOTS * sizeof(unsigned long long);
+    const size_t hot_lds = HOT_SLOTS * sizeof(unsigned long long);                       // table image
+    const size_t lookup_lds = hot_lds + (LH_THREADS / 64) * LH_QUEUE * sizeof(uint32_t);  // + per-wave cold queues
     if (use_hot && !ctx->d_hot_image) {
         if (hipMalloc((void **)&ctx->d_hot_image, hot_lds + 256 * sizeof(uint32_t)) != hipSuccess) {
             cr_pool_free(ctx, d_stage);
             cr_pool_free(ctx, d_cursor);
             return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc hot table failed");
         }
-        (void)hipFuncSetAttribute((const void *)k_lookup_hot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds);
+        (void)hipFuncSetAttribute((const void *)k_lookup_hot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lookup_lds);
     }
     hipError_t e = hipSuccess;
     bool hot_ready = false;
@@ -673,7 +698,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
             CrTimer t(ctx, CRGPU_T_MATCH, m);
             e = hipMemsetAsync(d_cursor, 0, plan.n_buckets * MB_CURSOR_STRIDE * sizeof(uint32_t), ctx->stream);
             if (hot_ready) {
-                hipLaunchKernelGGL(k_lookup_hot, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), hot_lds,
+                hipLaunchKernelGGL(k_lookup_hot, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
                                    ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
                                    d_idx_out + off);
                 if (plan.n_buckets <= SI_MISS_BUCKET)
