@@ -245,7 +245,9 @@ extern "C" int crgpu_balanced_bounds(crgpu_ctx *ctx, uint32_t n_ranks, uint32_t 
 // generic two-pass stream compaction driven by a flag functor: out position of every flagged item
 // ------------------------------------------------------------------------------------------------
 #define CP_BLOCK 256
+#ifndef CP_ITEMS
 #define CP_ITEMS 8  // items per thread per round: their flag loads are all issued before the first compare
+#endif
 #define CP_ROUND (CP_BLOCK * CP_ITEMS)
 #define CP_WAVES (CP_BLOCK / 64)
 
