@@ -401,7 +401,10 @@ __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                                                            const unsigned long long *__restrict__ hot_image,
                                                            const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
-                                                           uint64_t n, uint32_t *__restrict__ idx_out) {
+                                                           uint64_t n, uint32_t *__restrict__ idx_out,
+                                                           uint32_t *__restrict__ rec_i, uint32_t *__restrict__ rec_key,
+                                                           uint8_t *__restrict__ rec_fl, uint32_t *__restrict__ rec_count,
+                                                           uint32_t rec_cap, uint32_t rec_regions, uint32_t i_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hot[];  // HOT_SLOTS, then the cold queues
     uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_hot + HOT_SLOTS);          // LH_THREADS / 64 queues of LH_QUEUE
     const uint32_t tid = threadIdx.x;
@@ -411,6 +414,9 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
     for (uint32_t s = tid; s < HOT_SLOTS; s += LH_THREADS) s_hot[s] = hot_image[s];
     __syncthreads();
     const uint64_t chunk = (uint64_t)LH_THREADS * LH_ITEMS;
+    // miss records (for K2): every wave appends to its own region, no atomics; the cursor lives in a register
+    const uint32_t region = blockIdx.x * (LH_THREADS / 64) + (tid >> 6);
+    uint32_t rec_cur = rec_i ? rec_count[region] : 0u;
     // the keys of the next chunk are requested before this chunk's table probes and global lookups
     uint32_t nkey[LH_ITEMS], nfl[LH_ITEMS];
 #pragma unroll
@@ -420,12 +426,13 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
         nfl[j] = (i < n && flags) ? flags[i] : 0u;
     }
     for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
-        uint32_t key[LH_ITEMS], rank[LH_ITEMS];
+        uint32_t key[LH_ITEMS], rank[LH_ITEMS], cfl[LH_ITEMS];
         bool todo[LH_ITEMS];  // live read that the LDS table did not answer
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * LH_THREADS + tid;
             key[j] = nkey[j];
+            cfl[j] = nfl[j];
             todo[j] = i < n && !(nfl[j] & CRGPU_FLAG_CB_HAS_N) && (nfl[j] & CRGPU_FLAG_LIB_MASK) == 0u;
             rank[j] = CRGPU_MISS;
         }
@@ -496,7 +503,23 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
         for (int j = 0; j < LH_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * LH_THREADS + tid;
             if (i < n) idx_out[i] = rank[j];
+            if (rec_i) {
+                const bool miss = i < n && rank[j] == CRGPU_MISS;
+                const unsigned long long mm = __ballot(miss);
+                const uint32_t pos = rec_cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                if (miss && pos < rec_cap) {
+                    const uint64_t o = (uint64_t)region * rec_cap + pos;
+                    rec_i[o] = i_offset + (uint32_t)i;
+                    rec_key[o] = key[j];
+                    rec_fl[o] = (uint8_t)cfl[j];
+                }
+                rec_cur += (uint32_t)__popcll(mm);
+            }
         }
+    }
+    if (rec_i && (tid & 63u) == 0u) {
+        rec_count[region] = rec_cur;
+        if (rec_cur > rec_cap) atomicOr(&rec_count[rec_regions], 1u);  // overflow: K2 falls back to scanning idx
     }
 }
 
@@ -627,6 +650,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_match_and_count: no whitelist set");
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_cb && d_idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
+    cr_drop_miss_records(ctx);
     WlViewSet vs;
     CR_TRY(cr_make_views(ctx, vs.v));
     vs.n_canon = ctx->n_canon;
@@ -693,6 +717,31 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
         }
         (void)hipFuncSetAttribute((const void *)k_lookup_hot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lookup_lds);
     }
+    // miss records for K2: one region per wave of the lookup kernel (its grid is pinned to 256 workgroups)
+    MissRecords &rec = ctx->rec;
+    if (use_hot && n < 0xFFFFFFFFull && !getenv("CRGPU_NO_MISS_RECORDS")) {
+        const uint64_t H = n - first;
+        const uint64_t launches = (H + sb - 1) / sb + 1;
+        rec.regions = 256u * (LH_THREADS / 64);
+        rec.cap = (uint32_t)(H / rec.regions / 3 + 2048 + 512 * launches);  // a third of a wave's reads may miss
+        if (const char *env = getenv("CRGPU_MISS_RECORD_CAP")) rec.cap = (uint32_t)strtoul(env, nullptr, 10);  // tests: force the overflow fallback
+        const uint64_t C = (uint64_t)rec.regions * rec.cap;
+        int rr = cr_pool_alloc(ctx, (void **)&rec.d_i, C * sizeof(uint32_t));
+        if (rr == CRGPU_OK) rr = cr_pool_alloc(ctx, (void **)&rec.d_key, C * sizeof(uint32_t));
+        if (rr == CRGPU_OK) rr = cr_pool_alloc(ctx, (void **)&rec.d_fl, C);
+        if (rr == CRGPU_OK) rr = cr_pool_alloc(ctx, (void **)&rec.d_count, (rec.regions + 1) * sizeof(uint32_t));
+        if (rr == CRGPU_OK &&
+            hipMemsetAsync(rec.d_count, 0, (rec.regions + 1) * sizeof(uint32_t), ctx->stream) == hipSuccess) {
+            rec.valid = true;
+            rec.d_cb = d_cb;
+            rec.d_flags = d_flags;
+            rec.d_idx = d_idx_out;
+            rec.n = n;
+            rec.first = first;
+        } else {
+            cr_drop_miss_records(ctx);  // not fatal: K2 scans idx as before
+        }
+    }
     hipError_t e = hipSuccess;
     bool hot_ready = false;
     for (uint64_t off = 0; off < n && e == hipSuccess;) {
@@ -704,7 +753,8 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
             if (hot_ready) {
                 hipLaunchKernelGGL(k_lookup_hot, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
                                    ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
-                                   d_idx_out + off);
+                                   d_idx_out + off, rec.valid ? rec.d_i : nullptr, rec.d_key, rec.d_fl, rec.d_count, rec.cap,
+                                   rec.regions, (uint32_t)off);
                 if (plan.n_buckets <= SI_MISS_BUCKET)
                     hipLaunchKernelGGL(k_stage_idx, dim3(cr_grid((m + SI_TILE - 1) / SI_TILE, 1, 256u * 6u)), dim3(256), 0,
                                        ctx->stream, plan, d_idx_out + off, m, d_stage, d_cursor);
@@ -739,8 +789,20 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     }
     cr_pool_free(ctx, d_stage);
     cr_pool_free(ctx, d_cursor);
-    if (e != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "crgpu_match_and_count: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        cr_drop_miss_records(ctx);
+        return cr_fail(ctx, CRGPU_EHIP, "crgpu_match_and_count: %s", hipGetErrorString(e));
+    }
     return CRGPU_OK;
+}
+
+void cr_drop_miss_records(crgpu_ctx *ctx) {
+    MissRecords &r = ctx->rec;
+    cr_pool_free(ctx, r.d_i);
+    cr_pool_free(ctx, r.d_key);
+    cr_pool_free(ctx, r.d_fl);
+    cr_pool_free(ctx, r.d_count);
+    r = MissRecords();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -753,10 +815,13 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
 // Compact the indices of the reads that missed.  One global atomic per 16384-read chunk: same-address
 // atomics saturate near 88 per microsecond on this chip, so the reservation is aggregated over the
 // whole workgroup and over 64 reads per thread (a 64-bit miss mask per thread).
-__global__ __launch_bounds__(256) void k_collect_miss(const uint32_t *__restrict__ idx, uint64_t n,
+// idx points at read i_base of the caller's arrays; run_if (nullable): do nothing unless *run_if != 0.
+__global__ __launch_bounds__(256) void k_collect_miss(const uint32_t *__restrict__ idx, uint64_t n, uint32_t i_base,
+                                                      const uint32_t *__restrict__ run_if,
                                                       uint32_t *__restrict__ miss_list,
                                                       unsigned long long *__restrict__ n_miss) {
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
+    if (run_if && *run_if == 0u) return;
     const uint64_t chunk = 256ull * MISS_ITEMS;
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -781,7 +846,7 @@ __global__ __launch_bounds__(256) void k_collect_miss(const uint32_t *__restrict
         while (mask) {
             const int j = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
-            miss_list[o++] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);
+            miss_list[o++] = i_base + (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);
         }
     }
 }
@@ -795,117 +860,152 @@ __device__ __forceinline__ int one_base_diff(uint32_t a, uint32_t b) {
     return __ffs((int)y) - 1;
 }
 
+struct K2Params {
+    const uint8_t *qualn;
+    uint32_t len;
+    const double *ptab;
+    double max_expected, thresh;
+    bool check_expected;
+    uint32_t *idx_inout;
+    uint8_t *corrected_out;
+};
+
+// one missing read: i = index in the caller's arrays, key = packed barcode, f = flag byte
+template <bool UNIFORM>
+__device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Params &P, uint64_t i, uint32_t key, uint32_t f) {
+    const uint8_t *__restrict__ qualn = P.qualn;
+    const uint32_t len = P.len;
+    const double *__restrict__ ptab = P.ptab;
+    const double max_expected = P.max_expected, thresh = P.thresh;
+    const bool check_expected = P.check_expected;
+    uint32_t *__restrict__ idx_inout = P.idx_inout;
+    uint8_t *__restrict__ corrected_out = P.corrected_out;
+    const uint32_t lib = UNIFORM ? 0u : (f & CRGPU_FLAG_LIB_MASK);
+    if (UNIFORM && (f & CRGPU_FLAG_LIB_MASK) != 0u) return;
+    const WlView &w = vs.v[lib];
+    if (!UNIFORM && w.n == 0) return;
+
+    // qualities (bit 7 = N), kept in two 64-bit registers: byte k of (qlo,qhi) = position k
+    unsigned long long qlo, qhi;
+    if (qualn) {
+        if (len == 16) {
+            const uint4 q4 = *reinterpret_cast<const uint4 *>(qualn + i * 16);
+            qlo = (unsigned long long)q4.x | ((unsigned long long)q4.y << 32);
+            qhi = (unsigned long long)q4.z | ((unsigned long long)q4.w << 32);
+        } else {
+            qlo = 0ull;
+            qhi = 0ull;
+            for (uint32_t k = 0; k < len; k++) {
+                const unsigned long long b = qualn[i * len + k];
+                if (k < 8) qlo |= b << (8 * k); else qhi |= b << (8 * (k - 8));
+            }
+        }
+    } else {
+        qlo = qhi = 0x4242424242424242ull;      // BC_MAX_QV = 66, corrector.rs:126 map_or
+        if (f & CRGPU_FLAG_CB_HAS_N) return;   // N position unknown without qualities
+    }
+    // movemask of the N bits: bit k = position k
+    const uint32_t nmask = (uint32_t)(((qlo & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56) |
+                           ((uint32_t)(((qhi & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56) << 8);
+    const int n_n = __popc(nmask);
+
+    // candidate slots: bit (pos*4 + base)
+    unsigned long long cand = 0ull;
+    if (n_n == 0) {
+        const uint32_t head = key >> w.bitsB;
+        const uint32_t tail = key & ((1u << w.bitsB) - 1u);
+        const uint32_t hA = w.bitsA >> 1;
+        // the four bin bounds are independent loads
+        const U32x2 a2 = *reinterpret_cast<const U32x2 *>(w.offA + head);
+        const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offB + tail);
+        const uint32_t a_lo = a2.a, a_hi = a2.b, b_lo = b2.a, b_hi = b2.b;
+        // mutation in the tail: same head -> bin A
+        scan_u16_range<K2_SCAN_DWORDS>(w.tailA, a_lo, a_hi, [&](uint32_t t, uint32_t) {
+            const int bo = one_base_diff(t, tail);
+            if (bo >= 0) {
+                const uint32_t pos = len - 1u - (uint32_t)(bo >> 1);
+                cand |= 1ull << (pos * 4u + ((t >> bo) & 3u));
+            }
+        });
+        // mutation in the head: same tail -> bin B
+        scan_u16_range<K2_SCAN_DWORDS>(w.headB, b_lo, b_hi, [&](uint32_t h, uint32_t) {
+            const int bo = one_base_diff(h, head);
+            if (bo >= 0) {
+                const uint32_t pos = hA - 1u - (uint32_t)(bo >> 1);
+                cand |= 1ull << (pos * 4u + ((h >> bo) & 3u));
+            }
+        });
+    } else if (n_n == 1) {
+        // the N is "observed": all four bases are tried at its position (corrector.rs:128-131);
+        // a candidate built at any other position still contains the N and cannot match.
+        const uint32_t pos = (uint32_t)__ffs((int)nmask) - 1u;
+        cand = 0xFull << (pos * 4u);
+    }
+
+    bool have_best = false;
+    double best_like = 0.0, total = 0.0;
+    uint32_t best_rank = 0;
+    while (cand) {
+        const uint32_t slot = (uint32_t)__ffsll((long long)cand) - 1u;
+        cand &= cand - 1ull;
+        const uint32_t pos = slot >> 2, base = slot & 3u;
+        const uint32_t sh = 2u * (len - 1u - pos);
+        const uint32_t ckey = (key & ~(3u << sh)) | (base << sh);
+        const uint32_t r = wl_lookup(w, ckey);
+        if (r == CRGPU_MISS) continue;
+        uint32_t qv = (uint32_t)((pos < 8u ? qlo : qhi) >> (8u * (pos & 7u))) & 0x7Fu;
+        qv = qv < 66u ? qv : 66u;                                  // corrector.rs:126
+        const long long bc_count = 1ll + (long long)w.prior[r];    // Laplace smoothing, :138-139
+        const double like = ptab[qv] * (double)bc_count;           // :140-141
+        if (!have_best) {
+            have_best = true;
+            best_like = like;
+            best_rank = r;
+        } else if (like > best_like || (like == best_like && r >= best_rank)) {
+            // Ord::max on (NotNan, BarcodeSegment): ties go to the larger sequence == larger rank
+            best_like = like;
+            best_rank = r;
+        }
+        total += like;  // pos-major, A<C<G<T order (:146)
+    }
+    if (!have_best) return;
+    double expected = 0.0;  // :154, uncapped qualities, in order; 0.0 without qualities
+    if (check_expected)
+        for (uint32_t k = 0; k < len; k++)
+            expected += ptab[(uint32_t)((k < 8u ? qlo : qhi) >> (8u * (k & 7u))) & 0x7Fu];
+    if (expected < max_expected && best_like / total >= thresh) {
+        idx_inout[i] = best_rank;
+        if (corrected_out) corrected_out[i] = 1;
+        atomicAdd(&w.corrected[best_rank], 1u);
+    }
+}
+
+// the misses as a list of read indices (k_collect_miss); run_if_zero (nullable): do nothing if *run_if_zero != 0 ...
 template <bool UNIFORM>
 __global__ __launch_bounds__(256) void k_correct(const WlViewSet vs, const uint32_t *__restrict__ cb,
-                                                 const uint8_t *__restrict__ qualn, const uint8_t *__restrict__ flags,
-                                                 const uint32_t *__restrict__ miss_list,
-                                                 const unsigned long long *__restrict__ n_miss_ptr, uint32_t len,
-                                                 const double *__restrict__ ptab, double max_expected, double thresh,
-                                                 bool check_expected,
-                                                 uint32_t *__restrict__ idx_inout, uint8_t *__restrict__ corrected_out) {
+                                                 const uint8_t *__restrict__ flags, const uint32_t *__restrict__ miss_list,
+                                                 const unsigned long long *__restrict__ n_miss_ptr, const K2Params P) {
     const uint32_t n_miss = (uint32_t)*n_miss_ptr;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_miss; j += stride) {
         const uint64_t i = miss_list[j];
-        const uint32_t key = cb[i];
-        const uint32_t f = flags ? flags[i] : 0u;
-        const uint32_t lib = UNIFORM ? 0u : (f & CRGPU_FLAG_LIB_MASK);
-        if (UNIFORM && (f & CRGPU_FLAG_LIB_MASK) != 0u) continue;
-        const WlView &w = vs.v[lib];
-        if (!UNIFORM && w.n == 0) continue;
+        k2_correct_one<UNIFORM>(vs, P, i, cb[i], flags ? flags[i] : 0u);
+    }
+}
 
-        // qualities (bit 7 = N), kept in two 64-bit registers: byte k of (qlo,qhi) = position k
-        unsigned long long qlo, qhi;
-        if (qualn) {
-            if (len == 16) {
-                const uint4 q4 = *reinterpret_cast<const uint4 *>(qualn + i * 16);
-                qlo = (unsigned long long)q4.x | ((unsigned long long)q4.y << 32);
-                qhi = (unsigned long long)q4.z | ((unsigned long long)q4.w << 32);
-            } else {
-                qlo = 0ull;
-                qhi = 0ull;
-                for (uint32_t k = 0; k < len; k++) {
-                    const unsigned long long b = qualn[i * len + k];
-                    if (k < 8) qlo |= b << (8 * k); else qhi |= b << (8 * (k - 8));
-                }
-            }
-        } else {
-            qlo = qhi = 0x4242424242424242ull;      // BC_MAX_QV = 66, corrector.rs:126 map_or
-            if (f & CRGPU_FLAG_CB_HAS_N) continue;   // N position unknown without qualities
-        }
-        // movemask of the N bits: bit k = position k
-        const uint32_t nmask = (uint32_t)(((qlo & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56) |
-                               ((uint32_t)(((qhi & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56) << 8);
-        const int n_n = __popc(nmask);
-
-        // candidate slots: bit (pos*4 + base)
-        unsigned long long cand = 0ull;
-        if (n_n == 0) {
-            const uint32_t head = key >> w.bitsB;
-            const uint32_t tail = key & ((1u << w.bitsB) - 1u);
-            const uint32_t hA = w.bitsA >> 1;
-            // the four bin bounds are independent loads
-            const U32x2 a2 = *reinterpret_cast<const U32x2 *>(w.offA + head);
-            const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offB + tail);
-            const uint32_t a_lo = a2.a, a_hi = a2.b, b_lo = b2.a, b_hi = b2.b;
-            // mutation in the tail: same head -> bin A
-            scan_u16_range<K2_SCAN_DWORDS>(w.tailA, a_lo, a_hi, [&](uint32_t t, uint32_t) {
-                const int bo = one_base_diff(t, tail);
-                if (bo >= 0) {
-                    const uint32_t pos = len - 1u - (uint32_t)(bo >> 1);
-                    cand |= 1ull << (pos * 4u + ((t >> bo) & 3u));
-                }
-            });
-            // mutation in the head: same tail -> bin B
-            scan_u16_range<K2_SCAN_DWORDS>(w.headB, b_lo, b_hi, [&](uint32_t h, uint32_t) {
-                const int bo = one_base_diff(h, head);
-                if (bo >= 0) {
-                    const uint32_t pos = hA - 1u - (uint32_t)(bo >> 1);
-                    cand |= 1ull << (pos * 4u + ((h >> bo) & 3u));
-                }
-            });
-        } else if (n_n == 1) {
-            // the N is "observed": all four bases are tried at its position (corrector.rs:128-131);
-            // a candidate built at any other position still contains the N and cannot match.
-            const uint32_t pos = (uint32_t)__ffs((int)nmask) - 1u;
-            cand = 0xFull << (pos * 4u);
-        }
-
-        bool have_best = false;
-        double best_like = 0.0, total = 0.0;
-        uint32_t best_rank = 0;
-        while (cand) {
-            const uint32_t slot = (uint32_t)__ffsll((long long)cand) - 1u;
-            cand &= cand - 1ull;
-            const uint32_t pos = slot >> 2, base = slot & 3u;
-            const uint32_t sh = 2u * (len - 1u - pos);
-            const uint32_t ckey = (key & ~(3u << sh)) | (base << sh);
-            const uint32_t r = wl_lookup(w, ckey);
-            if (r == CRGPU_MISS) continue;
-            uint32_t qv = (uint32_t)((pos < 8u ? qlo : qhi) >> (8u * (pos & 7u))) & 0x7Fu;
-            qv = qv < 66u ? qv : 66u;                                  // corrector.rs:126
-            const long long bc_count = 1ll + (long long)w.prior[r];    // Laplace smoothing, :138-139
-            const double like = ptab[qv] * (double)bc_count;           // :140-141
-            if (!have_best) {
-                have_best = true;
-                best_like = like;
-                best_rank = r;
-            } else if (like > best_like || (like == best_like && r >= best_rank)) {
-                // Ord::max on (NotNan, BarcodeSegment): ties go to the larger sequence == larger rank
-                best_like = like;
-                best_rank = r;
-            }
-            total += like;  // pos-major, A<C<G<T order (:146)
-        }
-        if (!have_best) continue;
-        double expected = 0.0;  // :154, uncapped qualities, in order; 0.0 without qualities
-        if (check_expected)
-            for (uint32_t k = 0; k < len; k++)
-                expected += ptab[(uint32_t)((k < 8u ? qlo : qhi) >> (8u * (k & 7u))) & 0x7Fu];
-        if (expected < max_expected && best_like / total >= thresh) {
-            idx_inout[i] = best_rank;
-            if (corrected_out) corrected_out[i] = 1;
-            atomicAdd(&w.corrected[best_rank], 1u);
+// ... and the misses as the records K1's lookup kernel left behind (coalesced reads instead of two random
+// 128-byte lines per miss for cb and flags).  Does nothing when the records overflowed (k_collect_miss + k_correct
+// then cover everything).
+__global__ __launch_bounds__(256) void k_correct_records(const WlViewSet vs, const uint32_t *__restrict__ rec_i,
+                                                         const uint32_t *__restrict__ rec_key, const uint8_t *__restrict__ rec_fl,
+                                                         const uint32_t *__restrict__ rec_count, uint32_t rec_cap,
+                                                         uint32_t rec_regions, const K2Params P) {
+    if (rec_count[rec_regions] != 0u) return;
+    for (uint32_t r = blockIdx.x; r < rec_regions; r += gridDim.x) {
+        const uint32_t cnt = rec_count[r];
+        for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
+            const uint64_t o = (uint64_t)r * rec_cap + p;
+            k2_correct_one<true>(vs, P, rec_i[o], rec_key[o], rec_fl[o]);
         }
     }
 }
@@ -939,20 +1039,37 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
     CrTimer t(ctx, CRGPU_T_CORRECT, n);
     CR_HIP(ctx, hipMemsetAsync(n_miss, 0, sizeof(unsigned long long), ctx->stream));
     if (d_corrected_out) CR_HIP(ctx, hipMemsetAsync(d_corrected_out, 0, n, ctx->stream));
-    hipLaunchKernelGGL(k_collect_miss, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_idx_inout, n, miss_list, n_miss);
-    // K2 is launched for the worst case and loops over the device-side count: no host round trip
-    const dim3 grid(cr_grid(n / 8 + 1, 256)), block(256);
     // expected_errors < f64::MAX is always true for a finite sum: skip the sum for the default
     const bool check_expected = d_qualn && !fake_quals && ctx->max_expected_errors < 1.7976931348623157e308;
-    if (uniform_lib0(ctx))
-        hipLaunchKernelGGL(k_correct<true>, grid, block, 0, ctx->stream, vs, d_cb, d_qualn, d_flags, miss_list, n_miss,
-                           ctx->cb_len, ctx->d_ptab, ctx->max_expected_errors, ctx->confidence_threshold, check_expected,
-                           d_idx_inout, d_corrected_out);
+    const K2Params P{d_qualn, ctx->cb_len, ctx->d_ptab, ctx->max_expected_errors, ctx->confidence_threshold, check_expected,
+                     d_idx_inout, d_corrected_out};
+    const bool uniform = uniform_lib0(ctx);
+    // the records K1 left for exactly these buffers (consumed here: a second call scans idx again)
+    MissRecords &rec = ctx->rec;
+    const bool use_rec = rec.valid && uniform && rec.d_cb == d_cb && rec.d_flags == d_flags && rec.d_idx == d_idx_inout && rec.n == n;
+    if (use_rec) {
+        // reads before rec.first (K1's sampling batch) are not in the records; everything is scanned when they overflowed
+        const uint32_t *overflow = rec.d_count + rec.regions;
+        if (rec.first)
+            hipLaunchKernelGGL(k_collect_miss, dim3(cr_grid(rec.first, 256)), dim3(256), 0, ctx->stream, d_idx_inout, rec.first, 0u,
+                               (const uint32_t *)nullptr, miss_list, n_miss);
+        hipLaunchKernelGGL(k_collect_miss, dim3(cr_grid(n - rec.first, 256)), dim3(256), 0, ctx->stream, d_idx_inout + rec.first,
+                           n - rec.first, (uint32_t)rec.first, overflow, miss_list, n_miss);
+    } else {
+        hipLaunchKernelGGL(k_collect_miss, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_idx_inout, n, 0u,
+                           (const uint32_t *)nullptr, miss_list, n_miss);
+    }
+    // K2 is launched for the worst case and loops over the device-side count: no host round trip
+    const dim3 grid(cr_grid((use_rec ? rec.first + n / 64 : n) / 8 + 1, 256)), block(256);
+    if (uniform)
+        hipLaunchKernelGGL(k_correct<true>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, miss_list, n_miss, P);
     else
-        hipLaunchKernelGGL(k_correct<false>, grid, block, 0, ctx->stream, vs, d_cb, d_qualn, d_flags, miss_list, n_miss,
-                           ctx->cb_len, ctx->d_ptab, ctx->max_expected_errors, ctx->confidence_threshold, check_expected,
-                           d_idx_inout, d_corrected_out);
+        hipLaunchKernelGGL(k_correct<false>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, miss_list, n_miss, P);
+    if (use_rec)
+        hipLaunchKernelGGL(k_correct_records, dim3(2048), dim3(256), 0, ctx->stream, vs, rec.d_i, rec.d_key, rec.d_fl, rec.d_count,
+                           rec.cap, rec.regions, P);
     CR_HIP(ctx, hipGetLastError());
+    if (use_rec) cr_drop_miss_records(ctx);  // stream-ordered: the pool reuses the blocks only for later work
     return CRGPU_OK;
 }
 
@@ -1015,6 +1132,7 @@ extern "C" int crgpu_match_and_count(crgpu_ctx *ctx, int lib, const uint8_t *seq
     HostBatch b;
     CR_TRY(stage_host_batch(ctx, lib, seq, qual, n, b));
     CR_TRY(crgpu_match_and_count_dev(ctx, b.d_cb, b.d_flags, n, b.d_idx));
+    cr_drop_miss_records(ctx);  // the staging buffers are temporaries: a later call may get the same addresses back
     CR_TRY(crgpu_memcpy_d2h(ctx, idx_out, b.d_idx, n * sizeof(uint32_t)));
     return CRGPU_OK;
 }

@@ -70,6 +70,19 @@ struct KeyLayout {
     uint32_t total_bits() const { return 1 + bits_umi + bits_lib + bits_feat + bits_bc; }
 };
 
+// Compact (index, barcode, flags) records of the reads K1's table lookup kernel found no whitelist entry for:
+// crgpu_correct_dev on the same buffers reads them instead of scanning idx and gathering cb/flags again.
+struct MissRecords {
+    bool valid = false;
+    const uint32_t *d_cb = nullptr;
+    const uint8_t *d_flags = nullptr;
+    const uint32_t *d_idx = nullptr;
+    uint64_t n = 0, first = 0;  // reads [0, first) (the sampling batch) are not covered
+    uint32_t regions = 0, cap = 0;  // one region per wave of the lookup kernel, cap records each
+    uint32_t *d_i = nullptr, *d_key = nullptr, *d_count = nullptr;  // d_count[regions] = overflow flag
+    uint8_t *d_fl = nullptr;
+};
+
 struct crgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -85,6 +98,7 @@ struct crgpu_ctx {
     FeaturePattern pat[CRGPU_MAX_LIB];
     uint32_t *d_canon_keys = nullptr;         // n_canon packed canonical barcodes, ascending (rank -> sequence)
     unsigned long long *d_hot_image = nullptr;  // K1's hot-barcode table (HOT_SLOTS entries) + 256 u32 of scratch
+    MissRecords rec;
 
     double max_expected_errors = 1.7976931348623157e308;  // corrector.rs:104 (f64::MAX)
     double confidence_threshold = 0.975;                   // corrector.rs:83
@@ -138,6 +152,7 @@ void cr_set_thread_error(const char *msg);
 
 // workspace that only grows; returned pointer valid until the next cr_scratch call
 int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out);
+void cr_drop_miss_records(crgpu_ctx *ctx);  // barcode.hip: forget (and release) the K1 -> K2 miss records
 
 // Caching device pool for the per-step temporaries and results of the count stage.  hipMalloc /
 // hipFree of multi-GB buffers cost far more than the kernels; blocks are recycled instead.  Reuse is

@@ -52,6 +52,7 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
         CR_REQUIRE(ctx, keys[i] < space, CRGPU_EINVAL, "whitelist key %u does not fit %u bases", i, len);
     CR_HIP(ctx, hipSetDevice(ctx->device));
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    cr_drop_miss_records(ctx);
 
     // canonical space: ascending packed order == byte-lexicographic order (barcode/src/lib.rs:119-124)
     std::vector<uint32_t> order(n_canon);
@@ -228,6 +229,7 @@ extern "C" int crgpu_counts_dev(crgpu_ctx *ctx, int lib, int which, uint32_t **d
 
 extern "C" int crgpu_reset_counts(crgpu_ctx *ctx) {
     if (!ctx) return CRGPU_EINVAL;
+    cr_drop_miss_records(ctx);
     for (auto &w : ctx->wl)
         if (w.set) {
             CR_HIP(ctx, hipMemsetAsync(w.d_valid, 0, sizeof(uint32_t) * ctx->n_canon, ctx->stream));

@@ -138,7 +138,10 @@ int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_
  * accumulated so far (or the one installed by crgpu_set_counts(CRGPU_COUNTS_PRIOR)); it must be
  * complete -- over all batches and all ranks -- before this call.  d_qualn NULL => no qualities
  * (corrector.rs:126 map_or).  d_corrected_out (nullable) gets 1 for ValidAfterCorrection.
- * Corrected counts accumulate in the context. */
+ * Corrected counts accumulate in the context.
+ * When the call follows crgpu_match_and_count_dev on the SAME d_cb / d_flags / d_idx buffers and n (their contents
+ * unchanged in between), the misses are taken from compact records that pass A left in the context instead of being
+ * found again by a scan of d_idx; any other call sequence scans.  The results are identical either way. */
 int crgpu_set_posterior(crgpu_ctx *ctx, double max_expected_barcode_errors, double bc_confidence_threshold);
 int crgpu_correct_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_qualn, const uint8_t *d_flags,
                       uint64_t n, uint32_t *d_idx_inout, uint8_t *d_corrected_out);

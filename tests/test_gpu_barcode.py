@@ -139,6 +139,18 @@ def test_hot_barcode_table_path_bit_exact(monkeypatch):
     _compare_barcode_stage(w, 200_000)
 
 
+def test_miss_record_overflow_falls_back_to_the_scan(monkeypatch):
+    """Pass A leaves compact records of its misses for pass B; when a wave's region overflows, pass B scans idx as it
+    does for any other call sequence -- same indices, flags and histograms."""
+    from cellranger_amd import synth as S
+
+    monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")
+    monkeypatch.setenv("CRGPU_MISS_RECORD_CAP", "3")
+    w = S.Workload(n_total=400_000, seed=S.SEED0 + 6)
+    st = _compare_barcode_stage(w, 400_000)
+    assert st["corrected"] > 8_000
+
+
 def test_dense_small_whitelists_many_neighbours_and_ties():
     """Short barcodes with a dense whitelist: several Hamming-1 neighbours per read, equal priors,
     thresholds that accept ties' winners -- exercises the f64 accumulation order and tie-breaks."""
