@@ -691,11 +691,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     // slices per bucket: ~2 workgroups per CU in total (128 KB of LDS each -> one resident per CU)
     uint32_t slices = 512 / plan.n_buckets;
     if (slices < 1) slices = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_hist_buckets, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SIZE * 4);
-        attr_set = true;
-    }
+    cr_allow_lds(ctx, (const void *)k_hist_buckets, BIN_SIZE * 4);
     // hot-barcode table: one library without translation, and enough reads to pay for the sampling batch
     // (CRGPU_HOT_MIN_READS lowers the threshold so that the parity tests can drive this path with small inputs)
     uint64_t hot_min = 16ull << 20;
@@ -715,7 +711,6 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
             cr_pool_free(ctx, d_cursor);
             return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc hot table failed");
         }
-        (void)hipFuncSetAttribute((const void *)k_lookup_hot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lookup_lds);
     }
     // miss records for K2: one region per wave of the lookup kernel (its grid is pinned to 256 workgroups)
     MissRecords &rec = ctx->rec;
@@ -742,6 +737,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
             cr_drop_miss_records(ctx);  // not fatal: K2 scans idx as before
         }
     }
+    if (use_hot) cr_allow_lds(ctx, (const void *)k_lookup_hot, lookup_lds);
     hipError_t e = hipSuccess;
     bool hot_ready = false;
     for (uint64_t off = 0; off < n && e == hipSuccess;) {

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -99,6 +100,8 @@ struct crgpu_ctx {
     uint32_t *d_canon_keys = nullptr;         // n_canon packed canonical barcodes, ascending (rank -> sequence)
     unsigned long long *d_hot_image = nullptr;  // K1's hot-barcode table (HOT_SLOTS entries) + 256 u32 of scratch
     MissRecords rec;
+    std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device
+    uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
 
     double max_expected_errors = 1.7976931348623157e308;  // corrector.rs:104 (f64::MAX)
     double confidence_threshold = 0.975;                   // corrector.rs:83
@@ -152,7 +155,12 @@ void cr_set_thread_error(const char *msg);
 
 // workspace that only grows; returned pointer valid until the next cr_scratch call
 int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out);
-void cr_drop_miss_records(crgpu_ctx *ctx);  // barcode.hip: forget (and release) the K1 -> K2 miss records
+void cr_drop_miss_records(crgpu_ctx *ctx);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel): the attribute is per device
+static inline void cr_allow_lds(crgpu_ctx *ctx, const void *kernel, size_t bytes) {
+    if (ctx->lds_attr_done.insert(kernel).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}  // barcode.hip: forget (and release) the K1 -> K2 miss records
 
 // Caching device pool for the per-step temporaries and results of the count stage.  hipMalloc /
 // hipFree of multi-GB buffers cost far more than the kernels; blocks are recycled instead.  Reuse is

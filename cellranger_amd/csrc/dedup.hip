@@ -865,14 +865,8 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         if (n_tiles > 1) {
             const size_t lds_small = (2 * UES_CAP + UES_BUCKETS * 8) * sizeof(uint32_t);
             const size_t lds_large = (2 * UE_CAP + UE_BUCKETS * 8) * sizeof(uint32_t);
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void *)k_correct_umis_edges<false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_large);
-                (void)hipFuncSetAttribute((const void *)k_giant_probe, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds_large);
-                attr_set = true;
-            }
+            cr_allow_lds(ctx, (const void *)k_correct_umis_edges<false>, lds_large);
+            cr_allow_lds(ctx, (const void *)k_giant_probe, lds_large);
             // work list of the segments with more than UE_CAP keys: one item per chunk of UE_CAP keys
             DevBuf giant_b, best_b;
             const uint64_t max_items = nd / (UE_CAP / 2) + 16;

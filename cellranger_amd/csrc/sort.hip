@@ -414,22 +414,13 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
     }
     CrTimer t(ctx, sizeof(K) == 8 ? CRGPU_T_SORT : CRGPU_T_DEDUP, n);
     // more than 64 KB of LDS per workgroup has to be requested per kernel, once
-    static bool attr_kv = false, attr_k = false;
     const size_t lds_kv = SortCfg<K, true>::lds_bytes(BITS), lds_k = SortCfg<K, false>::lds_bytes(BITS);
     if (d_vin) {
-        if (!attr_kv) {
-            (void)hipFuncSetAttribute((const void *)k_radix_scatter<K, true, DIG, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds_kv);
-            attr_kv = true;
-        }
+        cr_allow_lds(ctx, (const void *)k_radix_scatter<K, true, DIG, BITS>, lds_kv);
         hipLaunchKernelGGL((k_radix_scatter<K, true, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), lds_kv, ctx->stream,
                            d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb, nullptr, nullptr);
     } else {
-        if (!attr_k) {
-            (void)hipFuncSetAttribute((const void *)k_radix_scatter<K, false, DIG, BITS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds_k);
-            attr_k = true;
-        }
+        cr_allow_lds(ctx, (const void *)k_radix_scatter<K, false, DIG, BITS>, lds_k);
         hipLaunchKernelGGL((k_radix_scatter<K, false, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), lds_k, ctx->stream,
                            d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb, nullptr, nullptr);
     }
@@ -518,8 +509,8 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     typedef SortCfg<uint64_t, false> Cfg;
     const uint64_t n_chunks = (n + Cfg::CHUNK - 1) / Cfg::CHUNK;
     void *d_small = nullptr, *d_status = nullptr;
-    static uint32_t n_xcc = 0;
-    if (!n_xcc) n_xcc = probe_xccs(ctx);
+    if (!ctx->n_xcc) ctx->n_xcc = probe_xccs(ctx);
+    const uint32_t n_xcc = ctx->n_xcc;
     // histograms + per pass 16 ticket counters, a cache line each
     const size_t small_bytes = (size_t)OS_MAX_PASSES * RADIX_MAX * 4 + OS_MAX_PASSES * 16 * 128;
     CR_TRY(cr_pool_alloc(ctx, &d_small, small_bytes));
@@ -536,7 +527,6 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         hipLaunchKernelGGL(k_global_hist<uint64_t>, dim3(256), dim3(SORT_BLOCK), 0, ctx->stream, d_keys, n, plan, ghist);
         hipLaunchKernelGGL(k_scan_global_hist, dim3(plan.n_passes), dim3(RADIX_MAX), 0, ctx->stream, ghist);
     }
-    static bool attr8 = false, attr9 = false;
     uint64_t *in = d_keys, *out = d_tmp;
     for (uint32_t p = 0; p < plan.n_passes && e == hipSuccess; p++) {
         const bool wide = widths[p] == 9;
@@ -549,20 +539,12 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         // workgroups whatever the dispatcher's rotation: always the full grid (idle workgroups leave after one atomic)
         const dim3 grid((unsigned)(n_xcc > 1 || n_chunks > 512 ? 512 : n_chunks));
         if (wide) {
-            if (!attr9) {
-                (void)hipFuncSetAttribute((const void *)k_radix_scatter<uint64_t, false, RadixDigit, 9, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr9 = true;
-            }
+            cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, false, RadixDigit, 9, true>, lds);
             hipLaunchKernelGGL((k_radix_scatter<uint64_t, false, RadixDigit, 9, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
                                out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
                                (unsigned long long *)d_status, tickets + p * 16 * 32);
         } else {
-            if (!attr8) {
-                (void)hipFuncSetAttribute((const void *)k_radix_scatter<uint64_t, false, RadixDigit, 8, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr8 = true;
-            }
+            cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, false, RadixDigit, 8, true>, lds);
             hipLaunchKernelGGL((k_radix_scatter<uint64_t, false, RadixDigit, 8, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
                                out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
                                (unsigned long long *)d_status, tickets + p * 16 * 32);
