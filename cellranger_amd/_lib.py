@@ -67,6 +67,15 @@ class MatrixDevView(C.Structure):
     ]
 
 
+SHARD_METRIC_FIELDS = ["sequenced_reads", "bc_n_bases", "bc_bases", "umi_n_bases", "umi_bases", "bc_q30_bases", "bc_q30_den",
+                       "umi_q30_bases", "umi_q30_den", "good_umi", "has_n_barcode", "has_n_umi", "homopolymer_barcode",
+                       "homopolymer_umi", "low_min_qual_barcode", "low_min_qual_umi", "miss_whitelist_barcode"]
+
+
+class ShardMetrics(C.Structure):
+    _fields_ = [(f, C.c_uint64) for f in SHARD_METRIC_FIELDS]
+
+
 class SynthParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64),
@@ -126,6 +135,7 @@ SYMBOLS = {
     "crgpu_whitelist_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "crgpu_get_canon_order": (_i, [_vp, _vp, _vp]),
     "crgpu_pack_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp]),
+    "crgpu_shard_metrics_dev": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, C.POINTER(ShardMetrics)]),
     "crgpu_match_and_count_dev": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "crgpu_set_posterior": (_i, [_vp, _dbl, _dbl]),
     "crgpu_correct_dev": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _vp]),

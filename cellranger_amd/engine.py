@@ -415,6 +415,13 @@ class Context:
                                                    _p(d_dupflags)))
         return Counts(self, h)
 
+    def shard_metrics(self, d_cb, d_cb_qualn, cb_len, d_umi, d_umi_qualn, umi_len, d_idx, n):
+        """MAKE_SHARD's barcode / UMI read metrics as a dict of counts (make_shard_metrics.rs:263-332)"""
+        m = _lib.ShardMetrics()
+        self._check(self.L.crgpu_shard_metrics_dev(self.h, _p(d_cb), _p(d_cb_qualn), cb_len, _p(d_umi), _p(d_umi_qualn), umi_len,
+                                                   _p(d_idx), n, C.byref(m)))
+        return {f: int(getattr(m, f)) for f in _lib.SHARD_METRIC_FIELDS}
+
     def concat_matrices(self, mats, gem_groups):
         """merged matrix of several GEM wells: column concatenation in (gem_group, barcode) order"""
         arr = (C.c_void_p * len(mats))(*[C.cast(m._mv, C.c_void_p) for m in mats])

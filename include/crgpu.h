@@ -121,6 +121,28 @@ int crgpu_get_canon_order(crgpu_ctx *ctx, uint32_t *order_out, uint32_t *seqs_ou
 int crgpu_pack_dev(crgpu_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, uint32_t len,
                    uint32_t *d_packed_out, uint8_t *d_qualn_out, uint8_t *d_flags_inout);
 
+/* ---- MAKE_SHARD read metrics ----------------------------------------------------------
+ * The per-read quality metrics MakeShardVisitor::visit_processed_read accumulates for the barcode and UMI parts of a
+ * read (cr_lib/src/make_shard_metrics.rs:263-332; frac_n_bases / frac_q30_bases :355-392; thresholds :20-23), as one
+ * fused scan over the packed arrays (crgpu_pack_dev layout).  PercentMetrics come back as numerator / denominator
+ * counts; they add up over batches in the caller.  d_idx (nullable): pass A's output, for miss_whitelist_barcode.
+ * Not covered: R1/R2/I1/I2 metrics (those sequences are not inputs of this path), polyt_suffix_umi. */
+typedef struct {
+    uint64_t sequenced_reads;
+    uint64_t bc_n_bases, bc_bases;          /* bc_N_bases */
+    uint64_t umi_n_bases, umi_bases;        /* umi_N_bases */
+    uint64_t bc_q30_bases, bc_q30_den;      /* bc_bases_with_q30: q >= 30+33 over q > 2+33 */
+    uint64_t umi_q30_bases, umi_q30_den;    /* umi_bases_with_q30 */
+    uint64_t good_umi;                      /* Umi::is_valid (umi/src/info.rs:20-37) */
+    uint64_t has_n_barcode, has_n_umi;
+    uint64_t homopolymer_barcode, homopolymer_umi;
+    uint64_t low_min_qual_barcode, low_min_qual_umi; /* min quality - 33 < 10 */
+    uint64_t miss_whitelist_barcode;
+} crgpu_shard_metrics;
+int crgpu_shard_metrics_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_cb_qualn, uint32_t cb_len,
+                            const uint32_t *d_umi, const uint8_t *d_umi_qualn, uint32_t umi_len, const uint32_t *d_idx,
+                            uint64_t n, crgpu_shard_metrics *out);
+
 /* ---- pass A: exact match + valid-barcode histogram (K1) -----------------------------------------
  * Replaces Whitelist::check_and_update per read (whitelist.rs:494-517, called from
  * rna_read.rs:352-366) and MakeShardHistograms::observe (cr_lib/src/make_shard_metrics.rs:171-188).

@@ -232,3 +232,57 @@ int oracle_posterior_correct(const oracle_whitelist *wl, const oracle_hist *bc_c
     }
     return 0;
 }
+
+/* ---- MAKE_SHARD read metrics (make_shard_metrics.rs:263-332) ------------------------------------------------ */
+static int seq_has_n(const char *s, uint32_t len) {
+    for (uint32_t i = 0; i < len; i++)
+        if (s[i] == 'N') return 1;
+    return 0;
+}
+static int seq_is_homopolymer(const char *s, uint32_t len) { /* every adjacent pair equal (umi/src/info.rs:57-65) */
+    for (uint32_t i = 1; i < len; i++)
+        if (s[i - 1] != s[i]) return 0;
+    return 1;
+}
+static uint8_t min_qual(const uint8_t *q, uint32_t len) {
+    uint8_t m = 255;
+    for (uint32_t i = 0; i < len; i++)
+        if (q[i] < m) m = q[i];
+    return m;
+}
+void oracle_shard_metrics_scan(const char *cb, const uint8_t *cb_qual, uint32_t cb_len, const char *umi,
+                               const uint8_t *umi_qual, uint32_t umi_len, const uint8_t *exact_hit, uint64_t n,
+                               oracle_shard_metrics *out) {
+    oracle_shard_metrics m;
+    memset(&m, 0, sizeof(m));
+    for (uint64_t r = 0; r < n; r++) {
+        const char *b = cb + r * cb_len, *u = umi + r * umi_len;
+        const uint8_t *bq = cb_qual + r * cb_len, *uq = umi_qual + r * umi_len;
+        m.sequenced_reads++;
+        for (uint32_t i = 0; i < cb_len; i++) { /* frac_n_bases / frac_q30_bases, :359-392 */
+            m.bc_n_bases += b[i] == 'N';
+            m.bc_bases++;
+            if (bq[i] > 2 + 33) {
+                m.bc_q30_den++;
+                m.bc_q30_bases += bq[i] >= 30 + 33;
+            }
+        }
+        for (uint32_t i = 0; i < umi_len; i++) {
+            m.umi_n_bases += u[i] == 'N';
+            m.umi_bases++;
+            if (uq[i] > 2 + 33) {
+                m.umi_q30_den++;
+                m.umi_q30_bases += uq[i] >= 30 + 33;
+            }
+        }
+        m.good_umi += (uint64_t)oracle_umi_is_valid(u, uq, umi_len);
+        m.has_n_barcode += (uint64_t)seq_has_n(b, cb_len);
+        m.has_n_umi += (uint64_t)seq_has_n(u, umi_len);
+        m.homopolymer_barcode += (uint64_t)seq_is_homopolymer(b, cb_len);
+        m.homopolymer_umi += (uint64_t)seq_is_homopolymer(u, umi_len);
+        m.low_min_qual_barcode += (uint8_t)(min_qual(bq, cb_len) - 33) < 10; /* BARCODE_MIN_QUAL_THRESHOLD, :21,313-315 */
+        m.low_min_qual_umi += (uint8_t)(min_qual(uq, umi_len) - 33) < 10;    /* UMI_MIN_QUAL_THRESHOLD, :22,316 */
+        if (exact_hit) m.miss_whitelist_barcode += !exact_hit[r];
+    }
+    *out = m;
+}

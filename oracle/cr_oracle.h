@@ -208,6 +208,28 @@ int64_t oracle_find_closest_feature(const char *feat_seqs, uint32_t n_feat, uint
 void oracle_compute_feature_dist(const int64_t *counts, const uint32_t *feature_type,
                                  uint32_t n_feat, double *dist_out);
 
+/* ---- MAKE_SHARD read metrics over the barcode / UMI parts of a read (cr_lib/src/make_shard_metrics.rs:263-332,
+ * :355-392; constants :20-23; RnaRead::barcode_min_qual / umi_min_qual cr_types/src/rna_read.rs:738-749).
+ * PercentMetric numerators / denominators as plain counts.  bc_state: the oracle_barcode_stage result
+ * (0 = not on the whitelist after pass A ... see BcResult); miss_whitelist counts reads whose barcode is invalid
+ * after the exact match, i.e. bc_state != 1.  Not restated: the R1/R2/I1/I2 metrics (those sequences are not inputs of
+ * this path) and polyt_suffix_umi (SSeq::has_polyt_suffix lives in the un-vendored fastq_set crate). */
+typedef struct {
+    uint64_t sequenced_reads;
+    uint64_t bc_n_bases, bc_bases;          /* bc_N_bases */
+    uint64_t umi_n_bases, umi_bases;        /* umi_N_bases */
+    uint64_t bc_q30_bases, bc_q30_den;      /* bc_bases_with_q30: q >= 30+33 over q > 2+33 */
+    uint64_t umi_q30_bases, umi_q30_den;    /* umi_bases_with_q30 */
+    uint64_t good_umi;                      /* Umi::is_valid */
+    uint64_t has_n_barcode, has_n_umi;
+    uint64_t homopolymer_barcode, homopolymer_umi;
+    uint64_t low_min_qual_barcode, low_min_qual_umi; /* min quality - 33 < 10 */
+    uint64_t miss_whitelist_barcode;
+} oracle_shard_metrics;
+void oracle_shard_metrics_scan(const char *cb, const uint8_t *cb_qual, uint32_t cb_len, const char *umi,
+                               const uint8_t *umi_qual, uint32_t umi_len, const uint8_t *exact_hit /* nullable */,
+                               uint64_t n, oracle_shard_metrics *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -358,3 +358,26 @@ def compute_feature_dist(counts, feature_types):
     out = np.zeros(len(c), dtype=np.float64)
     lib().oracle_compute_feature_dist(_ptr(c), _ptr(t), len(c), _ptr(out))
     return out
+
+
+SHARD_METRIC_FIELDS = ["sequenced_reads", "bc_n_bases", "bc_bases", "umi_n_bases", "umi_bases", "bc_q30_bases", "bc_q30_den",
+                       "umi_q30_bases", "umi_q30_den", "good_umi", "has_n_barcode", "has_n_umi", "homopolymer_barcode",
+                       "homopolymer_umi", "low_min_qual_barcode", "low_min_qual_umi", "miss_whitelist_barcode"]
+
+
+class _ShardMetrics(C.Structure):
+    _fields_ = [(f, C.c_uint64) for f in SHARD_METRIC_FIELDS]
+
+
+def shard_metrics(cb, cb_qual, umi, umi_qual, exact_hit=None):
+    """(n, L) uint8 ASCII arrays -> dict of counts (oracle_shard_metrics_scan)"""
+    cb, cbq = np.ascontiguousarray(cb, np.uint8), np.ascontiguousarray(cb_qual, np.uint8)
+    umi, uq = np.ascontiguousarray(umi, np.uint8), np.ascontiguousarray(umi_qual, np.uint8)
+    hit = None if exact_hit is None else np.ascontiguousarray(exact_hit, np.uint8)
+    m = _ShardMetrics()
+    f = lib().oracle_shard_metrics_scan
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                  C.POINTER(_ShardMetrics)]
+    f(_ptr(cb), _ptr(cbq), cb.shape[1], _ptr(umi), _ptr(uq), umi.shape[1], _ptr(hit), cb.shape[0], C.byref(m))
+    return {k: int(getattr(m, k)) for k in SHARD_METRIC_FIELDS}

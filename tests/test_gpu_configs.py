@@ -108,3 +108,36 @@ def test_cfg5_wells_counted_separately_then_merged(tmp_path):
         ctxs[0].concat_matrices(mats, [2, 1])
     for c in ctxs:
         c.close()
+
+
+def test_shard_metrics_match_oracle():
+    """The fused MAKE_SHARD metric scan over packed arrays equals the oracle's per-read loop, including
+    N bases, low qualities below the Q30 denominator cut-off, homopolymers and whitelist misses."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import MISS
+
+    n = 300_000
+    w = S.Workload(n_total=n, seed=66, n_wl=5000, n_cells=50, n_ambient=500, n_genes=100, n_rate=0.01, cb_err=0.02)
+    r = w.host_reads(0, n)
+    rng = np.random.default_rng(66)
+    # spread the qualities over the thresholds (2, 10, 30) and plant homopolymers
+    lowq = np.array([33 + 1, 33 + 2, 33 + 3, 33 + 9, 33 + 10, 33 + 29, 33 + 30, 33 + 40], np.uint8)
+    for key, L in (("cb_qualn", 16), ("umi_qualn", 12)):
+        keep_n = r[key] & 0x80
+        r[key] = (lowq[rng.integers(0, len(lowq), (n, L))] | keep_n).astype(np.uint8)
+    r["umi"][rng.random(n) < 0.01] = 0           # AAAAAAAAAAAA
+    r["cb"][rng.random(n) < 0.005] = 0xFFFFFFFF   # TTTTTTTTTTTTTTTT
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    idx_a, idx_b, corr, dev = G.gpu_barcode_stage(c, r, n)
+    d_idx_a = c.upload(idx_a)
+    got = c.shard_metrics(dev["cb"], dev["cbq"], 16, c.upload(r["umi"]), c.upload(r["umi_qualn"]), 12, d_idx_a, n)
+    cb, cbq = S.to_ascii(r["cb"], r["cb_qualn"], 16)
+    umi, uq = S.to_ascii(r["umi"], r["umi_qualn"], 12)
+    exp = O.shard_metrics(cb, cbq, umi, uq, exact_hit=(idx_a != MISS).astype(np.uint8))
+    assert got == exp
+    assert exp["bc_n_bases"] > 1000 and exp["homopolymer_umi"] > 1000 and exp["low_min_qual_barcode"] > n // 2
+    assert 0 < exp["bc_q30_bases"] < exp["bc_q30_den"] < exp["bc_bases"]
+    c.close()

@@ -158,3 +158,30 @@ def test_barcode_index_golden():
     # into_indicator_vec (barcode_index.rs:70-75): sorted_barcodes[i] in filter_set
     assert [bytes(b).decode() in set(g["query"]) for b in res.barcodes] == g["indicator"]
     assert list(res.indptr) == [0, 1, 2, 3] and list(res.data) == [1, 1, 1]
+
+
+def test_shard_metrics_hand_computed():
+    """MAKE_SHARD barcode/UMI read metrics (make_shard_metrics.rs:263-332, :355-392): a case small enough to count by hand.
+    No reference fixture exists for these metrics (parity unpinned); the expected values follow the cited lines."""
+    import oracle_lib as O
+
+    def q(s):
+        return np.frombuffer(s.encode(), np.uint8)
+
+    cb = np.stack([np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"AAAA", np.uint8), np.frombuffer(b"ANGT", np.uint8)])
+    #                 q-33:  40 40 40 40            2 30 29 3                        40 9 40 40
+    cbq = np.stack([q("IIII"), q("#?>$"), q("I*II")])
+    umi = np.stack([np.frombuffer(b"ACG", np.uint8), np.frombuffer(b"TTT", np.uint8), np.frombuffer(b"NNN", np.uint8)])
+    uq = np.stack([q("III"), q("III"), q("II+")])  # last: 40 40 10
+    m = O.shard_metrics(cb, cbq, umi, uq, exact_hit=np.array([1, 1, 0], np.uint8))
+    assert m["sequenced_reads"] == 3
+    assert (m["bc_n_bases"], m["bc_bases"]) == (1, 12) and (m["umi_n_bases"], m["umi_bases"]) == (3, 9)
+    # q > 2+33 counts in the denominator: row 2 has q-33 = 2 (excluded), 30, 29, 3 -> den 3, num 1 (only 30)
+    assert (m["bc_q30_bases"], m["bc_q30_den"]) == (4 + 1 + 3, 4 + 3 + 4)
+    assert (m["umi_q30_bases"], m["umi_q30_den"]) == (3 + 3 + 2, 9)
+    assert m["good_umi"] == 1                     # TTT is a homopolymer, NNN has N
+    assert m["has_n_barcode"] == 1 and m["has_n_umi"] == 1
+    assert m["homopolymer_barcode"] == 1 and m["homopolymer_umi"] == 2   # NNN: every adjacent pair equal (info.rs:57-65)
+    assert m["low_min_qual_barcode"] == 2         # min q-33: 40, 2, 9
+    assert m["low_min_qual_umi"] == 0             # min q-33: 40, 40, 10 (10 is not below 10)
+    assert m["miss_whitelist_barcode"] == 1
