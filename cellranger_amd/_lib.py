@@ -159,6 +159,8 @@ SYMBOLS = {
     "crgpu_counts_free": (None, [_vp, _vp]),
     "crgpu_assemble_matrix": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_matrix_free": (None, [_vp, C.POINTER(MatrixView)]),
+    "crgpu_sum_matrices": (_i, [_vp, C.POINTER(MatrixView), C.POINTER(MatrixView), C.POINTER(C.POINTER(MatrixView))]),
+    "crgpu_select_barcodes": (_i, [_vp, C.POINTER(MatrixView), _vp, _u64, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_concat_matrices": (_i, [_vp, _vp, _vp, _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_write_mtx": (_i, [_vp, C.POINTER(MatrixView), C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint16]),
     "crgpu_assemble_matrix_dev": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(MatrixDevView))]),

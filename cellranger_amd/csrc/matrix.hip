@@ -180,6 +180,88 @@ extern "C" int crgpu_concat_matrices(crgpu_ctx *ctx, const crgpu_matrix *const *
     return CRGPU_OK;
 }
 
+static void finish_view(MatrixImpl *m, uint32_t n_features, uint32_t cb_len) {
+    m->view.n_barcodes = m->rank.size();
+    m->view.nnz = m->data.size();
+    m->view.n_features = n_features;
+    m->view.cb_len = cb_len;
+    m->view.barcode_rank = m->rank.data();
+    m->view.barcode_seq = m->seq.data();
+    m->view.indptr = m->indptr.data();
+    m->view.indices = m->indices.data();
+    m->view.data = m->data.data();
+    m->view.gem_group = m->gem_group.empty() ? nullptr : m->gem_group.data();
+}
+
+// CountMatrix.merge (lib/python/cellranger/matrix.py:479-482, merge_matrices :1319-1329): `self.m += other.m` on two
+// matrices of the same shape (same features, same barcodes in the same order) -- the element-wise sum, canonical CSC.
+extern "C" int crgpu_sum_matrices(crgpu_ctx *ctx, const crgpu_matrix *a, const crgpu_matrix *b, crgpu_matrix **out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    *out = nullptr;
+    CR_REQUIRE(ctx, a && b, CRGPU_EINVAL, "crgpu_sum_matrices: NULL matrix");
+    CR_REQUIRE(ctx, a->n_features == b->n_features && a->n_barcodes == b->n_barcodes && a->cb_len == b->cb_len, CRGPU_EINVAL,
+               "crgpu_sum_matrices: shapes differ (%u x %llu vs %u x %llu)", a->n_features, (unsigned long long)a->n_barcodes,
+               b->n_features, (unsigned long long)b->n_barcodes);
+    for (uint64_t c = 0; c < a->n_barcodes; c++)
+        CR_REQUIRE(ctx, a->barcode_seq[c] == b->barcode_seq[c] && (a->gem_group ? a->gem_group[c] : 0) == (b->gem_group ? b->gem_group[c] : 0),
+                   CRGPU_EINVAL, "crgpu_sum_matrices: column %llu holds different barcodes", (unsigned long long)c);
+    MatrixImpl *m = new (std::nothrow) MatrixImpl();
+    if (!m) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
+    m->rank.assign(a->barcode_rank, a->barcode_rank + a->n_barcodes);
+    m->seq.assign(a->barcode_seq, a->barcode_seq + a->n_barcodes);
+    if (a->gem_group) m->gem_group.assign(a->gem_group, a->gem_group + a->n_barcodes);
+    m->indptr.push_back(0);
+    for (uint64_t c = 0; c < a->n_barcodes; c++) {
+        int64_t i = a->indptr[c], j = b->indptr[c];
+        const int64_t ie = a->indptr[c + 1], je = b->indptr[c + 1];
+        while (i < ie || j < je) {  // merge of two index-sorted columns
+            int32_t row, v;
+            if (j >= je || (i < ie && a->indices[i] < b->indices[j])) {
+                row = a->indices[i];
+                v = a->data[i++];
+            } else if (i >= ie || b->indices[j] < a->indices[i]) {
+                row = b->indices[j];
+                v = b->data[j++];
+            } else {
+                row = a->indices[i];
+                v = a->data[i++] + b->data[j++];
+            }
+            m->indices.push_back(row);
+            m->data.push_back(v);
+        }
+        m->indptr.push_back((int64_t)m->data.size());
+    }
+    finish_view(m, a->n_features, a->cb_len);
+    *out = &m->view;
+    return CRGPU_OK;
+}
+
+// CountMatrix.select_barcodes (matrix.py:860-875): the columns `cols` in the given order.
+extern "C" int crgpu_select_barcodes(crgpu_ctx *ctx, const crgpu_matrix *a, const uint64_t *cols, uint64_t n_cols,
+                                     crgpu_matrix **out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    *out = nullptr;
+    CR_REQUIRE(ctx, a && (cols || n_cols == 0), CRGPU_EINVAL, "crgpu_select_barcodes: NULL argument");
+    for (uint64_t k = 0; k < n_cols; k++)
+        CR_REQUIRE(ctx, cols[k] < a->n_barcodes, CRGPU_EINVAL, "crgpu_select_barcodes: column %llu out of range",
+                   (unsigned long long)cols[k]);
+    MatrixImpl *m = new (std::nothrow) MatrixImpl();
+    if (!m) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
+    m->indptr.push_back(0);
+    for (uint64_t k = 0; k < n_cols; k++) {
+        const uint64_t c = cols[k];
+        m->rank.push_back(a->barcode_rank[c]);
+        m->seq.push_back(a->barcode_seq[c]);
+        if (a->gem_group) m->gem_group.push_back(a->gem_group[c]);
+        m->indices.insert(m->indices.end(), a->indices + a->indptr[c], a->indices + a->indptr[c + 1]);
+        m->data.insert(m->data.end(), a->data + a->indptr[c], a->data + a->indptr[c + 1]);
+        m->indptr.push_back((int64_t)m->data.size());
+    }
+    finish_view(m, a->n_features, a->cb_len);
+    *out = &m->view;
+    return CRGPU_OK;
+}
+
 extern "C" void crgpu_matrix_free(crgpu_ctx *, crgpu_matrix *mv) {
     if (!mv) return;
     delete reinterpret_cast<MatrixImpl *>(mv);  // view is the first member

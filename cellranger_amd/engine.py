@@ -422,6 +422,19 @@ class Context:
                                                    _p(d_idx), n, C.byref(m)))
         return {f: int(getattr(m, f)) for f in _lib.SHARD_METRIC_FIELDS}
 
+    def sum_matrices(self, a, b):
+        """CountMatrix.merge: element-wise sum of two matrices of the same shape"""
+        mv = C.POINTER(MatrixView)()
+        self._check(self.L.crgpu_sum_matrices(self.h, a._mv, b._mv, C.byref(mv)))
+        return Matrix(self, mv)
+
+    def select_barcodes(self, m, cols):
+        """CountMatrix.select_barcodes: the given columns in the given order"""
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        mv = C.POINTER(MatrixView)()
+        self._check(self.L.crgpu_select_barcodes(self.h, m._mv, ptr(cols), len(cols), C.byref(mv)))
+        return Matrix(self, mv)
+
     def concat_matrices(self, mats, gem_groups):
         """merged matrix of several GEM wells: column concatenation in (gem_group, barcode) order"""
         arr = (C.c_void_p * len(mats))(*[C.cast(m._mv, C.c_void_p) for m in mats])

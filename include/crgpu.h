@@ -287,6 +287,12 @@ typedef struct {
 int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const uint32_t *feature, const uint32_t *count,
                           uint64_t n_triplets, uint32_t n_features, crgpu_matrix **out);
 void crgpu_matrix_free(crgpu_ctx *ctx, crgpu_matrix *m);
+/* aggr-style post-processing of host matrices, as the reference does with scipy:
+ * crgpu_sum_matrices    CountMatrix.merge / merge_matrices (lib/python/cellranger/matrix.py:479-482,1319-1329): element-wise
+ *                       sum of two matrices of the same shape (same features, same barcodes in the same order);
+ * crgpu_select_barcodes CountMatrix.select_barcodes (matrix.py:860-875): the given columns in the given order. */
+int crgpu_sum_matrices(crgpu_ctx *ctx, const crgpu_matrix *a, const crgpu_matrix *b, crgpu_matrix **out);
+int crgpu_select_barcodes(crgpu_ctx *ctx, const crgpu_matrix *a, const uint64_t *cols, uint64_t n_cols, crgpu_matrix **out);
 /* Several GEM wells of one sample (BASELINE configs[4]: one well per GPU): the merged matrix is the column
  * concatenation in (gem_group, barcode) order -- Barcode orders by gem group first (barcode/src/lib.rs:119-124).
  * gem_groups[i] is the group of mats[i], strictly ascending; all matrices share n_features and cb_len. */

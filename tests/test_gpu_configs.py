@@ -141,3 +141,49 @@ def test_shard_metrics_match_oracle():
     assert exp["bc_n_bases"] > 1000 and exp["homopolymer_umi"] > 1000 and exp["low_min_qual_barcode"] > n // 2
     assert 0 < exp["bc_q30_bases"] < exp["bc_q30_den"] < exp["bc_bases"]
     c.close()
+
+
+def test_aggr_merge_and_barcode_selection_match_scipy():
+    """aggr-style post-processing: CountMatrix.merge is scipy's `m += other.m` on equal-shape matrices
+    and select_barcodes is scipy column indexing (lib/python/cellranger/matrix.py:479-482,860-875) -- scipy itself is
+    the checker here.  Two libraries of the SAME cells (same barcode index) are counted separately and summed."""
+    import scipy.sparse as sp
+
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import CrgpuError
+
+    n = 150_000
+    w = S.Workload(n_total=2 * n, seed=77, n_wl=20_000, n_cells=60, n_ambient=1500, n_genes=200)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+    # pass A/B over both halves so that both matrices share one barcode index, then count each half on its own
+    r = w.host_reads(0, 2 * n)
+    idx_a, idx_b, corr, dev = G.gpu_barcode_stage(c, r, 2 * n)
+    d_umi, d_uq, d_ft = c.upload(r["umi"]), c.upload(r["umi_qualn"]), c.upload(r["feature"])
+    mats = []
+    for h in range(2):
+        recs = c.records(n, w.umi_len, dev["idx"].ptr + 4 * h * n, d_umi.ptr + 4 * h * n, d_uq.ptr + 12 * h * n,
+                         d_ft.ptr + 4 * h * n, dev["flags"].ptr + h * n)
+        mats.append(c.count(recs, w.n_genes))
+    a, b = mats
+    assert np.array_equal(a.barcode_rank, b.barcode_rank) and a.nnz > 1000 and b.nnz > 1000
+
+    def to_sp(m):
+        return sp.csc_matrix((m.data, m.indices, m.indptr), shape=(m.n_features, m.n_barcodes))
+
+    tot = c.sum_matrices(a, b)
+    exp = to_sp(a) + to_sp(b)
+    exp.sort_indices()
+    assert np.array_equal(tot.indptr, exp.indptr) and np.array_equal(tot.indices, exp.indices) and np.array_equal(tot.data, exp.data)
+    assert np.array_equal(tot.barcode_rank, a.barcode_rank)
+    rng = np.random.default_rng(7)
+    cols = rng.permutation(a.n_barcodes)[: a.n_barcodes // 3]
+    sel = c.select_barcodes(tot, cols)
+    exp_sel = exp[:, cols]
+    assert np.array_equal(sel.indptr, exp_sel.indptr) and np.array_equal(sel.indices, exp_sel.indices)
+    assert np.array_equal(sel.data, exp_sel.data) and np.array_equal(sel.barcode_rank, a.barcode_rank[cols])
+    with pytest.raises(CrgpuError):
+        c.sum_matrices(tot, sel)  # shapes differ
+    c.close()
