@@ -642,7 +642,9 @@ __global__ __launch_bounds__(512) void k_hist_buckets(const WlViewSet vs, const 
     }
 }
 
-#define MB_STAGE_BUDGET (2ull << 30)  // bytes of u16 staging per super-batch
+#ifndef MB_STAGE_BUDGET
+#define MB_STAGE_BUDGET (8ull << 30)  // bytes of u16 staging per super-batch: 6 launch rounds per 1 B reads (2 GB = 22 rounds cost 1.1 ms more in ramp-up / table loads)
+#endif
 
 extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_flags, uint64_t n,
                                          uint32_t *d_idx_out) {
