@@ -1199,7 +1199,8 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
     std::vector<uint32_t> order(nm);
     for (uint64_t i = 0; i < nm; i++) order[i] = (uint32_t)i;
     auto fld = [&](uint64_t k, uint32_t sh, uint32_t bits) { return (uint32_t)((k >> sh) & (bits >= 64 ? ~0ull : ((1ull << bits) - 1))); };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    // with a single library the device order (barcode, feature, umi) already is the required one
+    if (L.bits_lib != 0) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         const uint64_t ka = keys[a], kb = keys[b];
         const uint32_t bca = (uint32_t)(ka >> L.sh_bc()), bcb = (uint32_t)(kb >> L.sh_bc());
         if (bca != bcb) return bca < bcb;
