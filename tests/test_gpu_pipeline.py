@@ -96,3 +96,121 @@ def test_pipeline_collective_path_on_one_rank_rccl_group():
         c.close()
     finally:
         dist.destroy_process_group()
+
+
+class _Hub:
+    """In-process stand-in for a process group: the ranks are threads, the collectives copy between the ranks'
+    device tensors (all on the one GPU of the test box).  Everything except RCCL itself is the product path."""
+
+    def __init__(self, world):
+        import threading
+
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class _ThreadDist:
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+
+    def get_world_size(self):
+        return self.hub.world
+
+    def get_rank(self):
+        return self.rank
+
+    def _post(self, x):
+        self.hub.slots[self.rank] = x
+        self.hub.barrier.wait()
+        got = list(self.hub.slots)
+        return got
+
+    def all_reduce(self, t, op=None):
+        import torch
+
+        got = self._post(t)
+        total = torch.stack([g.clone() for g in got]).sum(0)
+        self.hub.barrier.wait()  # everybody has read the inputs
+        t.copy_(total)
+        torch.cuda.synchronize()
+        self.hub.barrier.wait()
+
+    def all_gather_into_tensor(self, out, inp):
+        import torch
+
+        got = self._post(inp)
+        out.copy_(torch.cat([g.reshape(-1) for g in got]))
+        torch.cuda.synchronize()
+        self.hub.barrier.wait()
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
+        import torch
+
+        W = self.hub.world
+        if input_split_sizes is None:
+            input_split_sizes = [inp.numel() // W] * W
+        if output_split_sizes is None:
+            output_split_sizes = [out.numel() // W] * W
+        got = self._post((inp, list(input_split_sizes)))
+        o = 0
+        for src in range(W):
+            s_inp, s_splits = got[src]
+            a = sum(s_splits[: self.rank])
+            n = s_splits[self.rank]
+            assert n == output_split_sizes[src]
+            if n:
+                out[o:o + n].copy_(s_inp[a:a + n])
+            o += n
+        torch.cuda.synchronize()
+        self.hub.barrier.wait()
+
+
+def test_three_virtual_ranks_share_one_gpu():
+    """The multi-rank orchestration with the PRODUCT backend on real device memory: three ranks as threads with their
+    own contexts, streams and pools; C1 all-reduce, C2 all-to-all over histogram-balanced barcode ranges, C3 gather;
+    the matrix on rank 0 equals the single-process oracle on all reads."""
+    import threading
+
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+    from cellranger_amd.pipeline import CountPipeline, HipBackend
+
+    world, per = 3, 120_000
+    n = world * per
+    w = S.Workload(n_total=n, seed=43, n_wl=60_000, n_cells=150, n_ambient=5000, n_genes=500)
+    r_all = w.host_reads(0, n)
+    hub = _Hub(world)
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            c = G.fresh_ctx()
+            c.set_whitelist(0, w.wl_packed, length=16)
+            c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+            r = {k: v[rank * per:(rank + 1) * per] for k, v in r_all.items()}
+            shard = _make_shard(c, w, r, per)
+            be = HipBackend(c, 0)
+            pipe = CountPipeline(be, dist=_ThreadDist(hub, rank))
+            for _ in range(2):
+                be.reset()
+                m = pipe.run(shard)
+            results[rank] = (c, m)
+        except Exception as e:  # noqa: BLE001 - surfaced below; a dead rank must not leave the others at a barrier
+            errors.append(e)
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert results[1][1] is None and results[2][1] is None
+    c0, m0 = results[0]
+    _check_against_oracle(c0, w, r_all, m0)
+    for c, _ in results:
+        c.close()
