@@ -84,6 +84,23 @@ struct MissRecords {
     uint8_t *d_fl = nullptr;
 };
 
+// digit plan of the onesweep sort: which bits every pass sorts on (sort.hip)
+#define OS_MAX_PASSES 8
+#define RADIX_MAX 512  // passes of 9 bits are used when they save a whole pass (61-bit keys: 8+8+9+9+9+9+9)
+struct SweepPlan {
+    uint32_t n_passes;
+    uint32_t shift[OS_MAX_PASSES], mask[OS_MAX_PASSES];
+};
+// digit histograms of all passes that k_build_keys counted while it wrote the keys (consumed by the next sort of
+// exactly these keys, which then skips its own histogram read)
+struct KeyHistograms {
+    bool valid = false;
+    const uint64_t *d_keys = nullptr;
+    uint64_t n = 0;
+    SweepPlan plan{};
+    uint32_t *d_hist = nullptr;  // OS_MAX_PASSES x RADIX_MAX, pool block
+};
+
 struct crgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -100,6 +117,7 @@ struct crgpu_ctx {
     uint32_t *d_canon_keys = nullptr;         // n_canon packed canonical barcodes, ascending (rank -> sequence)
     unsigned long long *d_hot_image = nullptr;  // K1's hot-barcode table (HOT_SLOTS entries) + 256 u32 of scratch
     MissRecords rec;
+    KeyHistograms ghist;
     std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
 
@@ -156,6 +174,8 @@ void cr_set_thread_error(const char *msg);
 // workspace that only grows; returned pointer valid until the next cr_scratch call
 int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out);
 void cr_drop_miss_records(crgpu_ctx *ctx);
+// sort.hip: the plan radix_sort would use for 64-bit keys on bits [lo_bit, hi_bit); false = onesweep does not apply
+bool cr_sweep_plan(uint32_t lo_bit, uint32_t hi_bit, SweepPlan *plan, uint32_t *widths);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel): the attribute is per device
 static inline void cr_allow_lds(crgpu_ctx *ctx, const void *kernel, size_t bytes) {
     if (ctx->lds_attr_done.insert(kernel).second)

@@ -81,14 +81,22 @@ template <int LQW>
 struct __attribute__((aligned(4))) QRow {
     uint32_t w[LQW ? LQW : 1];
 };
-template <int LQW>
+template <int LQW, bool HIST>
 __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t *__restrict__ bc_idx,
                                                     const uint32_t *__restrict__ umi, const uint8_t *__restrict__ umi_q,
                                                     const uint32_t *__restrict__ feature, const uint8_t *__restrict__ flags,
                                                     uint64_t n, uint64_t *__restrict__ keys_out,
                                                     uint32_t *__restrict__ vals_out,
-                                                    unsigned long long *__restrict__ n_out) {
+                                                    unsigned long long *__restrict__ n_out, const SweepPlan plan,
+                                                    uint32_t *__restrict__ ghist) {
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
+    // ghist != NULL: the digits of every emitted key are counted for all passes of the sort that follows, which
+    // then needs no histogram read of its own (k_global_hist)
+    __shared__ uint32_t s_hist[HIST ? OS_MAX_PASSES * RADIX_MAX : 1];
+    if (HIST) {
+        for (uint32_t x = threadIdx.x; x < plan.n_passes * RADIX_MAX; x += 256) s_hist[x] = 0;
+        __syncthreads();
+    }
     const uint32_t L = kl.umi_len;
     const uint64_t chunk = 256ull * KEY_ITEMS;
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
@@ -146,6 +154,9 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
             keys[j] = ((uint64_t)b << kl.sh_bc) | ((uint64_t)f << kl.sh_feat) | ((uint64_t)lib << kl.sh_lib) |
                       ((uint64_t)u << kl.sh_umi) | ((fl & CRGPU_FLAG_NONTXOMIC) ? 1ull : 0ull);
             if (keep) mask |= 1u << j;
+            if (HIST && keep)
+                for (uint32_t p = 0; p < plan.n_passes; p++)
+                    atomicAdd(&s_hist[p * RADIX_MAX + ((uint32_t)(keys[j] >> plan.shift[p]) & plan.mask[p])], 1u);
         }
       }
       // one global atomic per 4096-read chunk (same-address atomics saturate near 88 per microsecond)
@@ -157,6 +168,11 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
             if (vals_out) vals_out[o] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);  // read ordinal
             o++;
         }
+    }
+    if (HIST) {
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < plan.n_passes * RADIX_MAX; x += 256)
+            if (s_hist[x]) atomicAdd(&ghist[x], s_hist[x]);
     }
 }
 
@@ -177,10 +193,27 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         CrTimer t(ctx, CRGPU_T_KEYS, recs->n);
         CR_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(*d_n), ctx->stream));
         const KL kl = make_kl(ctx->layout);
-        const dim3 grid(cr_grid(recs->n, 256));
-#define CR_BUILD_KEYS(LQW)                                                                                                 \
-    hipLaunchKernelGGL(k_build_keys<LQW>, grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, recs->d_umi_qualn, \
-                       recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n)
+        // keys only (no read ordinals): count the sort's digit histograms on the way (1024 workgroups keep the
+        // flush at a few million atomics)
+        KeyHistograms &gh = ctx->ghist;
+        gh.valid = false;
+        SweepPlan plan;
+        uint32_t widths[OS_MAX_PASSES];
+        memset(&plan, 0, sizeof(plan));
+        uint32_t *d_hist = nullptr;
+        if (!d_vals_out && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(0, ctx->layout.total_bits(), &plan, widths)) {
+            if (!gh.d_hist) CR_TRY(cr_pool_alloc(ctx, (void **)&gh.d_hist, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t)));
+            d_hist = gh.d_hist;
+            CR_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t), ctx->stream));
+        }
+        const dim3 grid(cr_grid(recs->n, 256, d_hist ? 1024u : 256u * 8u));
+#define CR_BUILD_KEYS(LQW)                                                                                                  \
+    if (d_hist)                                                                                                             \
+        hipLaunchKernelGGL((k_build_keys<LQW, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,     \
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist); \
+    else                                                                                                                    \
+        hipLaunchKernelGGL((k_build_keys<LQW, false>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,    \
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist)
         switch (recs->umi_len) {
             case 4: CR_BUILD_KEYS(1); break;
             case 8: CR_BUILD_KEYS(2); break;
@@ -188,12 +221,18 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
             case 16: CR_BUILD_KEYS(4); break;
             default: CR_BUILD_KEYS(0); break;
         }
+        if (d_hist) {
+            gh.d_keys = d_keys_out;
+            gh.plan = plan;
+            gh.valid = true;  // gh.n is filled in below, once the number of keys is known
+        }
 #undef CR_BUILD_KEYS
         CR_HIP(ctx, hipGetLastError());
     }
     unsigned long long h = 0;
     CR_TRY(crgpu_memcpy_d2h(ctx, &h, d_n, sizeof(h)));
     *n_keys_out = h;
+    ctx->ghist.n = h;
     return CRGPU_OK;
 }
 

@@ -36,7 +36,6 @@
 #define SORT_WAVES (SORT_BLOCK / 64)
 #define RADIX_BITS 8
 #define RADIX 256
-#define RADIX_MAX 512  // passes of 9 bits are used when they save a whole pass (61-bit keys: 8+8+9+9+9+9+9)
 #ifndef SORT_MAX_BLOCKS
 #define SORT_MAX_BLOCKS 1024
 #endif
@@ -429,11 +428,6 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
 }
 
 // ---- onesweep: all passes' digit histograms in one read of the keys -------------------------------------
-#define OS_MAX_PASSES 8
-struct SweepPlan {
-    uint32_t n_passes;
-    uint32_t shift[OS_MAX_PASSES], mask[OS_MAX_PASSES];
-};
 template <typename K>
 __global__ __launch_bounds__(SORT_BLOCK) void k_global_hist(const K *__restrict__ keys, uint64_t n, SweepPlan plan,
                                                             uint32_t *__restrict__ ghist /* [pass][RADIX_MAX] */) {
@@ -504,8 +498,9 @@ static bool onesweep_enabled() {
 }
 
 // keys only, 64-bit: global histograms once, then one look-back scatter per pass
+// d_prehist (nullable): the digit histograms k_build_keys already counted for exactly these keys
 static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, const SweepPlan &plan,
-                             const uint32_t *widths, bool *result_in_tmp) {
+                             const uint32_t *widths, bool *result_in_tmp, const uint32_t *d_prehist) {
     typedef SortCfg<uint64_t, false> Cfg;
     const uint64_t n_chunks = (n + Cfg::CHUNK - 1) / Cfg::CHUNK;
     void *d_small = nullptr, *d_status = nullptr;
@@ -524,7 +519,12 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     hipError_t e = hipMemsetAsync(d_small, 0, small_bytes, ctx->stream);
     {
         CrTimer t(ctx, CRGPU_T_SORT_HIST, n);
-        hipLaunchKernelGGL(k_global_hist<uint64_t>, dim3(256), dim3(SORT_BLOCK), 0, ctx->stream, d_keys, n, plan, ghist);
+        if (d_prehist) {
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(ghist, d_prehist, (size_t)OS_MAX_PASSES * RADIX_MAX * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        } else {
+            hipLaunchKernelGGL(k_global_hist<uint64_t>, dim3(256), dim3(SORT_BLOCK), 0, ctx->stream, d_keys, n, plan, ghist);
+        }
         hipLaunchKernelGGL(k_scan_global_hist, dim3(plan.n_passes), dim3(RADIX_MAX), 0, ctx->stream, ghist);
     }
     uint64_t *in = d_keys, *out = d_tmp;
@@ -569,6 +569,28 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     return CRGPU_OK;
 }
 
+bool cr_sweep_plan(uint32_t lo_bit, uint32_t hi_bit, SweepPlan *plan, uint32_t *widths) {
+    if (hi_bit <= lo_bit || !onesweep_enabled()) return false;
+    const uint32_t total = hi_bit - lo_bit;
+    const uint32_t p8 = (total + 7) / 8, p9 = (total + 8) / 9;
+    uint32_t n9 = 0;
+    if (p9 < p8 && total > 8 * p9) n9 = total - 8 * p9;
+    if (const char *e = getenv("CRGPU_SORT_DIGITS"))
+        if (atoi(e) == 8) n9 = 0;
+    const uint32_t passes = n9 ? p9 : p8;
+    if (passes > OS_MAX_PASSES) return false;
+    memset(plan, 0, sizeof(*plan));
+    for (uint32_t pass = 0, sh = lo_bit; pass < passes && sh < hi_bit; pass++) {
+        const uint32_t width = pass >= passes - n9 ? 9u : 8u;
+        const uint32_t bits = hi_bit - sh < width ? hi_bit - sh : width;
+        plan->shift[plan->n_passes] = sh;
+        plan->mask[plan->n_passes] = (1u << bits) - 1u;
+        widths[plan->n_passes++] = width;
+        sh += width;
+    }
+    return true;
+}
+
 template <typename K>
 static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp, uint64_t n,
                       uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
@@ -585,19 +607,17 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
     if (const char *e = getenv("CRGPU_SORT_DIGITS"))     // "8": 8-bit digits only (A/B)
         if (atoi(e) == 8) n9 = 0;
     const uint32_t passes = n9 ? p9 : p8;
-    if (sizeof(K) == 8 && !d_vals && onesweep_enabled() && passes <= OS_MAX_PASSES) {
+    if (sizeof(K) == 8) {
         SweepPlan plan;
         uint32_t widths[OS_MAX_PASSES];
-        plan.n_passes = 0;
-        for (uint32_t pass = 0, sh = lo_bit; pass < passes && sh < hi_bit; pass++) {
-            const uint32_t width = pass >= passes - n9 ? 9u : 8u;
-            const uint32_t bits = hi_bit - sh < width ? hi_bit - sh : width;
-            plan.shift[plan.n_passes] = sh;
-            plan.mask[plan.n_passes] = (1u << bits) - 1u;
-            widths[plan.n_passes++] = width;
-            sh += width;
-        }
-        return onesweep_sort_u64(ctx, (uint64_t *)d_keys, (uint64_t *)d_tmp, n, plan, widths, result_in_tmp);
+        const bool sweep = !d_vals && cr_sweep_plan(lo_bit, hi_bit, &plan, widths);
+        KeyHistograms &gh = ctx->ghist;
+        const bool have_hist = sweep && gh.valid && gh.d_keys == (const uint64_t *)d_keys && gh.n == n &&
+                               memcmp(&gh.plan, &plan, sizeof(plan)) == 0;
+        gh.valid = false;  // consumed (or stale) either way
+        if (sweep)
+            return onesweep_sort_u64(ctx, (uint64_t *)d_keys, (uint64_t *)d_tmp, n, plan, widths, result_in_tmp,
+                                     have_hist ? gh.d_hist : nullptr);
     }
     uint32_t shift = lo_bit;
     for (uint32_t pass = 0; pass < passes && shift < hi_bit; pass++) {
