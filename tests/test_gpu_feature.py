@@ -55,15 +55,17 @@ def test_feature_golden_vectors_on_gpu(name):
     c.close()
 
 
-def test_feature_matching_random_vs_oracle():
+@pytest.mark.parametrize("n_feat,n", [(200, 60_000), (1500, 20_000)])
+def test_feature_matching_random_vs_oracle(n_feat, n):
+    """(200 features: the 256-thread kernel; 1500: one 1024-thread workgroup per CU around a larger LDS table)"""
     import gpu_helpers as G
     import oracle_lib as O
     from cellranger_amd import engine as E
     from cellranger_amd._lib import NO_FEATURE
 
     rng = np.random.default_rng(4)
-    L, n_feat, n = 15, 200, 60_000
-    feats = np.unique(rng.integers(0, 1 << 30, size=400, dtype=np.uint64))[:n_feat].astype(np.uint32)
+    L = 15
+    feats = np.unique(rng.integers(0, 1 << 30, size=4 * n_feat, dtype=np.uint64))[:n_feat].astype(np.uint32)
     feats = rng.permutation(feats)
     feat_ascii = E.unpack_seqs(feats, L)
     counts = rng.integers(0, 1000, n_feat)
@@ -100,5 +102,5 @@ def test_feature_matching_random_vs_oracle():
         exp_exact[i] = NO_FEATURE if f < 0 else index[f]
     assert np.array_equal(got, exp)
     assert np.array_equal(got_exact, exp_exact)
-    assert (exp != NO_FEATURE).sum() > n // 2 and (exp != exp_exact).sum() > 1000
+    assert (exp != NO_FEATURE).sum() > n // 2 and (exp != exp_exact).sum() > n // 60
     c.close()
