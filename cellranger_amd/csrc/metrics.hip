@@ -12,18 +12,32 @@ struct RowStats {
     uint32_t n_bases, q30, q30_den, min_q;
     bool any_low;  // some (q - 33) as u8 below 10: the per-base rule of UmiInfo::new
 };
+__device__ __forceinline__ void row_byte(RowStats &r, uint32_t b) {
+    const uint32_t v = b & 0x7Fu;
+    r.n_bases += b >> 7;
+    if (v > 2u + 33u) {
+        r.q30_den++;
+        r.q30 += v >= 30u + 33u;
+    }
+    r.min_q = v < r.min_q ? v : r.min_q;
+    r.any_low |= (uint8_t)(v - 33u) < 10u;
+}
 __device__ __forceinline__ RowStats row_stats(const uint8_t *__restrict__ q, uint32_t len) {
     RowStats r{0, 0, 0, 255u, false};
-    for (uint32_t k = 0; k < len; k++) {
-        const uint32_t b = q[k];
-        const uint32_t v = b & 0x7Fu;
-        r.n_bases += b >> 7;
-        if (v > 2u + 33u) {
-            r.q30_den++;
-            r.q30 += v >= 30u + 33u;
-        }
-        r.min_q = v < r.min_q ? v : r.min_q;
-        r.any_low |= (uint8_t)(v - 33u) < 10u;
+    if ((len & 3u) == 0u && ((uintptr_t)q & 3u) == 0u) {
+        // rows of 4k bytes: k dword loads (12- and 16-byte rows of neighbouring lanes coalesce)
+        const uint32_t *__restrict__ w = reinterpret_cast<const uint32_t *>(q);
+        uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            if (k < (len >> 2)) d[k] = w[k];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            if (k < (len >> 2))
+#pragma unroll
+                for (uint32_t b = 0; b < 4; b++) row_byte(r, (d[k] >> (8u * b)) & 0xFFu);
+    } else {
+        for (uint32_t k = 0; k < len; k++) row_byte(r, q[k]);
     }
     return r;
 }
