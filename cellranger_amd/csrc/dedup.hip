@@ -774,13 +774,16 @@ __global__ __launch_bounds__(256) void k_rep_read(const uint64_t *__restrict__ k
     }
 }
 
+struct __attribute__((aligned(4))) DupRec {
+    uint32_t umi, read_count, flags;
+};
+
 __global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ vals,
                                                   const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
                                                   const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc_all,
                                                   const uint8_t *__restrict__ low,
                                                   const unsigned long long *__restrict__ minraw,
-                                                  const uint32_t *__restrict__ rep_read, uint32_t *__restrict__ out_umi,
-                                                  uint32_t *__restrict__ out_cnt, uint8_t *__restrict__ out_flags) {
+                                                  const uint32_t *__restrict__ rep_read, DupRec *__restrict__ packed) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
         const uint32_t b = upos[k], e = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
@@ -796,10 +799,22 @@ __global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *_
                                        (low[K] ? CRGPU_DUP_LOW_SUPPORT : 0));
         for (uint32_t i = b; i < e; i++) {
             const uint32_t r = vals[i];
-            if (out_umi) out_umi[r] = umi;
-            if (out_cnt) out_cnt[r] = read_count;
-            if (out_flags) out_flags[r] = (uint8_t)(base | ((!low[K] && r == rep) ? CRGPU_DUP_UMI_COUNT : 0));
+            // one 12-byte store per read: the position of a read in sorted order has nothing to do with its ordinal,
+            // and three separate scattered stores cost three partial-line writes per read (38 GB per 200 M reads)
+            packed[r] = DupRec{umi, read_count, (uint32_t)(base | ((!low[K] && r == rep) ? CRGPU_DUP_UMI_COUNT : 0))};
         }
+    }
+}
+
+// the packed records -> the three output arrays of the ABI, streaming
+__global__ __launch_bounds__(256) void k_unpack_dupinfo(const DupRec *__restrict__ packed, uint64_t n, uint32_t *__restrict__ out_umi,
+                                                        uint32_t *__restrict__ out_cnt, uint8_t *__restrict__ out_flags) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const DupRec d = packed[r];
+        if (out_umi) out_umi[r] = d.umi;
+        if (out_cnt) out_cnt[r] = d.read_count;
+        if (out_flags) out_flags[r] = (uint8_t)d.flags;
     }
 }
 
@@ -824,6 +839,7 @@ static int read_u32(crgpu_ctx *ctx, const uint32_t *d, uint32_t *h) {
 }
 
 struct PerRead {
+    uint64_t n_reads = 0;        // entries of the output arrays
     uint32_t *d_vals = nullptr;  // read ordinal of every key (sorted along with the keys)
     uint32_t *out_umi = nullptr, *out_cnt = nullptr;
     uint8_t *out_flags = nullptr;
@@ -995,14 +1011,18 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
 
     // 5b. optional per-read DupInfo
     if (vals) {
-        DevBuf rep_b;
+        DevBuf rep_b, packed_b;
         CR_TRY(dmalloc(ctx, rep_b, nd * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, packed_b, pr.n_reads * sizeof(DupRec)));
         CrTimer t(ctx, CRGPU_T_DEDUP);
+        // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): all-zero records
+        CR_HIP(ctx, hipMemsetAsync(packed_b.p, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
         hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
                            rep_b.as<uint32_t>());
         hipLaunchKernelGGL(k_per_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys, corr,
-                           inc_all, low, minraw_b.as<unsigned long long>(), rep_b.as<uint32_t>(), pr.out_umi, pr.out_cnt,
-                           pr.out_flags);
+                           inc_all, low, minraw_b.as<unsigned long long>(), rep_b.as<uint32_t>(), packed_b.as<DupRec>());
+        hipLaunchKernelGGL(k_unpack_dupinfo, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream, packed_b.as<DupRec>(),
+                           pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
         CR_HIP(ctx, hipGetLastError());
     }
 
@@ -1049,20 +1069,22 @@ extern "C" int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs
     *out = nullptr;
     CR_REQUIRE(ctx, recs->n < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_count_records: at most 2^32-2 records per call");
     const uint64_t n = recs->n;
-    // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291)
-    if (d_processed_umi_out) CR_HIP(ctx, hipMemsetAsync(d_processed_umi_out, 0, n * sizeof(uint32_t), ctx->stream));
-    if (d_read_count_out) CR_HIP(ctx, hipMemsetAsync(d_read_count_out, 0, n * sizeof(uint32_t), ctx->stream));
-    if (d_dupflags_out) CR_HIP(ctx, hipMemsetAsync(d_dupflags_out, 0, n, ctx->stream));
     DevBuf keys_b, vals_b;
     CR_TRY(dmalloc(ctx, keys_b, n * sizeof(uint64_t)));
     CR_TRY(dmalloc(ctx, vals_b, n * sizeof(uint32_t)));
     uint64_t n_keys = 0;
     CR_TRY(build_keys_impl(ctx, recs, keys_b.as<uint64_t>(), vals_b.as<uint32_t>(), &n_keys));
     PerRead pr;
+    pr.n_reads = n;
     pr.d_vals = vals_b.as<uint32_t>();
     pr.out_umi = d_processed_umi_out;
     pr.out_cnt = d_read_count_out;
     pr.out_flags = d_dupflags_out;
+    if (n_keys == 0) {  // no read reaches DupBuilder::observe: no DupInfo anywhere (mark_dups.rs:289-291)
+        if (d_processed_umi_out) CR_HIP(ctx, hipMemsetAsync(d_processed_umi_out, 0, n * sizeof(uint32_t), ctx->stream));
+        if (d_read_count_out) CR_HIP(ctx, hipMemsetAsync(d_read_count_out, 0, n * sizeof(uint32_t), ctx->stream));
+        if (d_dupflags_out) CR_HIP(ctx, hipMemsetAsync(d_dupflags_out, 0, n, ctx->stream));
+    }
     return count_keys_impl(ctx, keys_b.as<uint64_t>(), n_keys, out, pr);
 }
 

@@ -499,9 +499,12 @@ static bool onesweep_enabled() {
 
 // keys only, 64-bit: global histograms once, then one look-back scatter per pass
 // d_prehist (nullable): the digit histograms k_build_keys already counted for exactly these keys
-static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, const SweepPlan &plan,
-                             const uint32_t *widths, bool *result_in_tmp, const uint32_t *d_prehist) {
-    typedef SortCfg<uint64_t, false> Cfg;
+// d_vals / d_vals_tmp (HAS_VALS): a 32-bit payload travels with every key
+template <bool HAS_VALS>
+static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
+                             uint64_t n, const SweepPlan &plan, const uint32_t *widths, bool *result_in_tmp,
+                             const uint32_t *d_prehist) {
+    typedef SortCfg<uint64_t, HAS_VALS> Cfg;
     const uint64_t n_chunks = (n + Cfg::CHUNK - 1) / Cfg::CHUNK;
     void *d_small = nullptr, *d_status = nullptr;
     if (!ctx->n_xcc) ctx->n_xcc = probe_xccs(ctx);
@@ -528,6 +531,7 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         hipLaunchKernelGGL(k_scan_global_hist, dim3(plan.n_passes), dim3(RADIX_MAX), 0, ctx->stream, ghist);
     }
     uint64_t *in = d_keys, *out = d_tmp;
+    uint32_t *vin = d_vals, *vout = d_vals_tmp;
     for (uint32_t p = 0; p < plan.n_passes && e == hipSuccess; p++) {
         const bool wide = widths[p] == 9;
         const size_t lds = Cfg::lds_bytes(wide ? 9 : 8);
@@ -539,20 +543,23 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         // workgroups whatever the dispatcher's rotation: always the full grid (idle workgroups leave after one atomic)
         const dim3 grid((unsigned)(n_xcc > 1 || n_chunks > 512 ? 512 : n_chunks));
         if (wide) {
-            cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, false, RadixDigit, 9, true>, lds);
-            hipLaunchKernelGGL((k_radix_scatter<uint64_t, false, RadixDigit, 9, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
-                               out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
+            cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 9, true>, lds);
+            hipLaunchKernelGGL((k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 9, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
+                               out, vin, vout, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
                                (unsigned long long *)d_status, tickets + p * 16 * 32);
         } else {
-            cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, false, RadixDigit, 8, true>, lds);
-            hipLaunchKernelGGL((k_radix_scatter<uint64_t, false, RadixDigit, 8, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
-                               out, nullptr, nullptr, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
+            cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 8, true>, lds);
+            hipLaunchKernelGGL((k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 8, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
+                               out, vin, vout, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
                                (unsigned long long *)d_status, tickets + p * 16 * 32);
         }
         if (e == hipSuccess) e = hipGetLastError();
         uint64_t *t2 = in;
         in = out;
         out = t2;
+        uint32_t *tv = vin;
+        vin = vout;
+        vout = tv;
         *result_in_tmp = !*result_in_tmp;
     }
     uint32_t aborted = 0;
@@ -610,14 +617,17 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
     if (sizeof(K) == 8) {
         SweepPlan plan;
         uint32_t widths[OS_MAX_PASSES];
-        const bool sweep = !d_vals && cr_sweep_plan(lo_bit, hi_bit, &plan, widths);
+        const bool sweep = cr_sweep_plan(lo_bit, hi_bit, &plan, widths);
         KeyHistograms &gh = ctx->ghist;
         const bool have_hist = sweep && gh.valid && gh.d_keys == (const uint64_t *)d_keys && gh.n == n &&
                                memcmp(&gh.plan, &plan, sizeof(plan)) == 0;
         gh.valid = false;  // consumed (or stale) either way
+        if (sweep && d_vals)
+            return onesweep_sort_u64<true>(ctx, (uint64_t *)d_keys, (uint64_t *)d_tmp, d_vals, d_vals_tmp, n, plan, widths,
+                                           result_in_tmp, nullptr);
         if (sweep)
-            return onesweep_sort_u64(ctx, (uint64_t *)d_keys, (uint64_t *)d_tmp, n, plan, widths, result_in_tmp,
-                                     have_hist ? gh.d_hist : nullptr);
+            return onesweep_sort_u64<false>(ctx, (uint64_t *)d_keys, (uint64_t *)d_tmp, nullptr, nullptr, n, plan, widths,
+                                            result_in_tmp, have_hist ? gh.d_hist : nullptr);
     }
     uint32_t shift = lo_bit;
     for (uint32_t pass = 0; pass < passes && shift < hi_bit; pass++) {
