@@ -76,6 +76,11 @@ class ShardMetrics(C.Structure):
     _fields_ = [(f, C.c_uint64) for f in SHARD_METRIC_FIELDS]
 
 
+# crgpu_barcode_summary_row as a numpy record
+BARCODE_SUMMARY_DTYPE = np.dtype([("barcode_rank", np.uint32), ("library", np.uint32), ("reads", np.uint64), ("umis", np.uint64),
+                                  ("candidate_dup_reads", np.uint64), ("umi_corrected_reads", np.uint64)])
+
+
 class SynthParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64),
@@ -156,6 +161,9 @@ SYMBOLS = {
     "crgpu_counts_triplets": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "crgpu_counts_molecules": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "crgpu_counts_molecule_info": (_i, [_vp, _vp, C.c_uint16, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "crgpu_enable_barcode_summary": (_i, [_vp, _i]),
+    "crgpu_counts_barcode_summary": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, C.POINTER(_u64)]),
+    "crgpu_write_barcode_summary_csv": (_i, [_vp, _vp, _u64, C.c_uint16, _vp, C.POINTER(C.c_char_p), _u32, C.c_char_p]),
     "crgpu_counts_free": (None, [_vp, _vp]),
     "crgpu_assemble_matrix": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_matrix_free": (None, [_vp, C.POINTER(MatrixView)]),

@@ -138,6 +138,7 @@ struct crgpu_ctx {
         bool in_use;
     };
     std::vector<PoolBlock> pool;
+    bool barcode_summary_on = false;  // crgpu_count_keys_dev keeps the corrected-read table (crgpu_enable_barcode_summary)
     uint64_t pool_budget = 64ull << 30;  // bytes the pool may hold before it starts re-using larger blocks (set at create)
 
     // timing ledger

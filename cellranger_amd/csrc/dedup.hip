@@ -32,6 +32,8 @@ struct crgpu_counts {
     uint32_t *d_bc = nullptr, *d_feature = nullptr, *d_count = nullptr;  // triplets
     uint64_t *d_mkeys = nullptr;    // molecule keys (primary layout), n_molecules
     uint32_t *d_mreads = nullptr;   // read_count of each molecule
+    uint32_t *d_corr_reads = nullptr;  // [library][barcode rank] reads whose UMI was corrected (BarcodeSummary), or NULL
+    uint32_t n_canon = 0;
     KeyLayout layout;
 };
 
@@ -821,6 +823,87 @@ __global__ __launch_bounds__(256) void k_unpack_dupinfo(const DupRec *__restrict
 // ------------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------------
+// BarcodeSummary::observe (cr_lib/src/aligner.rs:54-67), column umi_corrected_reads: reads whose raw (umi, feature) is a
+// key of umi_corrections.  Corrections are rare (the UMI error rate), so these are few scattered atomics.
+__global__ __launch_bounds__(256) void k_corrected_reads(const KL kl, const uint64_t *__restrict__ ukey,
+                                                         const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+                                                         const uint32_t *__restrict__ corr, uint32_t W,
+                                                         uint32_t *__restrict__ tab) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
+        if (corr[k] == NONE32) continue;
+        const uint64_t key = ukey[k];
+        const uint32_t run = (k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys) - upos[k];
+        const uint32_t lib = (uint32_t)((key >> kl.sh_lib) & lowmask(kl.bits_lib));
+        atomicAdd(&tab[(size_t)lib * W + (uint32_t)(key >> kl.sh_bc)], run);
+    }
+}
+
+// columns umis and candidate_dup_reads of the BarcodeSummary from the molecule table: every molecule has exactly one read
+// with is_umi_count(), and the reads of the kept (not low-support) molecules are the candidate_dup_reads.  Molecules are
+// sorted by barcode, so a thread sums a run of its MS_ITEMS consecutive molecules before it touches the table.
+constexpr int MS_ITEMS = 8;
+__global__ __launch_bounds__(256) void k_molecule_sums(const KL kl, const uint64_t *__restrict__ mkeys,
+                                                       const uint32_t *__restrict__ mreads, uint64_t nm, uint32_t W,
+                                                       uint32_t *__restrict__ umis, uint32_t *__restrict__ cand) {
+    const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * MS_ITEMS;
+    if (base >= nm) return;
+    uint64_t key[MS_ITEMS];
+    uint32_t rd[MS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < MS_ITEMS; j++) {
+        const uint64_t i = base + j < nm ? base + j : nm - 1;
+        key[j] = mkeys[i];
+        rd[j] = mreads[i];
+    }
+    size_t cur = ~(size_t)0;
+    uint32_t n_u = 0, n_c = 0;
+#pragma unroll
+    for (int j = 0; j < MS_ITEMS; j++) {
+        if (base + j >= nm) break;
+        const uint32_t lib = (uint32_t)((key[j] >> kl.sh_lib) & lowmask(kl.bits_lib));
+        const size_t slot = (size_t)lib * W + (uint32_t)(key[j] >> kl.sh_bc);
+        if (slot != cur) {
+            if (n_u) {
+                atomicAdd(&umis[cur], n_u);
+                atomicAdd(&cand[cur], n_c);
+            }
+            cur = slot;
+            n_u = n_c = 0;
+        }
+        n_u += 1;
+        n_c += rd[j];
+    }
+    if (n_u) {
+        atomicAdd(&umis[cur], n_u);
+        atomicAdd(&cand[cur], n_c);
+    }
+}
+
+struct SummaryFlag {  // barcode rank with at least one read of this library (a BarcodeSummary row exists)
+    const uint32_t *valid, *corrected;
+    uint32_t lo;
+    __device__ __forceinline__ bool operator()(uint64_t i) const { return (valid[lo + i] + corrected[lo + i]) != 0u; }
+};
+struct EmitSummary {
+    const uint32_t *valid, *corrected, *umis, *cand, *corr_reads;  // the last three may be NULL (no molecules)
+    uint32_t lo, lib;
+    crgpu_barcode_summary_row *rows;
+    struct Pre {};
+    __device__ __forceinline__ Pre pre(uint64_t) const { return Pre(); }
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t o, Pre) const {
+        const uint32_t r = lo + (uint32_t)i;
+        crgpu_barcode_summary_row w;
+        w.barcode_rank = r;
+        w.library = lib;
+        w.reads = (uint64_t)valid[r] + corrected[r];
+        w.umis = umis ? umis[r] : 0u;
+        w.candidate_dup_reads = cand ? cand[r] : 0u;
+        w.umi_corrected_reads = corr_reads ? corr_reads[r] : 0u;
+        rows[o] = w;
+    }
+};
+
 struct DevBuf {  // pooled temporary, returned to the context's pool at scope exit
     crgpu_ctx *ctx = nullptr;
     void *p = nullptr;
@@ -839,6 +922,7 @@ static int read_u32(crgpu_ctx *ctx, const uint32_t *d, uint32_t *h) {
 }
 
 struct PerRead {
+    bool summary = false;        // keep the per-barcode corrected-read table for crgpu_counts_barcode_summary
     uint64_t n_reads = 0;        // entries of the output arrays
     uint32_t *d_vals = nullptr;  // read ordinal of every key (sorted along with the keys)
     uint32_t *out_umi = nullptr, *out_cnt = nullptr;
@@ -855,6 +939,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     crgpu_counts *res = new (std::nothrow) crgpu_counts();
     if (!res) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
     res->layout = L;
+    res->n_canon = ctx->n_canon;
     if (n_keys == 0) {
         *out = res;
         return CRGPU_OK;
@@ -1026,6 +1111,18 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CR_HIP(ctx, hipGetLastError());
     }
 
+    // 5c. optional: reads with a corrected UMI per (library, barcode) -- the one BarcodeSummary column that cannot be
+    //     derived from the molecule table afterwards
+    if (pr.summary) {
+        const size_t bytes = ((size_t)1 << L.bits_lib) * ctx->n_canon * sizeof(uint32_t);
+        CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_corr_reads, bytes));
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        CR_HIP(ctx, hipMemsetAsync(res->d_corr_reads, 0, bytes, ctx->stream));
+        hipLaunchKernelGGL(k_corrected_reads, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, corr,
+                           ctx->n_canon, res->d_corr_reads);
+        CR_HIP(ctx, hipGetLastError());
+    }
+
     // 6. (barcode, feature) triplets = run lengths of the molecule keys at the feature boundary
     DevBuf tpos_b;
     CR_TRY(dmalloc(ctx, tpos_b, (nm + 1) * sizeof(uint32_t)));
@@ -1060,7 +1157,9 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
 }
 
 extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out) {
-    return count_keys_impl(ctx, d_keys_inout, n_keys, out, PerRead());
+    PerRead pr;
+    pr.summary = ctx->barcode_summary_on;
+    return count_keys_impl(ctx, d_keys_inout, n_keys, out, pr);
 }
 
 extern "C" int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
@@ -1075,6 +1174,7 @@ extern "C" int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs
     uint64_t n_keys = 0;
     CR_TRY(build_keys_impl(ctx, recs, keys_b.as<uint64_t>(), vals_b.as<uint32_t>(), &n_keys));
     PerRead pr;
+    pr.summary = true;
     pr.n_reads = n;
     pr.d_vals = vals_b.as<uint32_t>();
     pr.out_umi = d_processed_umi_out;
@@ -1283,6 +1383,69 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
     return CRGPU_OK;
 }
 
+extern "C" int crgpu_enable_barcode_summary(crgpu_ctx *ctx, int on) {
+    if (!ctx) return CRGPU_EINVAL;
+    ctx->barcode_summary_on = on != 0;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_counts_barcode_summary(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t rank_lo, uint32_t rank_hi,
+                                            crgpu_barcode_summary_row *rows_out, uint64_t cap, uint64_t *n_rows_out) {
+    if (!ctx || !c || !n_rows_out) return CRGPU_EINVAL;
+    *n_rows_out = 0;
+    CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_counts_barcode_summary: no whitelist set");
+    const uint32_t W = ctx->n_canon;
+    CR_REQUIRE(ctx, c->n_canon == W, CRGPU_ESTATE, "crgpu_counts_barcode_summary: the whitelist changed since the counts were made");
+    CR_REQUIRE(ctx, c->n_molecules == 0 || c->d_corr_reads, CRGPU_ESTATE,
+               "crgpu_counts_barcode_summary: these counts carry no corrected-read table "
+               "(crgpu_enable_barcode_summary before crgpu_count_keys_dev, or use crgpu_count_records_dev)");
+    if (rank_hi > W) rank_hi = W;
+    if (rank_lo >= rank_hi) return CRGPU_OK;
+    const KeyLayout &L = c->layout;
+    const uint32_t slots = 1u << L.bits_lib;
+    const KL kl = make_kl(L);
+    DevBuf umis_b, cand_b, rows_b;
+    const size_t tab_bytes = (size_t)slots * W * sizeof(uint32_t);
+    if (c->n_molecules) {
+        CR_TRY(dmalloc(ctx, umis_b, tab_bytes));
+        CR_TRY(dmalloc(ctx, cand_b, tab_bytes));
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        CR_HIP(ctx, hipMemsetAsync(umis_b.p, 0, tab_bytes, ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(cand_b.p, 0, tab_bytes, ctx->stream));
+        hipLaunchKernelGGL(k_molecule_sums, dim3(cr_grid((c->n_molecules + MS_ITEMS - 1) / MS_ITEMS, 256)), dim3(256), 0,
+                           ctx->stream, kl, c->d_mkeys, c->d_mreads, c->n_molecules, W, umis_b.as<uint32_t>(),
+                           cand_b.as<uint32_t>());
+        CR_HIP(ctx, hipGetLastError());
+    }
+    const uint64_t span = rank_hi - rank_lo;
+    CR_TRY(dmalloc(ctx, rows_b, span * sizeof(crgpu_barcode_summary_row)));
+    uint32_t *d_total = ctx->d_scalars + 16;
+    uint64_t n_rows = 0;
+    for (uint32_t lib = 0; lib < slots && lib < CRGPU_MAX_LIB; lib++) {
+        if (!ctx->wl[lib].set) continue;
+        const uint32_t *valid = ctx->wl[lib].d_valid, *corrected = ctx->wl[lib].d_corrected;
+        const size_t off = (size_t)lib * W;
+        uint32_t n = 0;
+        {
+            CrTimer t(ctx, CRGPU_T_DEDUP);
+            CR_TRY(compact(ctx, SummaryFlag{valid, corrected, rank_lo},
+                           EmitSummary{valid, corrected, c->n_molecules ? umis_b.as<uint32_t>() + off : nullptr,
+                                       c->n_molecules ? cand_b.as<uint32_t>() + off : nullptr,
+                                       c->d_corr_reads ? c->d_corr_reads + off : nullptr, rank_lo, lib,
+                                       rows_b.as<crgpu_barcode_summary_row>()},
+                           span, ctx->d_sort_hist, d_total));
+        }
+        CR_TRY(read_u32(ctx, d_total, &n));
+        if (rows_out && n_rows + n <= cap && n)
+            CR_TRY(crgpu_memcpy_d2h(ctx, rows_out + n_rows, rows_b.p, (size_t)n * sizeof(crgpu_barcode_summary_row)));
+        n_rows += n;
+    }
+    *n_rows_out = n_rows;
+    CR_REQUIRE(ctx, !rows_out || n_rows <= cap, CRGPU_ERANGE, "crgpu_counts_barcode_summary: %llu rows, room for %llu",
+               (unsigned long long)n_rows, (unsigned long long)cap);
+    return CRGPU_OK;
+}
+
 extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
     if (!c) return;
     cr_pool_free(ctx, c->d_bc);
@@ -1290,5 +1453,6 @@ extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
     cr_pool_free(ctx, c->d_count);
     cr_pool_free(ctx, c->d_mkeys);
     cr_pool_free(ctx, c->d_mreads);
+    cr_pool_free(ctx, c->d_corr_reads);
     delete c;
 }

@@ -319,3 +319,53 @@ extern "C" int crgpu_count(crgpu_ctx *ctx, const crgpu_records *recs, uint32_t n
     CrTimer t(ctx, CRGPU_T_MATRIX);
     return crgpu_assemble_matrix(ctx, bc.data(), ft.data(), ct.data(), nt, n_features, out);
 }
+
+// ------------------------------------------------------------------------------------------------
+// barcode_summary.csv (ALIGN_AND_COUNT join, cr_lib/src/stages/align_and_count.rs:806-817)
+// ------------------------------------------------------------------------------------------------
+extern "C" int crgpu_write_barcode_summary_csv(crgpu_ctx *ctx, const crgpu_barcode_summary_row *rows, uint64_t n_rows,
+                                               uint16_t gem_group, const uint32_t *library_type_order,
+                                               const char *const *library_type_name, uint32_t n_libs, const char *path) {
+    if (!ctx || !path || (n_rows && !rows)) return CRGPU_EINVAL;
+    CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_write_barcode_summary_csv: no whitelist set");
+    CR_REQUIRE(ctx, library_type_order && library_type_name && n_libs >= 1 && n_libs <= CRGPU_MAX_LIB, CRGPU_EINVAL,
+               "crgpu_write_barcode_summary_csv: library types missing");
+    // one BarcodeSummary per (library type, barcode): libraries of one type are visited by the same
+    // AlignAndCountVisitor (align_metrics.rs:704-719).  Same gem group everywhere, so the String order of
+    // "SEQ-gg" is the order of the sequences = the rank order.
+    struct Row {
+        uint32_t order, rank, lib;
+        uint64_t v[4];
+    };
+    std::vector<Row> merged;
+    merged.reserve(n_rows);
+    for (uint64_t i = 0; i < n_rows; i++) {
+        const crgpu_barcode_summary_row &r = rows[i];
+        CR_REQUIRE(ctx, r.library < n_libs && r.barcode_rank < ctx->n_canon, CRGPU_EINVAL,
+                   "crgpu_write_barcode_summary_csv: row %llu out of range", (unsigned long long)i);
+        merged.push_back(Row{library_type_order[r.library], r.barcode_rank, r.library,
+                             {r.reads, r.umis, r.candidate_dup_reads, r.umi_corrected_reads}});
+    }
+    std::stable_sort(merged.begin(), merged.end(),
+                     [](const Row &a, const Row &b) { return a.order != b.order ? a.order < b.order : a.rank < b.rank; });
+    FILE *f = fopen(path, "wb");
+    if (!f) return cr_fail(ctx, CRGPU_EINVAL, "cannot open %s", path);
+    fprintf(f, "library_type,barcode,reads,umis,candidate_dup_reads,umi_corrected_reads\n");
+    static const char acgt[4] = {'A', 'C', 'G', 'T'};
+    char buf[32];
+    for (size_t i = 0; i < merged.size();) {
+        Row acc = merged[i];
+        size_t j = i + 1;
+        for (; j < merged.size() && merged[j].order == acc.order && merged[j].rank == acc.rank; j++)
+            for (int k = 0; k < 4; k++) acc.v[k] += merged[j].v[k];
+        const uint32_t seq = ctx->canon_sorted[acc.rank];
+        for (uint32_t p = 0; p < ctx->cb_len; p++) buf[p] = acgt[(seq >> (2 * (ctx->cb_len - 1 - p))) & 3u];
+        buf[ctx->cb_len] = 0;
+        fprintf(f, "%s,%s-%u,%llu,%llu,%llu,%llu\n", library_type_name[acc.lib], buf, (unsigned)gem_group,
+                (unsigned long long)acc.v[0], (unsigned long long)acc.v[1], (unsigned long long)acc.v[2],
+                (unsigned long long)acc.v[3]);
+        i = j;
+    }
+    fclose(f);
+    return CRGPU_OK;
+}

@@ -225,6 +225,17 @@ class Counts:
                 ptr(out["library_idx"]), ptr(out["umi"]), ptr(out["count"]), ptr(out["umi_type"])))
         return out
 
+    def barcode_summary(self, rank_lo=0, rank_hi=0xFFFFFFFF):
+        """BarcodeSummary rows (cr_lib/src/aligner.rs:33-68) of the barcode ranks in [rank_lo, rank_hi), ordered by
+        (library, rank): a numpy record array of _lib.BARCODE_SUMMARY_DTYPE"""
+        n = C.c_uint64()
+        L, h = self.ctx.L, self.ctx.h
+        self.ctx._check(L.crgpu_counts_barcode_summary(h, self.h, rank_lo, rank_hi, None, 0, C.byref(n)))
+        rows = np.zeros(n.value, _lib.BARCODE_SUMMARY_DTYPE)
+        if n.value:
+            self.ctx._check(L.crgpu_counts_barcode_summary(h, self.h, rank_lo, rank_hi, ptr(rows), n.value, C.byref(n)))
+        return rows
+
     def free(self):
         if self.h is not None and self.ctx.h:
             self.ctx.L.crgpu_counts_free(self.ctx.h, self.h)
@@ -414,6 +425,20 @@ class Context:
         self._check(self.L.crgpu_count_records_dev(self.h, C.byref(recs), C.byref(h), _p(d_processed_umi), _p(d_read_count),
                                                    _p(d_dupflags)))
         return Counts(self, h)
+
+    def enable_barcode_summary(self, on=True):
+        """count_keys keeps what Counts.barcode_summary needs (count_records always does)"""
+        self._check(self.L.crgpu_enable_barcode_summary(self.h, int(bool(on))))
+
+    def write_barcode_summary_csv(self, rows, path, gem_group=1, library_types=(("Gene Expression", 0),)):
+        """barcode_summary.csv of ALIGN_AND_COUNT (align_and_count.rs:806-817).  library_types[lib] = (display
+        string of the LibraryType, its rank in the enum's order); libraries of equal rank are one type."""
+        rows = np.ascontiguousarray(rows, dtype=_lib.BARCODE_SUMMARY_DTYPE)
+        n = len(library_types)
+        order = np.array([t[1] for t in library_types], np.uint32)
+        names = (C.c_char_p * n)(*[t[0].encode() for t in library_types])
+        self._check(self.L.crgpu_write_barcode_summary_csv(self.h, ptr(rows), len(rows), gem_group, ptr(order), names, n,
+                                                           path.encode()))
 
     def shard_metrics(self, d_cb, d_cb_qualn, cb_len, d_umi, d_umi_qualn, umi_len, d_idx, n):
         """MAKE_SHARD's barcode / UMI read metrics as a dict of counts (make_shard_metrics.rs:263-332)"""

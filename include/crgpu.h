@@ -264,6 +264,35 @@ int crgpu_counts_molecule_info(crgpu_ctx *ctx, const crgpu_counts *c, uint16_t g
 int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint8_t *lib_out,
                            uint32_t *feature_out, uint32_t *umi_out, uint32_t *read_count_out,
                            uint8_t *utype_out);
+
+/* ---- per-barcode summary (barcode_summary.csv) --------------------------------------------------------
+ * BarcodeSummary (cr_lib/src/aligner.rs:33-68), one row per (library, valid barcode) that has a read, filled as
+ * AlignAndCountVisitor::visit_read_annotation does (cr_lib/src/align_metrics.rs:704-719):
+ *   reads                = reads of the barcode (the context's VALID + CORRECTED histograms of that library, i.e. they
+ *                          must cover exactly the reads that were counted),
+ *   umis                 = reads with DupInfo::is_umi_count()  (= molecules),
+ *   candidate_dup_reads  = reads with a DupInfo that is not low-support (= reads of the molecules),
+ *   umi_corrected_reads  = reads with DupInfo::is_corrected.
+ * The last column needs a table that crgpu_count_records_dev always keeps and crgpu_count_keys_dev keeps only after
+ * crgpu_enable_barcode_summary(ctx, 1) (one more pass over the distinct keys).
+ * crgpu_counts_barcode_summary: rows for barcode ranks in [rank_lo, rank_hi) (a rank's owner range in a multi-GPU run;
+ * 0, UINT32_MAX = all), ordered by (library, rank).  rows_out may be NULL to get *n_rows only; CRGPU_ERANGE (with
+ * *n_rows set) when cap is too small.
+ * crgpu_write_barcode_summary_csv: the CSV ALIGN_AND_COUNT's join writes (align_and_count.rs:806-817): header
+ * library_type,barcode,reads,umis,candidate_dup_reads,umi_corrected_reads; barcode = "SEQ-gem_group"; libraries with the
+ * same library_type_order are ONE library type (their rows are summed) and rows are sorted by (library_type_order,
+ * barcode), the derived Ord of the struct. */
+typedef struct crgpu_barcode_summary_row {
+    uint32_t barcode_rank;
+    uint32_t library;
+    uint64_t reads, umis, candidate_dup_reads, umi_corrected_reads;
+} crgpu_barcode_summary_row;
+int crgpu_enable_barcode_summary(crgpu_ctx *ctx, int on);
+int crgpu_counts_barcode_summary(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t rank_lo, uint32_t rank_hi,
+                                 crgpu_barcode_summary_row *rows_out, uint64_t cap, uint64_t *n_rows);
+int crgpu_write_barcode_summary_csv(crgpu_ctx *ctx, const crgpu_barcode_summary_row *rows, uint64_t n_rows,
+                                    uint16_t gem_group, const uint32_t *library_type_order,
+                                    const char *const *library_type_name, uint32_t n_libs, const char *path);
 void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c);
 
 /* ---- matrix (K6) ----------------------------------------------------------------------------------

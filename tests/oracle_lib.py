@@ -336,6 +336,31 @@ def run_pipeline(reads, whitelists, n_lib=1, multiplexing_lib_mask=0, n_threads=
     return out
 
 
+def barcode_summary(res, lib_of_read):
+    """BarcodeSummary (cr_lib/src/aligner.rs:33-68) restated in numpy from the oracle's per-read results: one row per
+    (library, valid barcode); visit_read_annotation (cr_lib/src/align_metrics.rs:704-719) observes every read whose
+    barcode is valid, and observe() adds up the DupInfo flags.  Rows sorted by (library, barcode sequence)."""
+    valid = res.bc_state != 0
+    cb = res.corrected_cb[valid]
+    n, L = cb.shape
+    code = np.zeros(n, np.uint64)
+    lut = np.zeros(256, np.uint64)
+    for k, ch in enumerate(b"ACGT"):
+        lut[ch] = k
+    for p in range(L):
+        code = (code << np.uint64(2)) | lut[cb[:, p]]
+    key = (np.asarray(lib_of_read, np.uint64)[valid] << np.uint64(2 * L)) | code
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    d = res.dupinfo[valid]
+    has = d["has_dupinfo"] != 0
+    m = len(uniq)
+    return dict(library=(uniq >> np.uint64(2 * L)).astype(np.uint32), barcode=cb[first],
+                reads=np.bincount(inv, minlength=m).astype(np.uint64),
+                umis=np.bincount(inv, weights=has & (d["is_umi_count"] != 0), minlength=m).astype(np.uint64),
+                candidate_dup_reads=np.bincount(inv, weights=has & (d["is_low_support"] == 0), minlength=m).astype(np.uint64),
+                umi_corrected_reads=np.bincount(inv, weights=has & (d["is_corrected"] != 0), minlength=m).astype(np.uint64))
+
+
 def correct_feature_barcode(feat_seqs, feat_dist, seq, qual):
     fs = as_bytes_matrix(feat_seqs)
     d = np.ascontiguousarray(feat_dist, dtype=np.float64)

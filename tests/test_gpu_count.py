@@ -18,6 +18,9 @@ def _run_gpu(c, r, n, w_cb_len, umi_len, n_features, n_libs=1, mux_mask=0):
     d_keys = c.empty(max(n, 1), np.uint64)
     nk = c.build_keys(recs, d_keys)
     counts = c.count_keys(d_keys, nk)
+    if counts.n_molecules:   # the corrected-read table is kept only on request
+        with pytest.raises(Exception, match="corrected-read table"):
+            counts.barcode_summary()
     bc, ft, ct = counts.triplets()
     mol = counts.molecules()
     mol["info"] = counts.molecule_info(gem_group=1)
@@ -32,6 +35,19 @@ def _run_gpu(c, r, n, w_cb_len, umi_len, n_features, n_libs=1, mux_mask=0):
     for a, b in zip(counts3.triplets(), (bc, ft, ct)):
         assert np.array_equal(a, b)
     dup = dict(processed_umi=d_pu.to_host(count=n), read_count=d_rc.to_host(count=n), flags=d_fl.to_host(count=n))
+    # BarcodeSummary rows: from the DupInfo path, and from the plain path once asked for
+    dup["summary"] = counts3.barcode_summary()
+    c.enable_barcode_summary(True)
+    nk = c.build_keys(recs, d_keys)
+    counts4 = c.count_keys(d_keys, nk)
+    c.enable_barcode_summary(False)
+    assert np.array_equal(counts4.barcode_summary(), dup["summary"])
+    W = len(c.canon_order()[1])
+    parts = [counts4.barcode_summary(lo, hi) for lo, hi in ((0, W // 3), (W // 3, W // 3), (W // 3, W))]
+    assert sum(len(p) for p in parts) == len(dup["summary"])
+    whole = np.concatenate(parts)
+    order = np.lexsort((whole["barcode_rank"], whole["library"]))
+    assert np.array_equal(whole[order], dup["summary"])
     return idx_b, (bc, ft, ct), mol, m, dup
 
 
@@ -57,6 +73,13 @@ def _compare_with_oracle(c, w, r, n, n_features, n_libs=1, mux_mask=0, whitelist
     assert np.array_equal(dup["read_count"][has], od["read_count"][has])
     assert not dup["read_count"][~has].any() and not dup["processed_umi"][~has].any()
     assert int(((dup["flags"] & 8) != 0).sum()) == len(mol["bc"])      # one representative read per molecule
+    # BarcodeSummary (aligner.rs:33-68) per (library, barcode)
+    osum, gsum = O.barcode_summary(res, (r["flags"] & 0x0F)), dup["summary"]
+    assert len(gsum) == len(osum["reads"])
+    assert np.array_equal(gsum["library"], osum["library"])
+    assert np.array_equal(E.unpack_seqs(canon_sorted[gsum["barcode_rank"]], w.cb_len), osum["barcode"]) if len(gsum) else True
+    for f in ("reads", "umis", "candidate_dup_reads", "umi_corrected_reads"):
+        assert np.array_equal(gsum[f], osum[f]), f
     # columns, indptr, indices, data: the arrays write_matrix_h5 stores
     assert np.array_equal(m.barcodes_ascii(), res.barcodes)
     assert np.array_equal(m.indptr, res.indptr)
@@ -229,3 +252,39 @@ def test_mtx_text_matches_oracle(tmp_path):
     assert p_gpu.read_text() == "\n".join(lines) + "\n"
     assert p_bc.read_text().splitlines() == [bytes(b).decode() + "-1" for b in res.barcodes]
     c.close()
+
+
+def test_barcode_summary_csv(tmp_path):
+    """barcode_summary.csv (align_and_count.rs:806-817): two libraries of ONE library type are summed per barcode,
+    another type follows; rows ordered by (library type, barcode)."""
+    import gpu_helpers as G
+
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+
+    c = G.fresh_ctx()
+    n = 60_000
+    w = S.Workload(n_total=n, seed=77, n_wl=3000, n_cells=40, n_ambient=100, n_genes=50, n_libs=3)
+    for lib in range(3):
+        c.set_whitelist(lib, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    _, _, _, dev = G.gpu_barcode_stage(c, r, n)
+    c.set_key_layout(w.n_genes, w.umi_len, 3, 0)
+    recs = c.records(n, w.umi_len, dev["idx"], c.upload(r["umi"]), c.upload(r["umi_qualn"]), c.upload(r["feature"]), dev["flags"])
+    rows = c.count_records(recs).barcode_summary()
+    assert set(rows["library"]) == {0, 1, 2}
+    path = str(tmp_path / "barcode_summary.csv")
+    types = (("Gene Expression", 0), ("Antibody Capture", 2), ("Gene Expression", 0))
+    c.write_barcode_summary_csv(rows, path, gem_group=3, library_types=types)
+    lines = open(path).read().split("\n")
+    assert lines[0] == "library_type,barcode,reads,umis,candidate_dup_reads,umi_corrected_reads" and lines[-1] == ""
+    _, canon_sorted = c.canon_order()
+    exp = {}
+    for row in rows:
+        t = types[row["library"]]
+        seq = bytes(E.unpack_seqs(canon_sorted[row["barcode_rank"]:row["barcode_rank"] + 1], 16)[0]).decode() + "-3"
+        acc = exp.setdefault((t[1], seq, t[0]), np.zeros(4, np.uint64))
+        acc += np.array([row["reads"], row["umis"], row["candidate_dup_reads"], row["umi_corrected_reads"]], np.uint64)
+    want = ["%s,%s,%d,%d,%d,%d" % (k[2], k[1], *v) for k, v in sorted(exp.items(), key=lambda kv: kv[0][:2])]
+    assert lines[1:-1] == want
+    assert int(rows["reads"].sum()) == int((dev["idx"].to_host() != E.MISS).sum())

@@ -185,3 +185,28 @@ def test_shard_metrics_hand_computed():
     assert m["low_min_qual_barcode"] == 2         # min q-33: 40, 2, 9
     assert m["low_min_qual_umi"] == 0             # min q-33: 40, 40, 10 (10 is not below 10)
     assert m["miss_whitelist_barcode"] == 1
+
+
+def test_barcode_summary_hand_computed():
+    """BarcodeSummary::observe (cr_lib/src/aligner.rs:54-67) on six reads worked out by hand: no fixture of
+    barcode_summary.csv ships with the reference, so this pins the restatement the GPU rows are compared with."""
+    import oracle_lib as O
+
+    class R:
+        pass
+
+    res = R()
+    res.corrected_cb = np.frombuffer(b"AAAC" b"AAAC" b"AAAC" b"CCCC" b"GGGG" b"AAAC", np.uint8).reshape(6, 4).copy()
+    res.bc_state = np.array([1, 2, 1, 1, 0, 1], np.uint8)           # read 4: barcode not valid -> not observed
+    d = np.zeros(6, O.DUPINFO_DTYPE)
+    #                      has corrected low umi_count
+    for i, f in enumerate([(1, 0, 0, 1), (1, 1, 0, 0), (0, 0, 0, 0), (1, 0, 1, 0), (1, 0, 0, 1), (1, 0, 0, 1)]):
+        d["has_dupinfo"][i], d["is_corrected"][i], d["is_low_support"][i], d["is_umi_count"][i] = f
+    res.dupinfo = d
+    s = O.barcode_summary(res, np.array([0, 0, 0, 0, 0, 1], np.uint8))
+    assert s["library"].tolist() == [0, 0, 1]
+    assert [bytes(b) for b in s["barcode"]] == [b"AAAC", b"CCCC", b"AAAC"]
+    assert s["reads"].tolist() == [3, 1, 1]                  # read 2 has no DupInfo but is a read of AAAC
+    assert s["umis"].tolist() == [1, 0, 1]
+    assert s["candidate_dup_reads"].tolist() == [2, 0, 1]    # low-support read of CCCC is not a candidate
+    assert s["umi_corrected_reads"].tolist() == [1, 0, 0]
