@@ -846,37 +846,38 @@ constexpr int MS_ITEMS = 8;
 __global__ __launch_bounds__(256) void k_molecule_sums(const KL kl, const uint64_t *__restrict__ mkeys,
                                                        const uint32_t *__restrict__ mreads, uint64_t nm, uint32_t W,
                                                        uint32_t *__restrict__ umis, uint32_t *__restrict__ cand) {
-    const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * MS_ITEMS;
-    if (base >= nm) return;
-    uint64_t key[MS_ITEMS];
-    uint32_t rd[MS_ITEMS];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * MS_ITEMS;
+    for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * MS_ITEMS; base < nm; base += stride) {
+        uint64_t key[MS_ITEMS];
+        uint32_t rd[MS_ITEMS];
 #pragma unroll
-    for (int j = 0; j < MS_ITEMS; j++) {
-        const uint64_t i = base + j < nm ? base + j : nm - 1;
-        key[j] = mkeys[i];
-        rd[j] = mreads[i];
-    }
-    size_t cur = ~(size_t)0;
-    uint32_t n_u = 0, n_c = 0;
-#pragma unroll
-    for (int j = 0; j < MS_ITEMS; j++) {
-        if (base + j >= nm) break;
-        const uint32_t lib = (uint32_t)((key[j] >> kl.sh_lib) & lowmask(kl.bits_lib));
-        const size_t slot = (size_t)lib * W + (uint32_t)(key[j] >> kl.sh_bc);
-        if (slot != cur) {
-            if (n_u) {
-                atomicAdd(&umis[cur], n_u);
-                atomicAdd(&cand[cur], n_c);
-            }
-            cur = slot;
-            n_u = n_c = 0;
+        for (int j = 0; j < MS_ITEMS; j++) {
+            const uint64_t i = base + j < nm ? base + j : nm - 1;
+            key[j] = mkeys[i];
+            rd[j] = mreads[i];
         }
-        n_u += 1;
-        n_c += rd[j];
-    }
-    if (n_u) {
-        atomicAdd(&umis[cur], n_u);
-        atomicAdd(&cand[cur], n_c);
+        size_t cur = ~(size_t)0;
+        uint32_t n_u = 0, n_c = 0;
+#pragma unroll
+        for (int j = 0; j < MS_ITEMS; j++) {
+            if (base + j >= nm) break;
+            const uint32_t lib = (uint32_t)((key[j] >> kl.sh_lib) & lowmask(kl.bits_lib));
+            const size_t slot = (size_t)lib * W + (uint32_t)(key[j] >> kl.sh_bc);
+            if (slot != cur) {
+                if (n_u) {
+                    atomicAdd(&umis[cur], n_u);
+                    atomicAdd(&cand[cur], n_c);
+                }
+                cur = slot;
+                n_u = n_c = 0;
+            }
+            n_u += 1;
+            n_c += rd[j];
+        }
+        if (n_u) {
+            atomicAdd(&umis[cur], n_u);
+            atomicAdd(&cand[cur], n_c);
+        }
     }
 }
 

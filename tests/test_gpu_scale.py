@@ -113,6 +113,26 @@ def test_conservation_sortedness_and_determinism(big):
     for a, b in ((m1.indptr, m.indptr), (m1.indices, m.indices), (m1.data, m.data), (indptr, m.indptr), (indices, m.indices),
                  (data, m.data), (rank, m.barcode_rank)):
         assert np.array_equal(a, b)
+    # per-read DupInfo and the per-barcode summary obey the conservation laws of mark_dups.rs / aligner.rs:54-67
+    pu, rc, fl = c.empty(d["n"], np.uint32), c.empty(d["n"], np.uint32), c.empty(d["n"], np.uint8)
+    counts3 = c.count_records(r2["recs"], pu, rc, fl)
+    flags, reads_of = fl.to_host(), rc.to_host()
+    has = (flags & 1) != 0
+    assert int(has.sum()) == r["nk"]                                     # every key-forming read gets a DupInfo
+    assert int(((flags & 8) != 0).sum()) == len(mol["bc"])               # one is_umi_count read per molecule
+    assert not (flags[~has]).any() and not reads_of[~has].any()
+    kept = has & ((flags & 4) == 0)
+    assert int(kept.sum()) == int(mol["read_count"].sum())               # reads of kept molecules
+    assert int(reads_of[(flags & 8) != 0].sum()) == int(mol["read_count"].sum())
+    rows = counts3.barcode_summary()
+    assert (rows["library"] == 0).all() and np.array_equal(rows["barcode_rank"], m.barcode_rank)
+    assert np.array_equal(rows["reads"], (r["valid"].astype(np.uint64) + r["corrected"])[m.barcode_rank])
+    assert int(rows["umis"].sum()) == len(mol["bc"]) and int(rows["candidate_dup_reads"].sum()) == int(kept.sum())
+    assert int(rows["umi_corrected_reads"].sum()) == int(((flags & 2) != 0).sum())
+    assert np.array_equal(rows["umis"], np.bincount(mol["bc"], minlength=c.n_canon)[m.barcode_rank].astype(np.uint64))
+    idx_valid = r["idx_b"] != MISS
+    assert np.array_equal(rows["umi_corrected_reads"],
+                          np.bincount(r["idx_b"][idx_valid & ((flags & 2) != 0)], minlength=c.n_canon)[m.barcode_rank].astype(np.uint64))
 
 
 def _rebuild_keys(c, recs, n):
