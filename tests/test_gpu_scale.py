@@ -161,3 +161,58 @@ def test_batch_split_invariance(big):
         c.correct(d["cb"].ptr + 4 * off, d["cb_qualn"].ptr + 16 * off, d["flags"].ptr + off, h, d["idx"].ptr + 4 * off)
     assert np.array_equal(d["idx"].to_host(count=n), one)
     assert np.array_equal(c.get_counts(0, COUNTS_VALID), v1) and np.array_equal(c.get_counts(0, COUNTS_CORRECTED), c1)
+
+
+def test_pack_metrics_and_feature_scans_at_scale(big):
+    """The streaming kernels either side of the path (crgpu_pack_dev, crgpu_shard_metrics_dev, crgpu_match_features_dev)
+    on grids far past one wave of workgroups: pack/unpack round trip, metrics against the oracle's per-read loop, and
+    tiling invariance of the feature matcher (whole array == two halves == an oracle-checked sample)."""
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import MISS, NO_FEATURE
+
+    c, w, d = big
+    n = 20_000_000
+    cb, cbq = d["cb"].to_host(count=n), d["cb_qualn"].to_host(count=n * 16).reshape(n, 16)
+    umi, uq = d["umi"].to_host(count=n), d["umi_qualn"].to_host(count=n * 12).reshape(n, 12)
+    cb_a, cbq_a = S.to_ascii(cb, cbq, 16)
+    umi_a, uq_a = S.to_ascii(umi, uq, 12)
+    # pack: ASCII + plain qualities -> the packed arrays the generator made (N bases pack as A with bit 7 set)
+    d_pk, d_qn, d_fl = c.empty(n, np.uint32), c.empty((n, 16), np.uint8), c.zeros(n, np.uint8)
+    c.pack(c.upload(cb_a), c.upload(cbq_a), n, 16, d_pk, d_qn, d_fl)
+    is_n = (cbq & 0x80) != 0
+    assert np.array_equal(d_qn.to_host().reshape(n, 16), cbq)
+    got_pk = d_pk.to_host()
+    clean = ~is_n.any(axis=1)
+    assert np.array_equal(got_pk[clean], cb[clean]) and clean.mean() > 0.98
+    assert np.array_equal((d_fl.to_host() & 0x10) != 0, ~clean)
+    # metrics
+    c.reset_counts()
+    d_idx = c.empty(n, np.uint32)
+    c.match_and_count(d["cb"], d["flags"], n, d_idx)
+    idx_a = d_idx.to_host()
+    got = c.shard_metrics(d["cb"], d["cb_qualn"], 16, d["umi"], d["umi_qualn"], 12, d_idx, n)
+    exp = O.shard_metrics(cb_a, cbq_a, umi_a, uq_a, exact_hit=(idx_a != MISS).astype(np.uint8))
+    assert got == exp and got["sequenced_reads"] == n
+    # feature matcher over 20 M captures (the UMI column stands in for 12-base captures)
+    rng = np.random.default_rng(9)
+    feats = np.unique(umi[:4000])[:300]
+    feat_ascii = E.unpack_seqs(feats, 12)
+    dist = O.compute_feature_dist(rng.integers(1, 1000, len(feats)), np.zeros(len(feats), np.uint32))
+    index = np.arange(len(feats), dtype=np.uint32)
+    c.set_feature_pattern(0, feat_ascii, index, dist)
+    out = c.empty(n, np.uint32)
+    c.match_features(0, d["umi"], d["umi_qualn"], n, out)
+    whole = out.to_host()
+    h = n // 2 + 12_345
+    out2 = c.empty(n, np.uint32)
+    c.match_features(0, d["umi"], d["umi_qualn"], h, out2)
+    first = out2.to_host(count=h)
+    assert np.array_equal(first, whole[:h])
+    hits = np.nonzero(whole != NO_FEATURE)[0]
+    assert len(hits) > 100
+    sample = np.concatenate([hits[:2000], hits[-2000:], rng.integers(0, n, 4000)])
+    for i in sample:
+        f = O.find_closest_feature(feat_ascii, dist, bytes(umi_a[i]), bytes(uq_a[i]))
+        assert whole[i] == (NO_FEATURE if f < 0 else index[f]), i
