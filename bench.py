@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--reads-per-gpu", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=24_000_000,
                     help="reads of the CPU-baseline sample (about 10-30 s of oracle work on the box's cores)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed full-size property checks (cfg3, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -226,6 +227,14 @@ def main():
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in ledger.items() if v[1]},
             "output": out_info,
         }
+        if world == 1 and workload == "cfg3" and not args.no_verify:
+            # not timed: the laws of cellranger_amd/selfcheck.py on this very workload at its full size
+            from cellranger_amd import selfcheck
+            try:
+                line["verify"] = dict(selfcheck.full_size_properties(ctx, shard, local_rank), ok=True)
+            except AssertionError as e:  # report, never hide: the line still carries the timing
+                import traceback
+                line["verify"] = {"ok": False, "failed": traceback.format_exc(limit=2).strip().splitlines()[-3:], "msg": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, workload, min(args.cpu_sample, n))
         print(json.dumps(line))

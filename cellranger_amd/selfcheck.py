@@ -1,0 +1,121 @@
+"""Size-independent properties of one pass of the hot path, checked on the device at any size (bench.py --verify runs
+them on the full 1 B-record workload, tests/test_gpu_scale.py at 1 B and 50 M).
+
+Not a CPU implementation of anything: the path runs through libcrgpu as always, and torch only reduces / compares the
+arrays it left in HBM (conservation laws, sortedness, the BarcodeIndex rule, CSC invariants).  Every check cites the
+reference rule it follows from.
+"""
+import numpy as np
+
+from ._lib import COUNTS_CORRECTED, COUNTS_VALID
+from .pipeline import _DevView
+
+
+def _i32(ptr, n, dev):
+    import torch
+
+    if n == 0:
+        return torch.empty(0, dtype=torch.int32, device=dev)
+    return torch.as_tensor(_DevView(ptr, (n,), "<i4"), device=dev)
+
+
+def full_size_properties(ctx, shard, device_index=0):
+    """Runs K1 -> K2 -> keys -> dedup -> matrix on `shard` (device arrays cb, cb_qualn, flags, idx, umi, umi_qualn,
+    feature; n; umi_len; library 0) and returns {check name: value}; raises AssertionError on the first violated law."""
+    import torch
+
+    dev = "cuda:%d" % device_index
+    n = shard["n"]
+    W = ctx.n_canon
+    out = {}
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize(device_index)
+
+    ctx.reset_counts()
+    ctx.match_and_count(shard["cb"], shard["flags"], n, shard["idx"])
+    sync()
+    idx = _i32(shard["idx"].ptr, n, dev)
+    idx_a = idx.clone()
+    hit_a = idx_a >= 0                                            # CRGPU_MISS is -1 as i32
+    valid = _i32(ctx.counts_dev(0, COUNTS_VALID), W, dev).clone()
+    # MakeShardHistograms::observe (make_shard_metrics.rs:171-188): one count per read whose barcode is on the whitelist
+    assert int(valid.sum()) == int(hit_a.sum())
+    assert torch.equal(torch.bincount(idx_a[hit_a].long(), minlength=W).int(), valid)
+    out["valid_reads"] = int(hit_a.sum())
+    sync()
+    ctx.correct(shard["cb"], shard["cb_qualn"], shard["flags"], n, shard["idx"])
+    sync()
+    corrected = _i32(ctx.counts_dev(0, COUNTS_CORRECTED), W, dev).clone()
+    hit_b = idx >= 0
+    fixed = hit_b & ~hit_a
+    # barcode_correction.rs:328-345: only invalid barcodes are looked at; each corrected read counts once
+    assert torch.equal(idx[hit_a], idx_a[hit_a])
+    assert int(corrected.sum()) == int(fixed.sum())
+    assert torch.equal(torch.bincount(idx[fixed].long(), minlength=W).int(), corrected)
+    out["corrected_reads"] = int(fixed.sum())
+    # corrector.rs:111-171: a corrected barcode is a whitelist entry at Hamming distance exactly 1 (<= 1 with an N)
+    _, canon_sorted = ctx.canon_order()
+    canon = torch.as_tensor(canon_sorted.astype(np.int64), device=dev)
+    cb = _i32(shard["cb"].ptr, n, dev)
+    sel = torch.nonzero(fixed).squeeze(1)[:50_000_000]
+    x = (canon[idx[sel].long()] ^ (cb[sel].long() & 0xFFFFFFFF))
+    y = (x | (x >> 1)) & 0x55555555
+    n_diff = torch.zeros_like(y)
+    for k in range(16):
+        n_diff += (y >> (2 * k)) & 1
+    fl = torch.as_tensor(_DevView(shard["flags"].ptr, (n,), "|u1"), device=dev)
+    has_n = (fl[sel] & 0x10) != 0
+    assert bool(((n_diff == 1) | has_n).all()) and bool((n_diff <= 1).all())
+    del x, y, n_diff, sel, has_n, cb, idx_a, hit_a, fixed
+    sync()
+
+    recs = ctx.records(n, shard["umi_len"], shard["idx"], shard["umi"], shard["umi_qualn"], shard["feature"], shard["flags"])
+    keys = shard["keys"] if shard.get("keys") is not None else ctx.empty(n, np.uint64)
+    ctx.enable_barcode_summary(True)
+    try:
+        nk = ctx.build_keys(recs, keys)
+        counts = ctx.count_keys(keys, nk)
+    finally:
+        ctx.enable_barcode_summary(False)
+    sync()
+    out["keys"], out["molecules"], out["triplets"] = int(nk), counts.n_molecules, counts.n_triplets
+    assert 0 < nk <= int(hit_b.sum())
+    d_bc, d_ft, d_ct = counts.triplets_dev()
+    nt = counts.n_triplets
+    bc, ft, ct = _i32(d_bc, nt, dev), _i32(d_ft, nt, dev), _i32(d_ct, nt, dev)
+    # BcUmiInfo::feature_counts (types.rs:180-188): one entry per (barcode, feature), BarcodeThenFeatureOrder, counts > 0
+    tkey = (bc.long() << 32) | ft.long()
+    assert bool((tkey[1:] > tkey[:-1]).all()) and bool((ct > 0).all())
+    assert int(ct.long().sum()) == counts.n_molecules
+    # every triplet's barcode has reads in the histograms (BarcodeIndex, barcode_index.rs:20-53)
+    seen = (valid != 0) | (corrected != 0)
+    assert bool(seen[bc.long()].all())
+    sync()
+    md = ctx.assemble_matrix_dev(d_bc, d_ft, d_ct, nt)
+    rank, indptr, indices, data = md.download()
+    # CSC arrays (count_matrix.rs:382-448)
+    assert indptr[0] == 0 and indptr[-1] == nt == len(data) and (np.diff(indptr) >= 0).all()
+    assert np.array_equal(rank, torch.nonzero(seen).squeeze(1).cpu().numpy().astype(np.uint32))
+    assert int(data.astype(np.int64).sum()) == counts.n_molecules
+    assert np.array_equal(indices, ft.cpu().numpy()) and np.array_equal(data, ct.cpu().numpy())
+    per_col = np.diff(indptr)
+    assert np.array_equal(np.repeat(rank, per_col), bc.cpu().numpy().astype(np.uint32))
+    out["matrix_columns"], out["matrix_nnz"] = len(rank), int(nt)
+    # BarcodeSummary (aligner.rs:33-68): one row per barcode with reads; umis = molecules; candidates = their reads
+    rows = counts.barcode_summary()
+    assert np.array_equal(rows["barcode_rank"], rank) and (rows["library"] == 0).all()
+    assert np.array_equal(rows["reads"], (valid.long() + corrected.long())[torch.as_tensor(rank.astype(np.int64), device=dev)].cpu().numpy().astype(np.uint64))
+    assert int(rows["umis"].sum()) == counts.n_molecules
+    cs = np.concatenate([np.zeros(1, np.int64), np.cumsum(data, dtype=np.int64)])
+    assert np.array_equal(rows["umis"].astype(np.int64), cs[indptr[1:]] - cs[indptr[:-1]])   # column sums of the matrix
+    cand = int(rows["candidate_dup_reads"].sum())
+    # mark_dups.rs: reads are conserved by the UMI correction; only low-support molecules drop out
+    assert cand <= nk and cand > 0.9 * nk
+    assert int(rows["umi_corrected_reads"].sum()) < 0.1 * nk
+    out["candidate_dup_reads"], out["umi_corrected_reads"] = cand, int(rows["umi_corrected_reads"].sum())
+    out["checksum"] = int((tkey * 1315423911 + ct.long()).sum().item() & 0x7FFFFFFFFFFFFFFF)
+    md.free()
+    counts.free()
+    return out

@@ -9,7 +9,7 @@ IFS=';' read -ra G <<< "$groups"
 p=0
 for g in "${G[@]}"; do
   rm -rf gpurun_out/pmc_${tag}_p$p
-  timeout -k 5 150 rocprofv3 --pmc $g --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_p$p -- python3 bench.py "$@" --no-cpu-baseline > gpurun_out/pmc_${tag}_p$p.json 2> gpurun_out/pmc_${tag}_p$p.err
+  timeout -k 5 150 rocprofv3 --pmc $g --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_p$p -- python3 bench.py "$@" --no-cpu-baseline --no-verify > gpurun_out/pmc_${tag}_p$p.json 2> gpurun_out/pmc_${tag}_p$p.err
   p=$((p+1))
 done
 python3 - <<PY
