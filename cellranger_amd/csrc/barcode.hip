@@ -909,7 +909,9 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
 
     // candidate slots: bit (pos*4 + base)
     unsigned long long cand = 0ull;
+    uint32_t posA = 0u, nA = 0u, tail_from = 0xFFFFFFFFu;  // tail_from: first position that lies in the tail
     if (n_n == 0) {
+        tail_from = w.bitsA >> 1;
         const uint32_t head = key >> w.bitsB;
         const uint32_t tail = key & ((1u << w.bitsB) - 1u);
         const uint32_t hA = w.bitsA >> 1;
@@ -918,11 +920,13 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
         const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offB + tail);
         const uint32_t a_lo = a2.a, a_hi = a2.b, b_lo = b2.a, b_hi = b2.b;
         // mutation in the tail: same head -> bin A
-        scan_u16_range<K2_SCAN_DWORDS>(w.tailA, a_lo, a_hi, [&](uint32_t t, uint32_t) {
+        scan_u16_range<K2_SCAN_DWORDS>(w.tailA, a_lo, a_hi, [&](uint32_t t, uint32_t at) {
             const int bo = one_base_diff(t, tail);
             if (bo >= 0) {
                 const uint32_t pos = len - 1u - (uint32_t)(bo >> 1);
                 cand |= 1ull << (pos * 4u + ((t >> bo) & 3u));
+                posA = at;  // bin A is the sorted whitelist itself: the entry's position gives its rank
+                nA++;
             }
         });
         // mutation in the head: same tail -> bin B
@@ -943,16 +947,26 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
     bool have_best = false;
     double best_like = 0.0, total = 0.0;
     uint32_t best_rank = 0;
+    const bool lone = n_n == 0 && (cand & (cand - 1ull)) == 0ull;  // exactly one candidate, already known to be listed
     while (cand) {
         const uint32_t slot = (uint32_t)__ffsll((long long)cand) - 1u;
         cand &= cand - 1ull;
         const uint32_t pos = slot >> 2, base = slot & 3u;
         const uint32_t sh = 2u * (len - 1u - pos);
         const uint32_t ckey = (key & ~(3u << sh)) | (base << sh);
-        const uint32_t r = wl_lookup(w, ckey);
+        // a lone tail mutation was seen in bin A at posA: no second lookup (offE + tail lines) for its rank
+        const uint32_t r = (nA == 1u && pos >= tail_from) ? (w.valA ? w.valA[posA] : posA) : wl_lookup(w, ckey);
         if (r == CRGPU_MISS) continue;
         uint32_t qv = (uint32_t)((pos < 8u ? qlo : qhi) >> (8u * (pos & 7u))) & 0x7Fu;
         qv = qv < 66u ? qv : 66u;                                  // corrector.rs:126
+        if (lone && ptab[qv] > 0.0) {
+            // the only candidate: likelihood / total == x / x == 1.0 for any positive finite x, whatever the
+            // prior count is -- skip its random 4-byte load (the tables are 3x the L2 of an XCD)
+            have_best = true;
+            best_like = total = 1.0;
+            best_rank = r;
+            break;
+        }
         const long long bc_count = 1ll + (long long)w.prior[r];    // Laplace smoothing, :138-139
         const double like = ptab[qv] * (double)bc_count;           // :140-141
         if (!have_best) {
