@@ -288,3 +288,37 @@ def test_barcode_summary_csv(tmp_path):
     want = ["%s,%s,%d,%d,%d,%d" % (k[2], k[1], *v) for k, v in sorted(exp.items(), key=lambda kv: kv[0][:2])]
     assert lines[1:-1] == want
     assert int(rows["reads"].sum()) == int((dev["idx"].to_host() != E.MISS).sum())
+
+
+def test_clustered_umis_and_long_runs_of_near_identical_keys():
+    """UMIs that differ only in their last bases (three 8-base prefixes), UmiTypes mixed inside every UMI, and keys that
+    agree in everything but the last 2.5 bases of the UMI in runs of 2..30, of 100 and of 50 000 reads: Hamming-1
+    neighbourhoods are dense, counts tie, and one (barcode, feature) segment holds most of the reads."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import FLAG_NONTXOMIC
+
+    n = 260_000
+    w = S.Workload(n_total=n, seed=31, n_wl=2000, n_cells=40, n_ambient=200, n_genes=40, umi_len=12, umi_err=0.0, cb_err=0.01,
+                   n_rate=0.001, no_feature_frac=0.05, reads_per_umi=1)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    rng = np.random.default_rng(31)
+    prefix = rng.integers(0, 1 << 16, 3, dtype=np.uint32)        # three 8-base prefixes
+    r["umi"] = ((prefix[rng.integers(0, 3, n)] << np.uint32(8)) | rng.integers(0, 256, n, dtype=np.uint32)).astype(np.uint32)
+    # one run of 50 000 reads: same barcode, feature and first 9.5 bases; 20 runs of 100 reads
+    assert not (r["flags"][0] & 0x10) and not (r["cb_qualn"][0] & 0x80).any()
+    r["cb"][:50_000], r["feature"][:50_000] = r["cb"][0], 7
+    r["cb_qualn"][:50_000] = r["cb_qualn"][0]
+    r["umi"][:50_000] = (r["umi"][0] & ~np.uint32(31)) | rng.integers(0, 32, 50_000, dtype=np.uint32)
+    for g in range(20):
+        s = 50_000 + 100 * g
+        r["cb"][s:s + 100], r["feature"][s:s + 100] = r["cb"][s], g
+        r["cb_qualn"][s:s + 100] = r["cb_qualn"][s]
+        r["umi"][s:s + 100] = (r["umi"][s] & ~np.uint32(31)) | rng.integers(0, 32, 100, dtype=np.uint32)
+    r["flags"][:52_000] = r["flags"][0] & 0x0F     # the planted runs copy a barcode without N
+    r["flags"] = (r["flags"] | np.where(rng.random(n) < 0.4, FLAG_NONTXOMIC, 0)).astype(np.uint8)
+    res, m = _compare_with_oracle(c, w, r, n, 40)
+    assert m.nnz > 1000
+    c.close()
