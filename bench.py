@@ -158,8 +158,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     result = None
+    step_marks = []
     for _ in range(args.steps):
+        result = None      # the previous step's matrix goes back to the device pool first: steady state allocates nothing
         result = step()
+        step_marks.append(time.perf_counter())   # host-side marks only (steps end in a blocking read of the totals)
     sync()
     dt = time.perf_counter() - t0
     ctx.timing(False)
@@ -226,6 +229,7 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in ledger.items() if v[1]},
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in ledger.items() if v[1]},
             "output": out_info,
+            "host_step_marks_ms": [round((m - t0) * 1e3, 2) for m in step_marks],
         }
         if world == 1 and workload == "cfg3" and not args.no_verify:
             # not timed: the laws of cellranger_amd/selfcheck.py on this very workload at its full size
