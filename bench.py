@@ -205,7 +205,9 @@ def main():
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": ms / launches,
                     "launches_per_step": launches / args.steps, "bytes_per_element": bpe,
-                    "elements_per_launch": units / launches}
+                    "elements_per_launch": units / launches,
+                    # a plain 8 GiB device-to-device copy on this box (profiles/r01_m_copy_rates.txt): context, not the peak
+                    "copy_rate_measured_GBps": 4835.0}
         step_gbs = STEP_BYTES[workload] * n / (ms_per_step * 1e-3) / 1e9
         line = {
             "metric": "M reads/sec barcode-correct+UMI-count" if workload == "cfg3" else "M reads/sec barcode-correct",
