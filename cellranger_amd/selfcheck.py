@@ -19,9 +19,22 @@ def _i32(ptr, n, dev):
     return torch.as_tensor(_DevView(ptr, (n,), "<i4"), device=dev)
 
 
-def full_size_properties(ctx, shard, device_index=0):
-    """Runs K1 -> K2 -> keys -> dedup -> matrix on `shard` (device arrays cb, cb_qualn, flags, idx, umi, umi_qualn,
-    feature; n; umi_len; library 0) and returns {check name: value}; raises AssertionError on the first violated law."""
+_SLICE = 1 << 30   # torch's masked indexing / nonzero are used on slices of at most 2^30 elements
+
+
+def _bincount_where(values, mask, minlength):
+    import torch
+
+    acc = torch.zeros(minlength, dtype=torch.int64, device=values.device)
+    for s in range(0, values.numel(), _SLICE):
+        v, m = values[s:s + _SLICE], mask[s:s + _SLICE]
+        acc += torch.bincount(v[m].long(), minlength=minlength)
+    return acc
+
+
+def barcode_stage_properties(ctx, shard, device_index=0, _keep=None):
+    """K1 -> K2 on `shard` (device arrays cb, cb_qualn, flags, idx; n; library 0): histograms == per-read results,
+    pass B touches only invalid reads, every correction is a Hamming-1 neighbour.  Returns {check name: value}."""
     import torch
 
     dev = "cuda:%d" % device_index
@@ -42,7 +55,7 @@ def full_size_properties(ctx, shard, device_index=0):
     valid = _i32(ctx.counts_dev(0, COUNTS_VALID), W, dev).clone()
     # MakeShardHistograms::observe (make_shard_metrics.rs:171-188): one count per read whose barcode is on the whitelist
     assert int(valid.sum()) == int(hit_a.sum())
-    assert torch.equal(torch.bincount(idx_a[hit_a].long(), minlength=W).int(), valid)
+    assert torch.equal(_bincount_where(idx_a, hit_a, W), valid.long())
     out["valid_reads"] = int(hit_a.sum())
     sync()
     ctx.correct(shard["cb"], shard["cb_qualn"], shard["flags"], n, shard["idx"])
@@ -51,15 +64,17 @@ def full_size_properties(ctx, shard, device_index=0):
     hit_b = idx >= 0
     fixed = hit_b & ~hit_a
     # barcode_correction.rs:328-345: only invalid barcodes are looked at; each corrected read counts once
-    assert torch.equal(idx[hit_a], idx_a[hit_a])
+    assert bool(((idx == idx_a) | ~hit_a).all())
     assert int(corrected.sum()) == int(fixed.sum())
-    assert torch.equal(torch.bincount(idx[fixed].long(), minlength=W).int(), corrected)
+    assert torch.equal(_bincount_where(idx, fixed, W), corrected.long())
     out["corrected_reads"] = int(fixed.sum())
     # corrector.rs:111-171: a corrected barcode is a whitelist entry at Hamming distance exactly 1 (<= 1 with an N)
     _, canon_sorted = ctx.canon_order()
     canon = torch.as_tensor(canon_sorted.astype(np.int64), device=dev)
     cb = _i32(shard["cb"].ptr, n, dev)
-    sel = torch.nonzero(fixed).squeeze(1)[:50_000_000]
+    sel = torch.nonzero(fixed[:_SLICE]).squeeze(1)[:25_000_000]
+    if n > _SLICE:   # both ends of the batch
+        sel = torch.cat([sel, torch.nonzero(fixed[n - _SLICE:]).squeeze(1)[-25_000_000:] + (n - _SLICE)])
     x = (canon[idx[sel].long()] ^ (cb[sel].long() & 0xFFFFFFFF))
     y = (x | (x >> 1)) & 0x55555555
     n_diff = torch.zeros_like(y)
@@ -68,7 +83,26 @@ def full_size_properties(ctx, shard, device_index=0):
     fl = torch.as_tensor(_DevView(shard["flags"].ptr, (n,), "|u1"), device=dev)
     has_n = (fl[sel] & 0x10) != 0
     assert bool(((n_diff == 1) | has_n).all()) and bool((n_diff <= 1).all())
-    del x, y, n_diff, sel, has_n, cb, idx_a, hit_a, fixed
+    if _keep is not None:
+        _keep.update(valid=valid, corrected=corrected, n_valid_after=int(hit_b.sum()))
+    return out
+
+
+def full_size_properties(ctx, shard, device_index=0):
+    """Runs K1 -> K2 -> keys -> dedup -> matrix on `shard` (device arrays cb, cb_qualn, flags, idx, umi, umi_qualn,
+    feature; n; umi_len; library 0) and returns {check name: value}; raises AssertionError on the first violated law."""
+    import torch
+
+    dev = "cuda:%d" % device_index
+    n = shard["n"]
+    keep = {}
+    out = barcode_stage_properties(ctx, shard, device_index, keep)
+    valid, corrected, n_valid_after = keep["valid"], keep["corrected"], keep["n_valid_after"]
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize(device_index)
+
     sync()
 
     recs = ctx.records(n, shard["umi_len"], shard["idx"], shard["umi"], shard["umi_qualn"], shard["feature"], shard["flags"])
@@ -81,7 +115,7 @@ def full_size_properties(ctx, shard, device_index=0):
         ctx.enable_barcode_summary(False)
     sync()
     out["keys"], out["molecules"], out["triplets"] = int(nk), counts.n_molecules, counts.n_triplets
-    assert 0 < nk <= int(hit_b.sum())
+    assert 0 < nk <= n_valid_after
     d_bc, d_ft, d_ct = counts.triplets_dev()
     nt = counts.n_triplets
     bc, ft, ct = _i32(d_bc, nt, dev), _i32(d_ft, nt, dev), _i32(d_ct, nt, dev)

@@ -245,3 +245,26 @@ def test_device_side_properties_up_to_the_full_1b_workload(n):
     assert 0.90 * n < a["valid_reads"] < 0.94 * n and 0.05 * n < a["corrected_reads"] < 0.09 * n   # SURVEY 8d error model
     assert a["molecules"] > 0.2 * a["keys"] and a["matrix_nnz"] == a["triplets"]
     c.close()
+
+
+def test_barcode_stage_on_more_than_2_31_reads():
+    """2.5 G reads in ONE batch (crgpu_match_and_count_dev / crgpu_correct_dev accept up to 2^32 - 2): read ordinals pass
+    2^31 and byte offsets into the quality rows pass 2^35, so any 32-bit index arithmetic in K1 / K2 shows up as a broken
+    histogram or a correction that is not a Hamming-1 neighbour."""
+    import gpu_helpers as G
+    from cellranger_amd import selfcheck
+    from cellranger_amd import synth as S
+
+    n = 2_500_000_000
+    w = S.Workload(n_total=n, seed=S.SEED0 + 2, n_genes=0)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    d = dict(n=n)
+    d["cb"], d["cb_qualn"], d["flags"], d["idx"] = c.empty(n, np.uint32), c.empty((n, 16), np.uint8), c.empty(n, np.uint8), c.empty(n, np.uint32)
+    chunk = 1 << 27
+    for off in range(0, n, chunk):
+        m = min(chunk, n - off)
+        c.synth(w, off, m, cb=d["cb"].ptr + 4 * off, cb_qualn=d["cb_qualn"].ptr + 16 * off, flags=d["flags"].ptr + off)
+    a = selfcheck.barcode_stage_properties(c, d)
+    assert 0.90 * n < a["valid_reads"] < 0.94 * n and 0.05 * n < a["corrected_reads"] < 0.09 * n
+    c.close()
