@@ -186,6 +186,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
                recs->umi_len, ctx->layout.umi_len);
     *n_keys_out = 0;
     if (recs->n == 0) return CRGPU_OK;
+    CR_REQUIRE(ctx, recs->n <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_build_keys: at most 2^31-1 records per call");
     CR_REQUIRE(ctx, recs->d_bc_idx && recs->d_umi && recs->d_umi_qualn && recs->d_feature && d_keys_out, CRGPU_EINVAL,
                "crgpu_build_keys: NULL buffer");
     CR_REQUIRE(ctx, (recs->umi_len & 3u) != 0u || (uintptr_t)recs->d_umi_qualn % 4 == 0, CRGPU_EINVAL,
@@ -934,7 +935,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     if (!ctx || !out) return CRGPU_EINVAL;
     *out = nullptr;
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_count_keys: call crgpu_set_key_layout first");
-    CR_REQUIRE(ctx, n_keys < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_count_keys: at most 2^32-2 keys per call");
+    CR_REQUIRE(ctx, n_keys <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_keys: at most 2^31-1 keys per call");
     const KeyLayout &L = ctx->layout;
     const KL kl = make_kl(L);
     crgpu_counts *res = new (std::nothrow) crgpu_counts();
@@ -1167,7 +1168,7 @@ extern "C" int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs
                                        uint32_t *d_processed_umi_out, uint32_t *d_read_count_out, uint8_t *d_dupflags_out) {
     if (!ctx || !recs || !out) return CRGPU_EINVAL;
     *out = nullptr;
-    CR_REQUIRE(ctx, recs->n < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_count_records: at most 2^32-2 records per call");
+    CR_REQUIRE(ctx, recs->n <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_records: at most 2^31-1 records per call");
     const uint64_t n = recs->n;
     DevBuf keys_b, vals_b;
     CR_TRY(dmalloc(ctx, keys_b, n * sizeof(uint64_t)));

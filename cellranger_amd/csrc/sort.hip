@@ -667,7 +667,7 @@ int cr_radix_sort_u32(crgpu_ctx *ctx, uint32_t *d_keys, uint32_t *d_tmp, uint32_
 int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
                           uint32_t n_ranks, const uint32_t *bounds, uint64_t *counts_out) {
     CR_REQUIRE(ctx, n_ranks >= 1 && n_ranks <= RADIX, CRGPU_EINVAL, "partition: n_ranks must be 1..256");
-    CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "partition: at most 2^32-2 keys per call");
+    CR_REQUIRE(ctx, n <= 0x7FFFFFFFull, CRGPU_ERANGE, "partition: at most 2^31-1 keys per call");
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = 0;
     if (n == 0) return CRGPU_OK;
     if (bounds) {

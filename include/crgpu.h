@@ -25,6 +25,10 @@
  *   - library types are small ids 0..CRGPU_MAX_LIB-1 chosen by the caller (one per
  *     cr_types LibraryType in the GEM well); all libraries of a context share ONE canonical
  *     barcode space, as in the reference (Trans whitelists map onto the GEX list).
+ *   - batch sizes: the barcode stage (crgpu_match_and_count*, crgpu_correct*) takes up to 2^32 - 2 reads per call
+ *     (exercised with 2.5 G reads in one call), the count stage (crgpu_build_keys_dev, crgpu_count_keys_dev,
+ *     crgpu_count_records_dev, crgpu_partition_keys_dev) up to 2^31 - 1 records / keys per call (exercised with 1 G);
+ *     larger inputs are CRGPU_ERANGE, never truncated.
  *   - one context per (process, device).  Calls on one context must be serialised by the caller.
  */
 #ifndef CRGPU_H

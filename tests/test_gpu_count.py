@@ -200,6 +200,7 @@ def test_large_segments_use_binary_search_path():
 
 def test_empty_and_degenerate_inputs():
     import gpu_helpers as G
+    from cellranger_amd import engine as E
     from cellranger_amd import synth as S
     from cellranger_amd._lib import MISS, NO_FEATURE
 
@@ -212,6 +213,13 @@ def test_empty_and_degenerate_inputs():
     m = c.count(recs, 5)
     assert m.n_barcodes == 0 and m.nnz == 0 and list(m.indptr) == [0]
     assert c.count_records(recs, None, None, None).n_triplets == 0
+    # more than 2^31 - 1 records in one call: refused before anything is read or allocated
+    dummy = c.empty(16, np.uint64)
+    too_many = c.records(1 << 31, 12, dummy, dummy, dummy, dummy, dummy)
+    for call in (lambda: c.build_keys(too_many, dummy), lambda: c.count_records(too_many), lambda: c.count_keys(dummy, 1 << 31)):
+        with pytest.raises(E.CrgpuError) as ei:
+            call()
+        assert ei.value.code == -6 and "2^31-1" in str(ei.value)
     # reads whose barcodes are all invalid / features all NONE: columns exist only for seen barcodes
     n = 1000
     r = w.host_reads(0, n)
