@@ -330,3 +330,37 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys():
     res, m = _compare_with_oracle(c, w, r, n, 40)
     assert m.nnz > 1000
     c.close()
+
+
+def test_random_key_layouts_bit_exact():
+    """Random whitelist sizes, feature counts, UMI lengths and library counts: key widths from 20 to 64 bits, i.e. every
+    digit plan of the sort (all 8-bit, mixed 8/9-bit, a narrow last digit), the classic and the onesweep path, keys with
+    and without library bits -- each compared with the oracle read by read."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import FLAG_NONTXOMIC
+
+    rng = np.random.default_rng(2024)
+    seen_bits = set()
+    for trial in range(14):
+        umi_len = int(rng.choice([3, 4, 5, 6, 8, 10, 11, 12, 12, 12]))
+        n_genes = int(rng.choice([1, 2, 3, 17, 100, 1000, 5000, 36601, 60000]))
+        n_wl = int(rng.choice([64, 300, 5000, 100_000, 737_280]))
+        n_libs = int(rng.choice([1, 1, 2, 3, 5]))
+        bits = 1 + 2 * umi_len + int(np.ceil(np.log2(max(n_libs, 1)))) + int(np.ceil(np.log2(max(n_genes, 1)))) + int(np.ceil(np.log2(n_wl)))
+        if bits > 64:
+            continue
+        seen_bits.add(bits)
+        n = int(rng.integers(5_000, 120_000))
+        n_cells = min(int(rng.integers(3, 200)), n_wl // 2)
+        w = S.Workload(n_total=n, seed=1000 + trial, n_wl=n_wl, n_cells=n_cells, n_ambient=min(300, n_wl - n_cells),
+                       n_genes=n_genes, umi_len=umi_len, umi_err=0.02, cb_err=0.01, n_rate=0.002, no_feature_frac=0.05,
+                       reads_per_umi=int(rng.integers(1, 5)), n_libs=n_libs)
+        c = G.fresh_ctx()
+        for lib in range(n_libs):
+            c.set_whitelist(lib, w.wl_packed, length=16)
+        r = w.host_reads(0, n)
+        r["flags"] = (r["flags"] | np.where(rng.random(n) < 0.2, FLAG_NONTXOMIC, 0)).astype(np.uint8)
+        _compare_with_oracle(c, w, r, n, n_genes, n_libs=n_libs)
+        c.close()
+    assert len(seen_bits) >= 8 and max(seen_bits) >= 58 and min(seen_bits) <= 30

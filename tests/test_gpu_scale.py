@@ -218,27 +218,34 @@ def test_pack_metrics_and_feature_scans_at_scale(big):
         assert whole[i] == (NO_FEATURE if f < 0 else index[f]), i
 
 
-@pytest.mark.parametrize("n", [50_000_000, 1_000_000_000])
-def test_device_side_properties_up_to_the_full_1b_workload(n):
+@pytest.mark.parametrize("n,model", [
+    (50_000_000, {}), (1_000_000_000, {}),
+    # other key widths at a size where every pass of the sort runs thousands of chunks: 48, 43 and 53 bits
+    (30_000_000, dict(n_wl=100_000, n_cells=3000, n_ambient=20_000, n_genes=1000, umi_len=10)),
+    (30_000_000, dict(n_wl=5000, n_cells=300, n_ambient=2000, n_genes=17, umi_len=12)),
+    (30_000_000, dict(umi_len=8)),
+])
+def test_device_side_properties_up_to_the_full_1b_workload(n, model):
     """BASELINE configs[2] at its full size (1 B records on one GPU): the laws of cellranger_amd/selfcheck.py, checked on
     the device, and a second pass gives the same checksum of the whole triplet table."""
     import gpu_helpers as G
     from cellranger_amd import selfcheck
     from cellranger_amd import synth as S
 
-    w = S.Workload(n_total=n, seed=S.SEED0 + 3)
+    w = S.Workload(n_total=n, seed=S.SEED0 + 3, **model)
+    U = w.umi_len
     c = G.fresh_ctx()
     c.set_whitelist(0, w.wl_packed, length=16)
     c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
     d = dict(n=n, umi_len=w.umi_len)
     d["cb"], d["cb_qualn"], d["flags"] = c.empty(n, np.uint32), c.empty((n, 16), np.uint8), c.empty(n, np.uint8)
-    d["umi"], d["umi_qualn"], d["feature"] = c.empty(n, np.uint32), c.empty((n, 12), np.uint8), c.empty(n, np.uint32)
+    d["umi"], d["umi_qualn"], d["feature"] = c.empty(n, np.uint32), c.empty((n, U), np.uint8), c.empty(n, np.uint32)
     d["idx"], d["keys"] = c.empty(n, np.uint32), c.empty(n, np.uint64)
     chunk = 1 << 27
     for off in range(0, n, chunk):
         m = min(chunk, n - off)
         c.synth(w, off, m, cb=d["cb"].ptr + 4 * off, cb_qualn=d["cb_qualn"].ptr + 16 * off, umi=d["umi"].ptr + 4 * off,
-                umi_qualn=d["umi_qualn"].ptr + 12 * off, feature=d["feature"].ptr + 4 * off, flags=d["flags"].ptr + off)
+                umi_qualn=d["umi_qualn"].ptr + U * off, feature=d["feature"].ptr + 4 * off, flags=d["flags"].ptr + off)
     a = selfcheck.full_size_properties(c, d)
     b = selfcheck.full_size_properties(c, d)
     assert a == b
