@@ -32,8 +32,9 @@ def _bincount_where(values, mask, minlength):
     return acc
 
 
-def barcode_stage_properties(ctx, shard, device_index=0, _keep=None):
-    """K1 -> K2 on `shard` (device arrays cb, cb_qualn, flags, idx; n; library 0): histograms == per-read results,
+def barcode_stage_properties(ctx, shard, device_index=0, _keep=None, libs=(0,)):
+    """K1 -> K2 on `shard` (device arrays cb, cb_qualn, flags, idx; n; the reads' libraries `libs`, all with a whitelist
+    over the same canonical list): per-library histograms == per-read results,
     pass B touches only invalid reads, every correction is a Hamming-1 neighbour.  Returns {check name: value}."""
     import torch
 
@@ -52,21 +53,27 @@ def barcode_stage_properties(ctx, shard, device_index=0, _keep=None):
     idx = _i32(shard["idx"].ptr, n, dev)
     idx_a = idx.clone()
     hit_a = idx_a >= 0                                            # CRGPU_MISS is -1 as i32
-    valid = _i32(ctx.counts_dev(0, COUNTS_VALID), W, dev).clone()
-    # MakeShardHistograms::observe (make_shard_metrics.rs:171-188): one count per read whose barcode is on the whitelist
-    assert int(valid.sum()) == int(hit_a.sum())
-    assert torch.equal(_bincount_where(idx_a, hit_a, W), valid.long())
+    fl = torch.as_tensor(_DevView(shard["flags"].ptr, (n,), "|u1"), device=dev)
+    lib_of = fl & 0x0F
+    in_lib = [lib_of == l for l in libs] if len(libs) > 1 else [torch.ones_like(hit_a)]
+    valid = [_i32(ctx.counts_dev(l, COUNTS_VALID), W, dev).clone() for l in libs]
+    # MakeShardHistograms::observe (make_shard_metrics.rs:171-188): one count per read whose barcode is on the whitelist,
+    # in the histogram of the read's library type
+    assert sum(int(v.sum()) for v in valid) == int(hit_a.sum())
+    for v, m in zip(valid, in_lib):
+        assert torch.equal(_bincount_where(idx_a, hit_a & m, W), v.long())
     out["valid_reads"] = int(hit_a.sum())
     sync()
     ctx.correct(shard["cb"], shard["cb_qualn"], shard["flags"], n, shard["idx"])
     sync()
-    corrected = _i32(ctx.counts_dev(0, COUNTS_CORRECTED), W, dev).clone()
+    corrected = [_i32(ctx.counts_dev(l, COUNTS_CORRECTED), W, dev).clone() for l in libs]
     hit_b = idx >= 0
     fixed = hit_b & ~hit_a
     # barcode_correction.rs:328-345: only invalid barcodes are looked at; each corrected read counts once
     assert bool(((idx == idx_a) | ~hit_a).all())
-    assert int(corrected.sum()) == int(fixed.sum())
-    assert torch.equal(_bincount_where(idx, fixed, W), corrected.long())
+    assert sum(int(v.sum()) for v in corrected) == int(fixed.sum())
+    for v, m in zip(corrected, in_lib):
+        assert torch.equal(_bincount_where(idx, fixed & m, W), v.long())
     out["corrected_reads"] = int(fixed.sum())
     # corrector.rs:111-171: a corrected barcode is a whitelist entry at Hamming distance exactly 1 (<= 1 with an N)
     _, canon_sorted = ctx.canon_order()
@@ -80,7 +87,6 @@ def barcode_stage_properties(ctx, shard, device_index=0, _keep=None):
     n_diff = torch.zeros_like(y)
     for k in range(16):
         n_diff += (y >> (2 * k)) & 1
-    fl = torch.as_tensor(_DevView(shard["flags"].ptr, (n,), "|u1"), device=dev)
     has_n = (fl[sel] & 0x10) != 0
     assert bool(((n_diff == 1) | has_n).all()) and bool((n_diff <= 1).all())
     if _keep is not None:
@@ -88,15 +94,15 @@ def barcode_stage_properties(ctx, shard, device_index=0, _keep=None):
     return out
 
 
-def full_size_properties(ctx, shard, device_index=0):
+def full_size_properties(ctx, shard, device_index=0, libs=(0,)):
     """Runs K1 -> K2 -> keys -> dedup -> matrix on `shard` (device arrays cb, cb_qualn, flags, idx, umi, umi_qualn,
-    feature; n; umi_len; library 0) and returns {check name: value}; raises AssertionError on the first violated law."""
+    feature; n; umi_len; libraries `libs` = 0..len-1, key layout set accordingly) and returns {check name: value}; raises AssertionError on the first violated law."""
     import torch
 
     dev = "cuda:%d" % device_index
     n = shard["n"]
     keep = {}
-    out = barcode_stage_properties(ctx, shard, device_index, keep)
+    out = barcode_stage_properties(ctx, shard, device_index, keep, libs)
     valid, corrected, n_valid_after = keep["valid"], keep["corrected"], keep["n_valid_after"]
 
     def sync():
@@ -124,7 +130,9 @@ def full_size_properties(ctx, shard, device_index=0):
     assert bool((tkey[1:] > tkey[:-1]).all()) and bool((ct > 0).all())
     assert int(ct.long().sum()) == counts.n_molecules
     # every triplet's barcode has reads in the histograms (BarcodeIndex, barcode_index.rs:20-53)
-    seen = (valid != 0) | (corrected != 0)
+    seen = torch.zeros_like(valid[0], dtype=torch.bool)
+    for v in valid + corrected:
+        seen |= v != 0
     assert bool(seen[bc.long()].all())
     sync()
     md = ctx.assemble_matrix_dev(d_bc, d_ft, d_ct, nt)
@@ -139,11 +147,19 @@ def full_size_properties(ctx, shard, device_index=0):
     out["matrix_columns"], out["matrix_nnz"] = len(rank), int(nt)
     # BarcodeSummary (aligner.rs:33-68): one row per barcode with reads; umis = molecules; candidates = their reads
     rows = counts.barcode_summary()
-    assert np.array_equal(rows["barcode_rank"], rank) and (rows["library"] == 0).all()
-    assert np.array_equal(rows["reads"], (valid.long() + corrected.long())[torch.as_tensor(rank.astype(np.int64), device=dev)].cpu().numpy().astype(np.uint64))
+    order = np.lexsort((rows["barcode_rank"], rows["library"]))
+    assert np.array_equal(order, np.arange(len(rows)))                  # ordered by (library, rank)
+    for l, v, cr in zip(libs, valid, corrected):
+        mine = rows[rows["library"] == l]
+        reads = (v.long() + cr.long()).cpu().numpy()
+        assert np.array_equal(mine["barcode_rank"], np.nonzero(reads)[0].astype(np.uint32))   # a row per barcode with a read
+        assert np.array_equal(mine["reads"], reads[mine["barcode_rank"]].astype(np.uint64))
+    assert set(np.unique(rows["library"])) <= set(libs)
     assert int(rows["umis"].sum()) == counts.n_molecules
     cs = np.concatenate([np.zeros(1, np.int64), np.cumsum(data, dtype=np.int64)])
-    assert np.array_equal(rows["umis"].astype(np.int64), cs[indptr[1:]] - cs[indptr[:-1]])   # column sums of the matrix
+    col_umis = np.zeros(ctx.n_canon, np.int64)
+    np.add.at(col_umis, rows["barcode_rank"], rows["umis"].astype(np.int64))      # summed over the libraries
+    assert np.array_equal(col_umis[rank], cs[indptr[1:]] - cs[indptr[:-1]])        # == column sums of the matrix
     cand = int(rows["candidate_dup_reads"].sum())
     # mark_dups.rs: reads are conserved by the UMI correction; only low-support molecules drop out
     assert cand <= nk and cand > 0.9 * nk

@@ -224,6 +224,9 @@ def test_pack_metrics_and_feature_scans_at_scale(big):
     (30_000_000, dict(n_wl=100_000, n_cells=3000, n_ambient=20_000, n_genes=1000, umi_len=10)),
     (30_000_000, dict(n_wl=5000, n_cells=300, n_ambient=2000, n_genes=17, umi_len=12)),
     (30_000_000, dict(umi_len=8)),
+    # three libraries (BASELINE configs[3] has two library types): per-library histograms, K1 / K2 without the
+    # one-library fast paths, library bits inside the keys (60 bits)
+    (40_000_000, dict(n_libs=3, n_genes=5000)),
 ])
 def test_device_side_properties_up_to_the_full_1b_workload(n, model):
     """BASELINE configs[2] at its full size (1 B records on one GPU): the laws of cellranger_amd/selfcheck.py, checked on
@@ -235,8 +238,10 @@ def test_device_side_properties_up_to_the_full_1b_workload(n, model):
     w = S.Workload(n_total=n, seed=S.SEED0 + 3, **model)
     U = w.umi_len
     c = G.fresh_ctx()
-    c.set_whitelist(0, w.wl_packed, length=16)
-    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+    libs = tuple(range(w.n_libs))
+    for lib in libs:
+        c.set_whitelist(lib, w.wl_packed, length=16)
+    c.set_key_layout(w.n_genes, w.umi_len, w.n_libs, 0)
     d = dict(n=n, umi_len=w.umi_len)
     d["cb"], d["cb_qualn"], d["flags"] = c.empty(n, np.uint32), c.empty((n, 16), np.uint8), c.empty(n, np.uint8)
     d["umi"], d["umi_qualn"], d["feature"] = c.empty(n, np.uint32), c.empty((n, U), np.uint8), c.empty(n, np.uint32)
@@ -246,8 +251,8 @@ def test_device_side_properties_up_to_the_full_1b_workload(n, model):
         m = min(chunk, n - off)
         c.synth(w, off, m, cb=d["cb"].ptr + 4 * off, cb_qualn=d["cb_qualn"].ptr + 16 * off, umi=d["umi"].ptr + 4 * off,
                 umi_qualn=d["umi_qualn"].ptr + U * off, feature=d["feature"].ptr + 4 * off, flags=d["flags"].ptr + off)
-    a = selfcheck.full_size_properties(c, d)
-    b = selfcheck.full_size_properties(c, d)
+    a = selfcheck.full_size_properties(c, d, libs=libs)
+    b = selfcheck.full_size_properties(c, d, libs=libs)
     assert a == b
     assert 0.90 * n < a["valid_reads"] < 0.94 * n and 0.05 * n < a["corrected_reads"] < 0.09 * n   # SURVEY 8d error model
     assert a["molecules"] > 0.2 * a["keys"] and a["matrix_nnz"] == a["triplets"]
