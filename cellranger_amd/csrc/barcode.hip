@@ -19,6 +19,9 @@ int cr_make_views(crgpu_ctx *ctx, WlView *views);
 struct WlViewSet {
     WlView v[CRGPU_MAX_LIB];
     uint32_t n_canon;
+    // one-library calls (the UNIFORM kernels): v[0] holds the tables of library `ulib`, and reads whose flag byte
+    // names another library are misses
+    uint32_t ulib;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void k_match(const WlViewSet vs, const uint32_
         const uint32_t lib = f & CRGPU_FLAG_LIB_MASK;
         if (!(f & CRGPU_FLAG_CB_HAS_N)) {
             if (UNIFORM) {
-                if (lib == 0) rank = wl_lookup(vs.v[0], key);
+                if (lib == vs.ulib) rank = wl_lookup(vs.v[0], key);
             } else {
                 if (vs.v[lib].n) rank = wl_lookup(vs.v[lib], key);
             }
@@ -119,11 +122,60 @@ __global__ __launch_bounds__(256) void k_match(const WlViewSet vs, const uint32_
     }
 }
 
-static bool uniform_lib0(const crgpu_ctx *ctx) {
-    if (!ctx->wl[0].set) return false;
-    for (int l = 1; l < CRGPU_MAX_LIB; l++)
-        if (ctx->wl[l].set) return false;
-    return true;
+// ---- which calls take the one-library kernels ---------------------------------------------------------------
+// MAKE_SHARD and BARCODE_CORRECTION hand over the reads of ONE library at a time (a FASTQ / a library type per chunk),
+// whatever the number of libraries in the GEM well.  k_lib_mask finds that out from the flag bytes when several
+// whitelists are set (1 byte per read, one host read of 4 bytes); with a single whitelist nothing is scanned.
+__global__ __launch_bounds__(256) void k_lib_mask(const uint8_t *__restrict__ flags, uint64_t n, uint32_t *__restrict__ mask_out) {
+    uint32_t m = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        m |= 1u << (flags[i] & CRGPU_FLAG_LIB_MASK);
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o);
+    if ((threadIdx.x & 63u) == 0u && m) atomicOr(mask_out, m);
+}
+
+// *ulib_out = the library all reads of the call belong to, or -1 (several libraries, or none with a whitelist)
+static int pick_uniform_lib(crgpu_ctx *ctx, const uint8_t *d_flags, uint64_t n, int *ulib_out) {
+    *ulib_out = -1;
+    int n_set = 0, only = -1;
+    for (int l = 0; l < CRGPU_MAX_LIB; l++)
+        if (ctx->wl[l].set) {
+            n_set++;
+            only = l;
+        }
+    if (n_set == 0) return CRGPU_OK;
+    if (n_set == 1) {  // reads of any other library are misses either way
+        *ulib_out = only;
+        return CRGPU_OK;
+    }
+    if (!d_flags) {  // no flag bytes: every read is of library 0
+        if (ctx->wl[0].set) *ulib_out = 0;
+        return CRGPU_OK;
+    }
+    uint32_t *d_mask = ctx->d_scalars + 28, mask = 0;
+    CR_HIP(ctx, hipMemsetAsync(d_mask, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_lib_mask, dim3(cr_grid(n, 256 * 16)), dim3(256), 0, ctx->stream, d_flags, n, d_mask);
+    CR_HIP(ctx, hipGetLastError());
+    CR_TRY(crgpu_memcpy_d2h(ctx, &mask, d_mask, sizeof(mask)));
+    if (mask != 0u && (mask & (mask - 1u)) == 0u) {
+        const int l = __builtin_ctz(mask);
+        if (l < CRGPU_MAX_LIB && ctx->wl[l].set) *ulib_out = l;
+    }
+    return CRGPU_OK;
+}
+
+// views for the kernels; ulib >= 0: the tables of that library are presented as v[0]
+static int make_view_set(crgpu_ctx *ctx, WlViewSet &vs, int ulib) {
+    CR_TRY(cr_make_views(ctx, vs.v));
+    vs.n_canon = ctx->n_canon;
+    vs.ulib = ulib > 0 ? (uint32_t)ulib : 0u;
+    if (ulib > 0) {
+        const WlView t = vs.v[0];
+        vs.v[0] = vs.v[ulib];
+        vs.v[ulib] = t;
+    }
+    return CRGPU_OK;
 }
 
 // ---- K1 with an LDS-binned histogram ---------------------------------------------------------------
@@ -203,7 +255,7 @@ __global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const 
                     const bool ok = i < n;
                     key[jj] = ok ? cb[i] : 0u;
                     const uint32_t f = (ok && flags) ? flags[i] : 0u;
-                    live[jj] = ok && !(f & CRGPU_FLAG_CB_HAS_N) && (f & CRGPU_FLAG_LIB_MASK) == 0u;
+                    live[jj] = ok && !(f & CRGPU_FLAG_CB_HAS_N) && (f & CRGPU_FLAG_LIB_MASK) == vs.ulib;
                 }
 #pragma unroll
                 for (int jj = 0; jj < MB_LKB; jj++) {
@@ -433,7 +485,7 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
             const uint64_t i = base + (uint64_t)j * LH_THREADS + tid;
             key[j] = nkey[j];
             cfl[j] = nfl[j];
-            todo[j] = i < n && !(nfl[j] & CRGPU_FLAG_CB_HAS_N) && (nfl[j] & CRGPU_FLAG_LIB_MASK) == 0u;
+            todo[j] = i < n && !(nfl[j] & CRGPU_FLAG_CB_HAS_N) && (nfl[j] & CRGPU_FLAG_LIB_MASK) == vs.ulib;
             rank[j] = CRGPU_MISS;
         }
 #pragma unroll
@@ -653,14 +705,18 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_cb && d_idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
     cr_drop_miss_records(ctx);
+    int ulib = -1;
+    CR_TRY(pick_uniform_lib(ctx, d_flags, n, &ulib));
+    const bool uniform = ulib >= 0;
     WlViewSet vs;
-    CR_TRY(cr_make_views(ctx, vs.v));
-    vs.n_canon = ctx->n_canon;
-    const bool uniform = uniform_lib0(ctx);
+    CR_TRY(make_view_set(ctx, vs, ulib));
+    const WlTables &uw = ctx->wl[uniform ? ulib : 0];  // the call's library (one-library calls only)
 
     BinPlan plan;
     uint32_t n_slots = 0;
-    for (int l = 0; l < CRGPU_MAX_LIB; l++) plan.lib_slot[l] = ctx->wl[l].set ? n_slots++ : 0xFFFFFFFFu;
+    // a one-library call stages into a single slot, which k_hist_buckets adds to v[0] (= that library's tables)
+    for (int l = 0; l < CRGPU_MAX_LIB; l++)
+        plan.lib_slot[l] = uniform ? (l == 0 ? n_slots++ : 0xFFFFFFFFu) : (ctx->wl[l].set ? n_slots++ : 0xFFFFFFFFu);
     plan.buckets_per_lib = (ctx->n_canon + BIN_SIZE - 1) / BIN_SIZE;
     plan.n_buckets = plan.buckets_per_lib * n_slots;
 
@@ -698,7 +754,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     // (CRGPU_HOT_MIN_READS lowers the threshold so that the parity tests can drive this path with small inputs)
     uint64_t hot_min = 16ull << 20;
     if (const char *env = getenv("CRGPU_HOT_MIN_READS")) hot_min = strtoull(env, nullptr, 10);
-    const bool use_hot = uniform && ctx->wl[0].d_valA == nullptr && n >= hot_min && n >= 4ull * MB_TILE &&
+    const bool use_hot = uniform && uw.d_valA == nullptr && n >= hot_min && n >= 4ull * MB_TILE &&
                          ctx->d_canon_keys != nullptr;
     uint64_t first = 0;  // reads of the sampling batch (a multiple of MB_TILE)
     if (use_hot) {
@@ -735,6 +791,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
             rec.d_idx = d_idx_out;
             rec.n = n;
             rec.first = first;
+            rec.ulib = ulib;
         } else {
             cr_drop_miss_records(ctx);  // not fatal: K2 scans idx as before
         }
@@ -776,8 +833,8 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                 uint32_t *d_hh = reinterpret_cast<uint32_t *>(ctx->d_hot_image + HOT_SLOTS);
                 if (e == hipSuccess) e = hipMemsetAsync(ctx->d_hot_image, 0xFF, hot_lds, ctx->stream);
                 if (e == hipSuccess) e = hipMemsetAsync(d_hh, 0, 256 * sizeof(uint32_t), ctx->stream);
-                hipLaunchKernelGGL(k_hot_hist, dim3(128), dim3(256), 0, ctx->stream, ctx->wl[0].d_valid, ctx->n_canon, d_hh);
-                hipLaunchKernelGGL(k_hot_build, dim3(128), dim3(256), 0, ctx->stream, ctx->wl[0].d_valid, ctx->d_canon_keys,
+                hipLaunchKernelGGL(k_hot_hist, dim3(128), dim3(256), 0, ctx->stream, uw.d_valid, ctx->n_canon, d_hh);
+                hipLaunchKernelGGL(k_hot_build, dim3(128), dim3(256), 0, ctx->stream, uw.d_valid, ctx->d_canon_keys,
                                    ctx->n_canon, d_hh, ctx->d_hot_image);
                 hot_ready = true;
             }
@@ -879,7 +936,7 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
     uint32_t *__restrict__ idx_inout = P.idx_inout;
     uint8_t *__restrict__ corrected_out = P.corrected_out;
     const uint32_t lib = UNIFORM ? 0u : (f & CRGPU_FLAG_LIB_MASK);
-    if (UNIFORM && (f & CRGPU_FLAG_LIB_MASK) != 0u) return;
+    if (UNIFORM && (f & CRGPU_FLAG_LIB_MASK) != vs.ulib) return;
     const WlView &w = vs.v[lib];
     if (!UNIFORM && w.n == 0) return;
 
@@ -1042,8 +1099,18 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
         CR_REQUIRE(ctx, (uintptr_t)d_qualn % 16 == 0, CRGPU_EINVAL, "crgpu_correct: quality buffer must be 16-byte aligned");
     // NotNan::try_from(threshold).ok()? (corrector.rs:152): a NaN threshold corrects nothing
     if (ctx->confidence_threshold != ctx->confidence_threshold) return CRGPU_OK;
+    // the records K1 left for exactly these buffers (consumed here: a second call scans idx again) also say which
+    // library the call is about; otherwise the flag bytes do
+    MissRecords &rec = ctx->rec;
+    const bool use_rec = rec.valid && rec.d_cb == d_cb && rec.d_flags == d_flags && rec.d_idx == d_idx_inout && rec.n == n;
+    int ulib = -1;
+    if (use_rec)
+        ulib = rec.ulib;
+    else
+        CR_TRY(pick_uniform_lib(ctx, d_flags, n, &ulib));
+    const bool uniform = ulib >= 0;
     WlViewSet vs;
-    CR_TRY(cr_make_views(ctx, vs.v));
+    CR_TRY(make_view_set(ctx, vs, ulib));
     void *ws;
     CR_TRY(cr_scratch(ctx, n * sizeof(uint32_t), &ws));
     uint32_t *miss_list = (uint32_t *)ws;
@@ -1055,10 +1122,6 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
     const bool check_expected = d_qualn && !fake_quals && ctx->max_expected_errors < 1.7976931348623157e308;
     const K2Params P{d_qualn, ctx->cb_len, ctx->d_ptab, ctx->max_expected_errors, ctx->confidence_threshold, check_expected,
                      d_idx_inout, d_corrected_out};
-    const bool uniform = uniform_lib0(ctx);
-    // the records K1 left for exactly these buffers (consumed here: a second call scans idx again)
-    MissRecords &rec = ctx->rec;
-    const bool use_rec = rec.valid && uniform && rec.d_cb == d_cb && rec.d_flags == d_flags && rec.d_idx == d_idx_inout && rec.n == n;
     if (use_rec) {
         // reads before rec.first (K1's sampling batch) are not in the records; everything is scanned when they overflowed
         const uint32_t *overflow = rec.d_count + rec.regions;

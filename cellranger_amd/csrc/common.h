@@ -79,6 +79,7 @@ struct MissRecords {
     const uint8_t *d_flags = nullptr;
     const uint32_t *d_idx = nullptr;
     uint64_t n = 0, first = 0;  // reads [0, first) (the sampling batch) are not covered
+    int ulib = 0;               // the library of the call that wrote the records
     uint32_t regions = 0, cap = 0;  // one region per wave of the lookup kernel, cap records each
     uint32_t *d_i = nullptr, *d_key = nullptr, *d_count = nullptr;  // d_count[regions] = overflow flag
     uint8_t *d_fl = nullptr;

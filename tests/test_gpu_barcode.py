@@ -247,3 +247,60 @@ def test_empty_and_error_paths():
     c.correct(None, None, None, 0, None)
     assert c.get_counts(0).sum() == 0
     c.close()
+
+
+@pytest.mark.parametrize("hot", [False, True])
+def test_one_library_per_call_in_a_three_library_well(monkeypatch, hot):
+    """MAKE_SHARD / BARCODE_CORRECTION hand over one library per call.  With three whitelists set, a call whose reads all
+    carry one library id takes the one-library kernels (with `hot`: the LDS table and the miss records) with that
+    library's tables; pass A runs for every library before pass B, so B's first two calls scan idx and the last one
+    reads A's records.  A mixed call afterwards takes the general kernels.  All equal to the oracle."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import COUNTS_CORRECTED, COUNTS_VALID
+
+    if hot:
+        monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")
+    n = 600_000
+    w = S.Workload(n_total=n, seed=S.SEED0 + 9, n_wl=20_000, n_cells=300, n_ambient=2000, n_libs=3)
+    r = w.host_reads(0, n)
+    lib_of = r["flags"] & 0x0F
+    order = np.argsort(lib_of, kind="stable")                  # the reads library by library
+    r = {k: np.ascontiguousarray(v[order]) for k, v in r.items()}
+    lib_of = lib_of[order]
+    c = G.fresh_ctx()
+    for lib in range(3):
+        c.set_whitelist(lib, w.wl_packed, length=16)
+    _, canon_sorted = c.canon_order()
+    bounds = np.searchsorted(lib_of, np.arange(4))
+    dev = []
+    for lib in range(3):                                        # pass A, one call per library
+        a, b = bounds[lib], bounds[lib + 1]
+        d = dict(cb=c.upload(r["cb"][a:b]), cbq=c.upload(r["cb_qualn"][a:b]), fl=c.upload(r["flags"][a:b]),
+                 idx=c.empty(b - a, np.uint32), corr=c.empty(b - a, np.uint8))
+        c.match_and_count(d["cb"], d["fl"], b - a, d["idx"])
+        dev.append(d)
+    idx_a = np.concatenate([d["idx"].to_host() for d in dev])
+    for lib in range(3):                                        # pass B
+        d = dev[lib]
+        c.correct(d["cb"], d["cbq"], d["fl"], bounds[lib + 1] - bounds[lib], d["idx"], d["corr"])
+    idx_b = np.concatenate([d["idx"].to_host() for d in dev])
+    corr = np.concatenate([d["corr"].to_host() for d in dev])
+
+    owl = O.Whitelist(E.unpack_seqs(w.wl_packed, 16))
+    res = O.run_pipeline(G.oracle_reads_from_packed(r, 16, w.umi_len), [owl] * 3, count=False, n_threads=4)
+    exp_a, exp_b = G.oracle_expected_idx(res, canon_sorted)
+    assert np.array_equal(idx_a, exp_a) and np.array_equal(idx_b, exp_b)
+    assert np.array_equal(corr, (res.bc_state == 2).astype(np.uint8))
+    for lib in range(3):
+        assert np.array_equal(c.get_counts(lib, COUNTS_VALID), G.hist_as_rank_counts(res.valid_hist[lib], 16, canon_sorted))
+        assert np.array_equal(c.get_counts(lib, COUNTS_CORRECTED),
+                              G.hist_as_rank_counts(res.corrected_hist[lib], 16, canon_sorted))
+    assert (res.bc_state == 2).sum() > 10_000 and min(np.diff(bounds)) > 100_000
+    # the same reads in ONE mixed call: the general kernels, same answers
+    c.reset_counts()
+    ia, ib, cr, _ = G.gpu_barcode_stage(c, r, n)
+    assert np.array_equal(ia, exp_a) and np.array_equal(ib, exp_b) and np.array_equal(cr, corr)
+    c.close()
