@@ -11,7 +11,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+# ORACLE_LIB: another build of the same checker (the sanitizer build of `make -C oracle asan`)
+LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 
 NO_FEATURE = 0xFFFFFFFF
 MAX_LIB = 16
