@@ -140,6 +140,7 @@ SYMBOLS = {
     "crgpu_whitelist_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "crgpu_get_canon_order": (_i, [_vp, _vp, _vp]),
     "crgpu_pack_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp]),
+    "crgpu_pack_rows_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp, _vp]),
     "crgpu_shard_metrics_dev": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, C.POINTER(ShardMetrics)]),
     "crgpu_match_and_count_dev": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "crgpu_set_posterior": (_i, [_vp, _dbl, _dbl]),

@@ -97,6 +97,47 @@ extern "C" int crgpu_pack_dev(crgpu_ctx *ctx, const uint8_t *d_seq, const uint8_
     return CRGPU_OK;
 }
 
+// The same packing straight from whole read rows (R1 as the FASTQ holds it: row_stride bytes per read): bases
+// [offset, offset + len) of every row, i.e. the slicing of RnaRead's barcode / UMI ranges
+// (cr_types/src/rna_read.rs:103-138) done on the device, so the host uploads R1 once for both parts.
+__global__ __launch_bounds__(256) void k_pack_rows(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, uint64_t n,
+                                                   uint32_t row_stride, uint32_t offset, uint32_t len,
+                                                   uint32_t *__restrict__ packed, uint8_t *__restrict__ qualn,
+                                                   uint8_t *__restrict__ flags) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint8_t *s = seq + i * row_stride + offset, *q = qual + i * row_stride + offset;
+        uint32_t key = 0;
+        bool any_n = false;
+        for (uint32_t j = 0; j < len; j++) {
+            bool is_n;
+            const uint32_t code = base_code(s[j], is_n);
+            key = (key << 2) | code;
+            any_n |= is_n;
+            const uint32_t qq = q[j] > 127u ? 127u : q[j];
+            qualn[i * len + j] = (uint8_t)(qq | (is_n ? 0x80u : 0u));
+        }
+        packed[i] = key;
+        if (flags && any_n) flags[i] |= CRGPU_FLAG_CB_HAS_N;
+    }
+}
+
+extern "C" int crgpu_pack_rows_dev(crgpu_ctx *ctx, const uint8_t *d_seq_rows, const uint8_t *d_qual_rows, uint64_t n,
+                                   uint32_t row_stride, uint32_t offset, uint32_t len, uint32_t *d_packed_out,
+                                   uint8_t *d_qualn_out, uint8_t *d_flags_inout) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_REQUIRE(ctx, len >= 1 && len <= 16, CRGPU_ERANGE, "sequence length %u unsupported (<= 16)", len);
+    CR_REQUIRE(ctx, (uint64_t)offset + len <= row_stride, CRGPU_EINVAL, "crgpu_pack_rows_dev: bases [%u, %u) lie outside a row of %u bytes",
+               offset, offset + len, row_stride);
+    if (n == 0) return CRGPU_OK;
+    CR_REQUIRE(ctx, d_seq_rows && d_qual_rows && d_packed_out && d_qualn_out, CRGPU_EINVAL, "crgpu_pack_rows_dev: NULL buffer");
+    CrTimer t(ctx, CRGPU_T_PACK, n);
+    hipLaunchKernelGGL(k_pack_rows, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_seq_rows, d_qual_rows, n, row_stride, offset,
+                       len, d_packed_out, d_qualn_out, d_flags_inout);
+    CR_HIP(ctx, hipGetLastError());
+    return CRGPU_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: exact match + valid-barcode histogram
 // ------------------------------------------------------------------------------------------------

@@ -343,6 +343,11 @@ class Context:
     def pack(self, d_seq, d_qual, n, length, d_packed, d_qualn, d_flags=None):
         self._check(self.L.crgpu_pack_dev(self.h, _p(d_seq), _p(d_qual), n, length, _p(d_packed), _p(d_qualn), _p(d_flags)))
 
+    def pack_rows(self, d_seq_rows, d_qual_rows, n, row_stride, offset, length, d_packed, d_qualn, d_flags=None):
+        """pack bases [offset, offset + length) of every row_stride-byte read row (barcode / UMI ranges of R1)"""
+        self._check(self.L.crgpu_pack_rows_dev(self.h, _p(d_seq_rows), _p(d_qual_rows), n, row_stride, offset, length,
+                                               _p(d_packed), _p(d_qualn), _p(d_flags)))
+
     def match_and_count(self, d_cb, d_flags, n, d_idx_out):
         self._check(self.L.crgpu_match_and_count_dev(self.h, _p(d_cb), _p(d_flags), n, _p(d_idx_out)))
 

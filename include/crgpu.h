@@ -124,6 +124,13 @@ int crgpu_get_canon_order(crgpu_ctx *ctx, uint32_t *order_out, uint32_t *seqs_ou
  * flags_inout (nullable) n bytes: CRGPU_FLAG_CB_HAS_N is OR-ed in when a base is N. */
 int crgpu_pack_dev(crgpu_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, uint32_t len,
                    uint32_t *d_packed_out, uint8_t *d_qualn_out, uint8_t *d_flags_inout);
+/* The same from whole read rows as the FASTQ holds them (R1: row_stride bytes of sequence / quality per read): packs
+ * bases [offset, offset + len) of every row, e.g. (0, 16) for the barcode and (16, 12) for the UMI of a 28-base R1 -- the
+ * host uploads R1 once and slices on the device (RnaRead's ranges, cr_types/src/rna_read.rs:103-138).  Outputs as
+ * crgpu_pack_dev (qualn_out is n x len, not row_stride). */
+int crgpu_pack_rows_dev(crgpu_ctx *ctx, const uint8_t *d_seq_rows, const uint8_t *d_qual_rows, uint64_t n,
+                        uint32_t row_stride, uint32_t offset, uint32_t len, uint32_t *d_packed_out,
+                        uint8_t *d_qualn_out, uint8_t *d_flags_inout);
 
 /* ---- MAKE_SHARD read metrics ----------------------------------------------------------
  * The per-read quality metrics MakeShardVisitor::visit_processed_read accumulates for the barcode and UMI parts of a

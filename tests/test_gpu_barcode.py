@@ -223,6 +223,20 @@ def test_pack_and_host_abi_match_device_abi():
     assert np.array_equal(d_pk.to_host(), r["cb"])
     assert np.array_equal(d_qn.to_host(), r["cb_qualn"])
     assert np.array_equal(d_fl.to_host() & FLAG_CB_HAS_N, r["flags"] & FLAG_CB_HAS_N)
+    # the same from whole R1 rows (16 barcode bases + 12 UMI bases + 3 bytes of anything, an odd stride on purpose)
+    umi_ascii, umi_qual = S.to_ascii(r["umi"], r["umi_qualn"], 12)
+    pad = np.full((n, 3), ord("G"), np.uint8)
+    rows_s, rows_q = np.hstack([seq_ascii, umi_ascii, pad]), np.hstack([qual, umi_qual, pad])
+    d_rs, d_rq = c.upload(rows_s), c.upload(rows_q)
+    d_pk2, d_qn2, d_fl2 = c.empty(n, np.uint32), c.empty((n, 16), np.uint8), c.zeros(n, np.uint8)
+    c.pack_rows(d_rs, d_rq, n, 31, 0, 16, d_pk2, d_qn2, d_fl2)
+    assert np.array_equal(d_pk2.to_host(), r["cb"]) and np.array_equal(d_qn2.to_host(), r["cb_qualn"])
+    assert np.array_equal(d_fl2.to_host(), d_fl.to_host())
+    d_um, d_uq = c.empty(n, np.uint32), c.empty((n, 12), np.uint8)
+    c.pack_rows(d_rs, d_rq, n, 31, 16, 12, d_um, d_uq)
+    assert np.array_equal(d_um.to_host(), r["umi"]) and np.array_equal(d_uq.to_host(), r["umi_qualn"])
+    with pytest.raises(Exception, match="outside a row"):
+        c.pack_rows(d_rs, d_rq, n, 31, 20, 12, d_um, d_uq)
     idx_a, idx_b, corr, _ = G.gpu_barcode_stage(c, r, n)
     c.reset_counts()
     h_a = c.match_and_count_host(0, seq_ascii, qual)
