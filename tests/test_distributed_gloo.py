@@ -1,5 +1,5 @@
 """N>1 path on CPUs: CountPipeline's collectives (C1 all-reduce of the prior, C2 all-to-all of molecule
-keys by barcode range, C3 gather of triplets) under gloo with world_size 2 and 3, driven through the
+keys by barcode range, C3 gather of triplets) under gloo with world_size 2, 3 and 8 (the size of the scaling run), driven through the
 oracle-backed stand-in backend; the assembled matrix must equal the single-process oracle's."""
 import os
 import socket
@@ -53,7 +53,7 @@ def _worker(rank, world, port, n, seed, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_pipeline_collectives_match_single_process_oracle(world, tmp_path):
     sys.path.insert(0, HERE)
     import oracle_lib as O
