@@ -183,7 +183,15 @@ struct DupInfo {
     bool is_corrected, is_low_support_umi, is_umi_count;
 };
 
+/// BarcodeSummary (cr_lib/src/aligner.rs:33-68) with the barcode as its canonical rank and the library id in place of
+/// the LibraryType; `reads` comes from the context's histograms (the reads check_and_update / correct_barcodes saw).
+struct BarcodeSummary {
+    uint32_t barcode_rank, library;
+    uint64_t reads, umis, candidate_dup_reads, umi_corrected_reads;
+};
+
 struct BarcodeDupMarker {
+    std::vector<BarcodeSummary> barcode_summaries;    // ordered by (library, barcode), one per barcode with a read
     std::vector<UmiCount> umi_counts;                 // sorted per barcode as align_and_count.rs:314
     std::vector<FeatureBarcodeCount> feature_counts;  // sorted by (barcode, feature)
     /// process(read): one entry per observe() call, in call order (the order stands in for the qname
@@ -242,6 +250,14 @@ class DupBuilder {
         std::vector<uint8_t> ml(nm), mt(nm);
         int rc = crgpu_counts_triplets(ctx_.get(), c, tb.data(), tf.data(), tc.data());
         if (rc == CRGPU_OK) rc = crgpu_counts_molecules(ctx_.get(), c, mb.data(), ml.data(), mf.data(), mu.data(), mr.data(), mt.data());
+        std::vector<crgpu_barcode_summary_row> rows;
+        if (rc == CRGPU_OK) {
+            uint64_t n_rows = 0;
+            rc = crgpu_counts_barcode_summary(ctx_.get(), c, 0, 0xFFFFFFFFu, nullptr, 0, &n_rows);
+            rows.resize(n_rows);
+            if (rc == CRGPU_OK && n_rows)
+                rc = crgpu_counts_barcode_summary(ctx_.get(), c, 0, 0xFFFFFFFFu, rows.data(), n_rows, &n_rows);
+        }
         crgpu_counts_free(ctx_.get(), c);
         ctx_.check(rc);
         ctx_.check(crgpu_memcpy_d2h(ctx_.get(), pu.data(), d_pu.p, n * 4));
@@ -252,6 +268,8 @@ class DupBuilder {
             if (df[i] & CRGPU_DUP_HAS)
                 out.dup_infos[i] = DupInfo{pu[i], rc32[i], (df[i] & CRGPU_DUP_CORRECTED) != 0, (df[i] & CRGPU_DUP_LOW_SUPPORT) != 0,
                                            (df[i] & CRGPU_DUP_UMI_COUNT) != 0};
+        for (const auto &r : rows)
+            out.barcode_summaries.push_back({r.barcode_rank, r.library, r.reads, r.umis, r.candidate_dup_reads, r.umi_corrected_reads});
         for (uint64_t i = 0; i < nt; i++) out.feature_counts.push_back({tb[i], tf[i], tc[i]});
         for (uint64_t i = 0; i < nm; i++) out.umi_counts.push_back({mb[i], ml[i], mf[i], mu[i], mr[i], mt[i]});
         return out;

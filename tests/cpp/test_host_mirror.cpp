@@ -81,6 +81,8 @@ static void test_correct_umis_through_dup_builder() {
     const Qual q(4, 'I');
     const uint32_t g0 = 0, g1 = 1;
     {
+        // the seven reads below carry barcode 0: MAKE_SHARD's pass over them fills the valid histogram
+        corrector.check_and_update(std::vector<std::string>(7, "ACGTACGTACGTACGT"));
         // {(ACAA,g0):3, (ACAT,g0):2, (ACAA,g1):1, (ACTT,g1):1}: ACAT -> ACAA within g0 (count wins)
         crgpu::DupBuilder b(ctx, 2, 4);
         for (int i = 0; i < 3; i++) b.observe(0, 0, "ACAA", q, g0);
@@ -95,6 +97,14 @@ static void test_correct_umis_through_dup_builder() {
             CHECK(m.umi_counts[1].feature_idx == g1 && m.umi_counts[1].umi == 0b00011111u && m.umi_counts[1].read_count == 1);
         }
         CHECK(m.feature_counts.size() == 2 && m.feature_counts[0].umi_count == 1 && m.feature_counts[1].umi_count == 1);
+        // BarcodeSummary::observe over the same reads (aligner.rs:54-67): 7 reads, 2 with is_umi_count, 6 that are not
+        // low support (the lone (ACAA,g1) read is), 2 whose UMI was corrected (ACAT x 2)
+        CHECK(m.barcode_summaries.size() == 1);
+        if (m.barcode_summaries.size() == 1) {
+            const crgpu::BarcodeSummary &s = m.barcode_summaries[0];
+            CHECK(s.barcode_rank == 0 && s.library == 0 && s.reads == 7 && s.umis == 2);
+            CHECK(s.candidate_dup_reads == 6 && s.umi_corrected_reads == 2);
+        }
         // BarcodeDupMarker::process per read (mark_dups.rs:280-363), in observe() order
         CHECK(m.dup_infos.size() == 7);
         if (m.dup_infos.size() == 7) {
