@@ -1,0 +1,22 @@
+"""One-off: the cfg3 model at 12 M .. 100 M reads (thousands of chunk tickets in every pass of the sort)
+compared with the oracle read by read -- the checker of tests/test_gpu_count.py at 12x .. 100x its usual size.
+usage (GPU box): python3 scripts/parity_large.py [n_reads]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gpu_helpers as G  # noqa: E402
+import test_gpu_count as T  # noqa: E402
+from cellranger_amd import synth as S  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 12_000_000
+w = S.Workload(n_total=n, seed=S.SEED0 + 3)
+c = G.fresh_ctx()
+c.set_whitelist(0, w.wl_packed, length=16)
+r = w.host_reads(0, n)
+t0 = time.time()
+res, m = T._compare_with_oracle(c, w, r, n, w.n_genes)
+print("parity ok: n=%d columns=%d nnz=%d molecules=%d (%.0f s)" % (n, m.n_barcodes, m.nnz, len(res.mol), time.time() - t0))
