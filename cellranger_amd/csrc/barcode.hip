@@ -236,6 +236,7 @@ static int make_view_set(crgpu_ctx *ctx, WlViewSet &vs, int ulib) {
 #define MB_MAX_BUCKETS 1024
 #define MB_BPT (MB_MAX_BUCKETS / 256)  // buckets per thread in the tile scan
 #define MB_LKB 8                       // reads whose lookups advance together
+#define MB_LKG 4                       // ... in a call with several libraries (per-lane table pointers cost registers)
 #define MB_CURSOR_STRIDE 32u            // one 128-byte line per bucket cursor: atomics on one line serialise in one L2 channel
 
 struct BinPlan {
@@ -342,25 +343,70 @@ __global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const 
                 }
             }
         } else {
+            // Several libraries in one call: the same phases with per-lane table pointers (every library has its own
+            // index and, for a translation whitelist, its own rank table).  Lanes without a live read follow the tables
+            // of `safe_lib` (a library that has a whitelist) so that every load of a phase is unconditional.
+            uint32_t safe_lib = 0;
+            for (uint32_t l = 0; l < CRGPU_MAX_LIB; l++)
+                if (plan.lib_slot[CRGPU_MAX_LIB - 1u - l] != 0xFFFFFFFFu) safe_lib = CRGPU_MAX_LIB - 1u - l;
 #pragma unroll
-        for (int j = 0; j < MB_ITEMS; j++) {
-            const uint64_t i = tile * MB_TILE + (uint64_t)j * 256 + tid;
-            bv[j] = 0xFFFFFFFFu;
-            loff[j] = 0;
-            if (i < n) {
-                const uint32_t key = cb[i];
-                const uint32_t f = flags ? flags[i] : 0u;
-                const uint32_t lib = f & CRGPU_FLAG_LIB_MASK;
-                uint32_t rank = CRGPU_MISS;
-                if (!(f & CRGPU_FLAG_CB_HAS_N) && vs.v[lib].n) rank = wl_lookup(vs.v[lib], key);
-                idx_out[i] = rank;
-                if (rank != CRGPU_MISS) {
-                    const uint32_t b = plan.lib_slot[lib] * plan.buckets_per_lib + (rank >> BIN_SHIFT);
-                    loff[j] = (uint16_t)atomicAdd(&bcnt[b], 1u);
-                    bv[j] = (b << 16) | (rank & (BIN_SIZE - 1u));
+            for (int j0 = 0; j0 < MB_ITEMS; j0 += MB_LKG) {
+                uint32_t key[MB_LKG], lo[MB_LKG], hi[MB_LKG], lib[MB_LKG];
+                const uint32_t *twl[MB_LKG];
+                U32x4 d[MB_LKG];
+                bool live[MB_LKG];
+#pragma unroll
+                for (int jj = 0; jj < MB_LKG; jj++) {
+                    const uint64_t i = tile * MB_TILE + (uint64_t)(j0 + jj) * 256 + tid;
+                    const bool ok = i < n;
+                    key[jj] = ok ? cb[i] : 0u;
+                    const uint32_t f = (ok && flags) ? flags[i] : 0u;
+                    const uint32_t l = f & CRGPU_FLAG_LIB_MASK;
+                    live[jj] = ok && !(f & CRGPU_FLAG_CB_HAS_N) && vs.v[l].n != 0u;
+                    lib[jj] = live[jj] ? l : safe_lib;
+                }
+#pragma unroll
+                for (int jj = 0; jj < MB_LKG; jj++) {
+                    const WlView &w = vs.v[lib[jj]];
+                    const uint32_t bin = (uint32_t)((uint64_t)key[jj] >> w.shiftE);
+                    const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offE + bin);
+                    lo[jj] = b2.a;
+                    hi[jj] = b2.b;
+                    twl[jj] = reinterpret_cast<const uint32_t *>(w.tailA);
+                }
+#pragma unroll
+                for (int jj = 0; jj < MB_LKG; jj++) d[jj] = *reinterpret_cast<const U32x4 *>(twl[jj] + (lo[jj] >> 1));
+#pragma unroll
+                for (int jj = 0; jj < MB_LKG; jj++) {
+                    const int j = j0 + jj;
+                    const uint64_t i = tile * MB_TILE + (uint64_t)j * 256 + tid;
+                    const WlView &w = vs.v[lib[jj]];
+                    const uint32_t tail = key[jj] & ((1u << w.bitsB) - 1u);
+                    const uint32_t p0 = lo[jj] & ~1u;
+                    uint32_t found = CRGPU_MISS;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const uint32_t pos = p0 + k;
+                        const uint32_t t = (d[jj].w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                        if (pos >= lo[jj] && pos < hi[jj] && t == tail) found = pos;
+                    }
+                    if (hi[jj] > p0 + 8u && found == CRGPU_MISS && live[jj]) {  // a bin of more than 7 keys: rare
+                        scan_u16_range<4>(w.tailA, p0 + 8u, hi[jj], [&](uint32_t t, uint32_t pos) {
+                            if (t == tail) found = pos;
+                        });
+                    }
+                    uint32_t rank = CRGPU_MISS;
+                    if (live[jj] && found != CRGPU_MISS) rank = w.valA ? w.valA[found] : found;
+                    bv[j] = 0xFFFFFFFFu;
+                    loff[j] = 0;
+                    if (i < n) idx_out[i] = rank;
+                    if (rank != CRGPU_MISS) {
+                        const uint32_t b = plan.lib_slot[lib[jj]] * plan.buckets_per_lib + (rank >> BIN_SHIFT);
+                        loff[j] = (uint16_t)atomicAdd(&bcnt[b], 1u);
+                        bv[j] = (b << 16) | (rank & (BIN_SIZE - 1u));
+                    }
                 }
             }
-        }
         }
         __syncthreads();
         // exclusive scan of the tile's bucket counts (MB_BPT consecutive buckets per thread) and one
