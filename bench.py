@@ -193,10 +193,10 @@ def main():
             # over their summed HIP-event durations == per-launch bytes / average launch duration
             achieved = bpe * units / (ms * 1e-3) / 1e9
             # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-            # profiles/r01_k_*_pmc_fetch_write.json): measured bytes per element x elements per launch
+            # profiles/r01_m_*_pmc_fetch_write.json): measured bytes per element x elements per launch
             traffic = None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_k_cfg3_1B_pmc_fetch_write.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r01_m_cfg3_1B_pmc_fetch_write.json")) as f:
                     pmc = json.load(f)["derived"]
                 if kname == "k_radix_scatter":
                     traffic = pmc["k_radix_scatter_hbm_bytes_per_element_weighted"] * units / launches
