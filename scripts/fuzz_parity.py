@@ -1,6 +1,6 @@
 """One-off randomized parity hunt (not part of the suite): random layouts, sizes around tile boundaries, library mixes
 and multiplexing masks, each compared with the oracle read by read through tests/test_gpu_count.py's checker.
-usage (GPU box): python3 scripts/fuzz_parity.py [n_trials] [seed]"""
+usage (GPU box): python3 scripts/fuzz_parity.py [n_trials] [seed] [max_reads]"""
 import os
 import sys
 import traceback
@@ -19,6 +19,7 @@ from cellranger_amd._lib import FLAG_NONTXOMIC  # noqa: E402
 def main():
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 300_000
     edges = [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193, 16383, 16384, 16385,
              32767, 32768, 32769, 65535, 65536, 65537, 131071, 131073]
     bad = 0
@@ -31,7 +32,7 @@ def main():
         bits = 1 + 2 * umi_len + int(np.ceil(np.log2(n_libs))) + int(np.ceil(np.log2(max(n_genes, 1)))) + int(np.ceil(np.log2(n_wl)))
         if bits > 64 or n_wl > 4 ** cb_len // 2:
             continue
-        n = int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, 300_000))
+        n = int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, max_n))
         n_cells = max(1, min(int(rng.integers(1, 400)), n_wl // 2))
         mux = int(rng.integers(0, 1 << n_libs)) if n_libs > 1 and rng.random() < 0.4 else 0
         cfg = dict(n=n, umi_len=umi_len, n_genes=n_genes, n_wl=n_wl, n_libs=n_libs, cb_len=cb_len, n_cells=n_cells, mux=mux, bits=bits)
