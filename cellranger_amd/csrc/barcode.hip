@@ -16,6 +16,17 @@
 
 int cr_make_views(crgpu_ctx *ctx, WlView *views);
 
+// Streams that are touched once (barcodes, flag bytes, quality rows, the index output) go around the caches' normal
+// replacement so that they do not evict the whitelist tables, which every cold lookup and every K2 probe needs in L2.
+typedef uint32_t cr_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef CR_NO_NT
+#define CR_LOAD_STREAM(p) (*(p))
+#define CR_STORE_STREAM(v, p) (*(p) = (v))
+#else
+#define CR_LOAD_STREAM(p) __builtin_nontemporal_load(p)
+#define CR_STORE_STREAM(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 struct WlViewSet {
     WlView v[CRGPU_MAX_LIB];
     uint32_t n_canon;
@@ -561,8 +572,8 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
 #pragma unroll
     for (int j = 0; j < LH_ITEMS; j++) {
         const uint64_t i = (uint64_t)blockIdx.x * chunk + (uint64_t)j * LH_THREADS + tid;
-        nkey[j] = i < n ? cb[i] : 0u;
-        nfl[j] = (i < n && flags) ? flags[i] : 0u;
+        nkey[j] = i < n ? CR_LOAD_STREAM(&cb[i]) : 0u;
+        nfl[j] = (i < n && flags) ? CR_LOAD_STREAM(&flags[i]) : 0u;
     }
     for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
         uint32_t key[LH_ITEMS], rank[LH_ITEMS], cfl[LH_ITEMS];
@@ -578,8 +589,8 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)gridDim.x * chunk + (uint64_t)j * LH_THREADS + tid;
-            nkey[j] = i < n ? cb[i] : 0u;
-            nfl[j] = (i < n && flags) ? flags[i] : 0u;
+            nkey[j] = i < n ? CR_LOAD_STREAM(&cb[i]) : 0u;
+            nfl[j] = (i < n && flags) ? CR_LOAD_STREAM(&flags[i]) : 0u;
         }
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * LH_THREADS + tid;
-            if (i < n) idx_out[i] = rank[j];
+            if (i < n) CR_STORE_STREAM(rank[j], &idx_out[i]);
             if (rec_i) {
                 const bool miss = i < n && rank[j] == CRGPU_MISS;
                 const unsigned long long mm = __ballot(miss);
@@ -1031,7 +1042,8 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
     unsigned long long qlo, qhi;
     if (qualn) {
         if (len == 16) {
-            const uint4 q4 = *reinterpret_cast<const uint4 *>(qualn + i * 16);
+            const cr_u32x4 qv = CR_LOAD_STREAM(reinterpret_cast<const cr_u32x4 *>(qualn + i * 16));
+            const uint4 q4 = make_uint4(qv.x, qv.y, qv.z, qv.w);
             qlo = (unsigned long long)q4.x | ((unsigned long long)q4.y << 32);
             qhi = (unsigned long long)q4.z | ((unsigned long long)q4.w << 32);
         } else {
@@ -1130,7 +1142,7 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
         for (uint32_t k = 0; k < len; k++)
             expected += ptab[(uint32_t)((k < 8u ? qlo : qhi) >> (8u * (k & 7u))) & 0x7Fu];
     if (expected < max_expected && best_like / total >= thresh) {
-        idx_inout[i] = best_rank;
+        CR_STORE_STREAM(best_rank, &idx_inout[i]);
         if (corrected_out) corrected_out[i] = 1;
         atomicAdd(&w.corrected[best_rank], 1u);
     }
@@ -1161,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_correct_records(const WlViewSet vs, con
         const uint32_t cnt = rec_count[r];
         for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
             const uint64_t o = (uint64_t)r * rec_cap + p;
-            k2_correct_one<true>(vs, P, rec_i[o], rec_key[o], rec_fl[o]);
+            k2_correct_one<true>(vs, P, CR_LOAD_STREAM(&rec_i[o]), CR_LOAD_STREAM(&rec_key[o]), CR_LOAD_STREAM(&rec_fl[o]));
         }
     }
 }
