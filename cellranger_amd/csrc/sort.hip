@@ -26,6 +26,17 @@
 // per CU) the open lines (1024 x 256 x 128 B = 32 MB) do not survive in the 4 MB L2s between two chunks and
 // runs of 128 B go out as partial lines; with one large workgroup per CU the open set is 8 MB and the runs
 // are 512 B.  Measured at 400 M reads: 13.1 -> 10.9 ms per step going from 4 K to 8 K keys at 256 threads.
+// A/B switches for the scatter's key stream: -DSORT_NT_IN / -DSORT_NT_OUT use non-temporal loads / stores
+#ifdef SORT_NT_IN
+#define SORT_LOAD_IN(p) __builtin_nontemporal_load(p)
+#else
+#define SORT_LOAD_IN(p) (*(p))
+#endif
+#ifdef SORT_NT_OUT
+#define SORT_STORE_OUT(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define SORT_STORE_OUT(v, p) (*(p) = (v))
+#endif
 #ifndef SORT_BLOCK
 #define SORT_BLOCK 1024
 #endif
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         if (chunk_n == CHUNK) {
 #pragma unroll
             for (int it = 0; it < ITEMS; it++) {
-                key[it] = kin[it * 64];
+                key[it] = SORT_LOAD_IN(&kin[it * 64]);
                 if (HAS_VALS) val[it] = vin[it * 64];
             }
 #pragma unroll
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         for (uint32_t p = tid; p < chunk_n; p += SORT_BLOCK) {
             const K k = skeys[p];
             const uint32_t pos = p + gdelta[dig(k)];
-            keys_out[pos] = k;
+            SORT_STORE_OUT(k, &keys_out[pos]);
             if (HAS_VALS) vals_out[pos] = svals[p];
         }
         __syncthreads();
