@@ -20,7 +20,9 @@ FLAG_CB_HAS_N = 0x10
 FLAG_NONTXOMIC = 0x20
 
 COUNTS_VALID, COUNTS_CORRECTED, COUNTS_PRIOR = 0, 1, 2
-T_NAMES = ["pack", "match", "correct", "keys", "sort_scatter", "dedup", "matrix", "synth", "sort_hist", "scan"]
+T_NAMES = ["pack", "match", "correct", "keys", "sort_scatter", "dedup", "matrix", "synth", "sort_hist", "scan", "comm"]
+UNIQUE_ID_BYTES = 128
+OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS = 0
 
 
 class CrgpuError(RuntimeError):
@@ -121,7 +123,18 @@ class SynthOut(C.Structure):
 _vp, _u8p, _u32, _u64, _i, _dbl = C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
 SYMBOLS = {
     "crgpu_abi_version": (_i, []),
-    "crgpu_create": (_i, [C.POINTER(_vp), _i]),
+    "crgpu_get_unique_id": (_i, [_vp]),
+    "crgpu_local_group_id": (_i, [_u32, _vp]),
+    "crgpu_create": (_i, [C.POINTER(_vp), _i, _i, _i, _vp]),
+    "crgpu_comm_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
+    "crgpu_set_option": (_i, [_vp, _i, C.c_int64]),
+    "crgpu_invalidate": (_i, [_vp]),
+    "crgpu_barrier": (_i, [_vp]),
+    "crgpu_allreduce_counts": (_i, [_vp, _i, _i]),
+    "crgpu_exchange_keys_dev": (_i, [_vp, _vp, _u64, C.POINTER(_vp), C.POINTER(_u64), _vp]),
+    "crgpu_gatherv_dev": (_i, [_vp, _vp, _u64, _i, C.POINTER(_vp), _vp]),
+    "crgpu_gather_triplets_dev": (_i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64)]),
+    "crgpu_allreduce_max_f64": (_i, [_vp, C.POINTER(_dbl)]),
     "crgpu_destroy": (None, [_vp]),
     "crgpu_last_error": (C.c_char_p, [_vp]),
     "crgpu_synchronize": (_i, [_vp]),

@@ -65,7 +65,10 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("libcrgpu build failed")
     if procs or force or not os.path.exists(OUT):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        # librccl is linked directly (comm.hip: C1/C2/C3 over xGMI); torch ships a librccl.so.1 of its own, and whichever
+        # of the two a process loads first serves both
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + [
+            "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -48,7 +48,8 @@ __device__ __forceinline__ uint32_t base_code(uint32_t c, bool &is_n) {
 
 __global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
                                               uint64_t n, uint32_t len, uint32_t *__restrict__ packed,
-                                              uint8_t *__restrict__ qualn, uint8_t *__restrict__ flags) {
+                                              uint8_t *__restrict__ qualn, uint8_t *__restrict__ flags,
+                                              uint32_t *__restrict__ n_without_flags) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint32_t key = 0;
@@ -89,12 +90,14 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ seq, c
         }
         packed[i] = key;
         if (flags && any_n) flags[i] |= CRGPU_FLAG_CB_HAS_N;
+        if (!flags && any_n) atomicOr(n_without_flags, 1u);  // rare; remembered for a pass A that runs without flags
     }
 }
 
 extern "C" int crgpu_pack_dev(crgpu_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, uint64_t n, uint32_t len,
                               uint32_t *d_packed_out, uint8_t *d_qualn_out, uint8_t *d_flags_inout) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, len >= 1 && len <= 16, CRGPU_ERANGE, "sequence length %u unsupported (<= 16)", len);
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_seq && d_qual && d_packed_out && d_qualn_out, CRGPU_EINVAL, "crgpu_pack_dev: NULL buffer");
@@ -102,8 +105,9 @@ extern "C" int crgpu_pack_dev(crgpu_ctx *ctx, const uint8_t *d_seq, const uint8_
         CR_REQUIRE(ctx, ((uintptr_t)d_seq | (uintptr_t)d_qual | (uintptr_t)d_qualn_out) % 16 == 0, CRGPU_EINVAL,
                    "crgpu_pack_dev: 16-base buffers must be 16-byte aligned");
     CrTimer t(ctx, CRGPU_T_PACK, n);
+    cr_invalidate(ctx);
     hipLaunchKernelGGL(k_pack, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_seq, d_qual, n, len, d_packed_out,
-                       d_qualn_out, d_flags_inout);
+                       d_qualn_out, d_flags_inout, ctx->d_scalars + CR_SCALAR_N_WITHOUT_FLAGS);
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
 }
@@ -114,7 +118,7 @@ extern "C" int crgpu_pack_dev(crgpu_ctx *ctx, const uint8_t *d_seq, const uint8_
 __global__ __launch_bounds__(256) void k_pack_rows(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual, uint64_t n,
                                                    uint32_t row_stride, uint32_t offset, uint32_t len,
                                                    uint32_t *__restrict__ packed, uint8_t *__restrict__ qualn,
-                                                   uint8_t *__restrict__ flags) {
+                                                   uint8_t *__restrict__ flags, uint32_t *__restrict__ n_without_flags) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint8_t *s = seq + i * row_stride + offset, *q = qual + i * row_stride + offset;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256) void k_pack_rows(const uint8_t *__restrict__ s
         }
         packed[i] = key;
         if (flags && any_n) flags[i] |= CRGPU_FLAG_CB_HAS_N;
+        if (!flags && any_n) atomicOr(n_without_flags, 1u);
     }
 }
 
@@ -137,14 +142,16 @@ extern "C" int crgpu_pack_rows_dev(crgpu_ctx *ctx, const uint8_t *d_seq_rows, co
                                    uint32_t row_stride, uint32_t offset, uint32_t len, uint32_t *d_packed_out,
                                    uint8_t *d_qualn_out, uint8_t *d_flags_inout) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, len >= 1 && len <= 16, CRGPU_ERANGE, "sequence length %u unsupported (<= 16)", len);
     CR_REQUIRE(ctx, (uint64_t)offset + len <= row_stride, CRGPU_EINVAL, "crgpu_pack_rows_dev: bases [%u, %u) lie outside a row of %u bytes",
                offset, offset + len, row_stride);
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_seq_rows && d_qual_rows && d_packed_out && d_qualn_out, CRGPU_EINVAL, "crgpu_pack_rows_dev: NULL buffer");
     CrTimer t(ctx, CRGPU_T_PACK, n);
+    cr_invalidate(ctx);
     hipLaunchKernelGGL(k_pack_rows, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_seq_rows, d_qual_rows, n, row_stride, offset,
-                       len, d_packed_out, d_qualn_out, d_flags_inout);
+                       len, d_packed_out, d_qualn_out, d_flags_inout, ctx->d_scalars + CR_SCALAR_N_WITHOUT_FLAGS);
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
 }
@@ -799,10 +806,24 @@ __global__ __launch_bounds__(512) void k_hist_buckets(const WlViewSet vs, const 
 extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_flags, uint64_t n,
                                          uint32_t *d_idx_out) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_match_and_count: no whitelist set");
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_cb && d_idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
     cr_drop_miss_records(ctx);
+    if (!d_flags) {
+        // NULL flags mean "no barcode holds an N".  A pack call that ran without a flags array and met an N left a mark:
+        // such a barcode would be looked up with its N read as A and could count as a whitelist hit, which the
+        // reference's check_and_update never does (whitelist.rs:494-517)
+        uint32_t seen = 0;
+        CR_TRY(crgpu_memcpy_d2h(ctx, &seen, ctx->d_scalars + CR_SCALAR_N_WITHOUT_FLAGS, sizeof(seen)));
+        if (seen) {
+            CR_HIP(ctx, hipMemsetAsync(ctx->d_scalars + CR_SCALAR_N_WITHOUT_FLAGS, 0, sizeof(uint32_t), ctx->stream));
+            return cr_fail(ctx, CRGPU_EINVAL,
+                           "crgpu_match_and_count: barcodes containing N were packed without a flags array; pass flags to "
+                           "crgpu_pack*_dev and to this call (CRGPU_FLAG_CB_HAS_N)");
+        }
+    }
     int ulib = -1;
     CR_TRY(pick_uniform_lib(ctx, d_flags, n, &ulib));
     const bool uniform = ulib >= 0;
@@ -870,7 +891,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     }
     // miss records for K2: one region per wave of the lookup kernel (its grid is pinned to 256 workgroups)
     MissRecords &rec = ctx->rec;
-    if (use_hot && n < 0xFFFFFFFFull && !getenv("CRGPU_NO_MISS_RECORDS")) {
+    if (use_hot && ctx->trust_buffers && n < 0xFFFFFFFFull && !getenv("CRGPU_NO_MISS_RECORDS")) {
         const uint64_t H = n - first;
         const uint64_t launches = (H + sb - 1) / sb + 1;
         rec.regions = 256u * (LH_THREADS / 64);
@@ -1180,6 +1201,7 @@ __global__ __launch_bounds__(256) void k_correct_records(const WlViewSet vs, con
 
 extern "C" int crgpu_set_posterior(crgpu_ctx *ctx, double max_expected_barcode_errors, double bc_confidence_threshold) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     ctx->max_expected_errors = max_expected_barcode_errors;
     ctx->confidence_threshold = bc_confidence_threshold;
     return CRGPU_OK;
@@ -1249,6 +1271,8 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
 
 extern "C" int crgpu_correct_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_qualn, const uint8_t *d_flags,
                                  uint64_t n, uint32_t *d_idx_inout, uint8_t *d_corrected_out) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     return correct_dev_impl(ctx, d_cb, d_qualn, d_flags, n, d_idx_inout, d_corrected_out, false);
 }
 
@@ -1300,6 +1324,7 @@ static int stage_host_batch(crgpu_ctx *ctx, int lib, const uint8_t *seq, const u
 extern "C" int crgpu_match_and_count(crgpu_ctx *ctx, int lib, const uint8_t *seq, const uint8_t *qual, uint64_t n,
                                      uint32_t *idx_out) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_match_and_count: no whitelist set");
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, seq && idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
@@ -1314,6 +1339,7 @@ extern "C" int crgpu_match_and_count(crgpu_ctx *ctx, int lib, const uint8_t *seq
 extern "C" int crgpu_correct(crgpu_ctx *ctx, int lib, const uint8_t *seq, const uint8_t *qual, uint64_t n,
                              uint32_t *idx_inout, uint8_t *corrected_flag_out) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_correct: no whitelist set");
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, seq && idx_inout, CRGPU_EINVAL, "crgpu_correct: NULL buffer");

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -14,6 +15,8 @@
 #include "../../include/crgpu.h"
 
 #define CR_WAVE 64
+// words of the context's 4 KB scalar page with a fixed meaning (the other users take theirs by offset: 0, 8, 16, 28, 128, 760)
+#define CR_SCALAR_N_WITHOUT_FLAGS 40
 
 // --------------------------------------------------------------------------------------------
 // whitelist tables of one library type (device + host mirrors)
@@ -102,10 +105,16 @@ struct KeyHistograms {
     uint32_t *d_hist = nullptr;  // OS_MAX_PASSES x RADIX_MAX, pool block
 };
 
+struct CrComm;  // comm.hip: RCCL communicator or in-process group of this context (NULL: single GPU)
+
 struct crgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    std::recursive_mutex mu;  // every entry point holds it (CR_ENTER): calls of several host threads are serialised
+    int n_ranks = 1, rank = 0;
+    CrComm *comm = nullptr;
+    bool trust_buffers = false;  // CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS
 
     // canonical barcode space
     bool canon_set = false;
@@ -152,6 +161,30 @@ struct crgpu_ctx {
 };
 
 int cr_fail(crgpu_ctx *ctx, int code, const char *fmt, ...);
+
+// Scope of an entry point: locks the context and makes its device current (pool allocations, hipFuncSetAttribute and
+// launches act on the calling thread's current device, which need not be the context's when a host thread serves
+// several GPUs); the caller's device is restored on exit.
+struct CrEnter {
+    crgpu_ctx *c;
+    int prev = -1;
+    explicit CrEnter(crgpu_ctx *ctx) : c(ctx) {
+        c->mu.lock();
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) == hipSuccess) prev = cur;
+    }
+    ~CrEnter() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        c->mu.unlock();
+    }
+    CrEnter(const CrEnter &) = delete;
+    CrEnter &operator=(const CrEnter &) = delete;
+};
+#define CR_ENTER(ctx) CrEnter _cr_enter(ctx)
+// forget every by-product kept for the next call (K1's miss records, the key histograms)
+void cr_invalidate(crgpu_ctx *ctx);
+void cr_comm_destroy(crgpu_ctx *ctx);
+int cr_comm_init(crgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id);
 void cr_set_thread_error(const char *msg);
 
 #define CR_HIP(ctx, call)                                                                      \

@@ -29,9 +29,14 @@ extern "C" const char *crgpu_last_error(const crgpu_ctx *ctx) {
     return ctx ? ctx->err.c_str() : g_thread_err.c_str();
 }
 
-extern "C" int crgpu_create(crgpu_ctx **out, int device_id) {
+extern "C" int crgpu_create(crgpu_ctx **out, int device_id, int n_ranks, int rank, const void *unique_id) {
     if (!out) return cr_fail(nullptr, CRGPU_EINVAL, "crgpu_create: out is NULL");
     *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return cr_fail(nullptr, CRGPU_EINVAL, "crgpu_create: rank %d of %d ranks", rank, n_ranks);
+    if (n_ranks > 1 && !unique_id)
+        return cr_fail(nullptr, CRGPU_EINVAL, "crgpu_create: %d ranks need a unique_id (crgpu_get_unique_id / crgpu_local_group_id)",
+                       n_ranks);
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0)
@@ -72,7 +77,48 @@ extern "C" int crgpu_create(crgpu_ctx **out, int device_id) {
         crgpu_destroy(ctx);
         return cr_fail(nullptr, CRGPU_ENOMEM, "crgpu_create: device allocation failed");
     }
+    if (unique_id) {
+        // blocks until every rank has arrived; the message of a failure is kept for crgpu_last_error(NULL)
+        const int rc = cr_comm_init(ctx, n_ranks, rank, unique_id);
+        if (rc != CRGPU_OK) {
+            const std::string msg = ctx->err;
+            crgpu_destroy(ctx);
+            return cr_fail(nullptr, rc, "%s", msg.c_str());
+        }
+    }
     *out = ctx;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_comm_info(crgpu_ctx *ctx, uint32_t *n_ranks_out, uint32_t *rank_out) {
+    if (!ctx) return CRGPU_EINVAL;
+    if (n_ranks_out) *n_ranks_out = (uint32_t)ctx->n_ranks;
+    if (rank_out) *rank_out = (uint32_t)ctx->rank;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_set_option(crgpu_ctx *ctx, int option, int64_t value) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    switch (option) {
+        case CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS:
+            ctx->trust_buffers = value != 0;
+            cr_invalidate(ctx);
+            return CRGPU_OK;
+        default:
+            return cr_fail(ctx, CRGPU_EINVAL, "crgpu_set_option: unknown option %d", option);
+    }
+}
+
+void cr_invalidate(crgpu_ctx *ctx) {
+    cr_drop_miss_records(ctx);
+    ctx->ghist.valid = false;
+}
+
+extern "C" int crgpu_invalidate(crgpu_ctx *ctx) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    cr_invalidate(ctx);
     return CRGPU_OK;
 }
 
@@ -93,8 +139,11 @@ void cr_free_wl(WlTables &w) { free_wl(w); }
 
 extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
     if (!ctx) return;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    cr_comm_destroy(ctx);
     for (auto &w : ctx->wl) free_wl(w);
     for (auto &p : ctx->pat) {
         hipFree(p.d_seq);
@@ -115,10 +164,12 @@ extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
     for (auto ev : ctx->event_pool) hipEventDestroy(ev);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
 }
 
 extern "C" int crgpu_synchronize(crgpu_ctx *ctx) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CRGPU_OK;
 }
@@ -127,17 +178,20 @@ extern "C" void *crgpu_stream(crgpu_ctx *ctx) { return ctx ? (void *)ctx->stream
 
 extern "C" int crgpu_malloc(crgpu_ctx *ctx, void **d_out, uint64_t bytes) {
     if (!ctx || !d_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     return cr_pool_alloc(ctx, d_out, bytes);
 }
 
 extern "C" int crgpu_free(crgpu_ctx *ctx, void *d_ptr) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     cr_pool_free(ctx, d_ptr);
     return CRGPU_OK;
 }
 
 extern "C" int crgpu_trim(crgpu_ctx *ctx) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < ctx->pool.size();) {
         if (!ctx->pool[i].in_use) {
@@ -152,7 +206,9 @@ extern "C" int crgpu_trim(crgpu_ctx *ctx) {
 
 extern "C" int crgpu_memcpy_h2d(crgpu_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     if (!bytes) return CRGPU_OK;
+    cr_invalidate(ctx);  // the destination may be a buffer a kept by-product describes
     CR_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CRGPU_OK;
@@ -160,6 +216,7 @@ extern "C" int crgpu_memcpy_h2d(crgpu_ctx *ctx, void *d_dst, const void *h_src, 
 
 extern "C" int crgpu_memcpy_d2h(crgpu_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     if (!bytes) return CRGPU_OK;
     CR_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -168,7 +225,9 @@ extern "C" int crgpu_memcpy_d2h(crgpu_ctx *ctx, void *h_dst, const void *d_src, 
 
 extern "C" int crgpu_memset(crgpu_ctx *ctx, void *d_dst, int value, uint64_t bytes) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     if (!bytes) return CRGPU_OK;
+    cr_invalidate(ctx);
     CR_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
     return CRGPU_OK;
 }
@@ -302,6 +361,7 @@ static int drain_spans(crgpu_ctx *ctx) {
 
 extern "C" int crgpu_timing_enable(crgpu_ctx *ctx, int on) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_TRY(drain_spans(ctx));
     ctx->timing = on != 0;
     return CRGPU_OK;
@@ -309,6 +369,7 @@ extern "C" int crgpu_timing_enable(crgpu_ctx *ctx, int on) {
 
 extern "C" int crgpu_timing_reset(crgpu_ctx *ctx) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_TRY(drain_spans(ctx));
     for (int i = 0; i < CRGPU_T_NSLOTS; i++) {
         ctx->acc_ms[i] = 0;
@@ -320,6 +381,7 @@ extern "C" int crgpu_timing_reset(crgpu_ctx *ctx) {
 
 extern "C" int crgpu_timing_get(crgpu_ctx *ctx, double *ms_out, uint64_t *launches_out, uint64_t *units_out) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_TRY(drain_spans(ctx));
     for (int i = 0; i < CRGPU_T_NSLOTS; i++) {
         if (ms_out) ms_out[i] = ctx->acc_ms[i];

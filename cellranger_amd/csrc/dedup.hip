@@ -43,6 +43,7 @@ struct crgpu_counts {
 extern "C" int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_t umi_len, uint32_t n_libs,
                                     uint32_t multiplexing_lib_mask) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_set_key_layout: set the whitelist first");
     CR_REQUIRE(ctx, n_features >= 1, CRGPU_EINVAL, "n_features must be >= 1");
     CR_REQUIRE(ctx, umi_len >= 1 && umi_len <= 16, CRGPU_ERANGE, "umi_len must be 1..16");
@@ -204,7 +205,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         uint32_t widths[OS_MAX_PASSES];
         memset(&plan, 0, sizeof(plan));
         uint32_t *d_hist = nullptr;
-        if (!d_vals_out && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(0, ctx->layout.total_bits(), &plan, widths)) {
+        if (!d_vals_out && ctx->trust_buffers && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(0, ctx->layout.total_bits(), &plan, widths)) {
             if (!gh.d_hist) CR_TRY(cr_pool_alloc(ctx, (void **)&gh.d_hist, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t)));
             d_hist = gh.d_hist;
             CR_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t), ctx->stream));
@@ -241,14 +242,18 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
 
 extern "C" int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out,
                                     uint64_t *n_keys_out) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     return build_keys_impl(ctx, recs, d_keys_out, nullptr, n_keys_out);
 }
 
 extern "C" int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n, uint32_t n_ranks,
                                         const uint32_t *bounds, uint64_t *d_keys_out, uint64_t *counts_out) {
     if (!ctx || !counts_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_partition_keys: call crgpu_set_key_layout first");
     CR_REQUIRE(ctx, n == 0 || (d_keys && d_keys_out), CRGPU_EINVAL, "crgpu_partition_keys: NULL buffer");
+    cr_invalidate(ctx);
     return cr_partition_by_owner(ctx, d_keys, d_keys_out, n, ctx->layout.sh_bc(), n_ranks, bounds, counts_out);
 }
 
@@ -257,6 +262,7 @@ extern "C" int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, 
 // tables have been all-reduced so that every rank derives the same bounds).
 extern "C" int crgpu_balanced_bounds(crgpu_ctx *ctx, uint32_t n_ranks, uint32_t *bounds_out) {
     if (!ctx || !bounds_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_balanced_bounds: no whitelist set");
     CR_REQUIRE(ctx, n_ranks >= 1 && n_ranks <= 256, CRGPU_EINVAL, "crgpu_balanced_bounds: n_ranks must be 1..256");
     const uint32_t W = ctx->n_canon;
@@ -977,7 +983,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     uint32_t *upos = upos_b.as<uint32_t>();
     uint32_t nd32 = 0;
     {
-        CrTimer t(ctx, CRGPU_T_DEDUP);
+        CrTimer t(ctx, CRGPU_T_DEDUP, n_keys);  // the family's unit: one sorted key (counted here, once per call)
         CR_TRY(compact(ctx, HeadFlag{keys, 1u}, EmitRun{keys, ukey, upos}, n_keys, d_block, d_total));
     }
     CR_TRY(read_u32(ctx, d_total, &nd32));
@@ -1159,6 +1165,8 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
 }
 
 extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     PerRead pr;
     pr.summary = ctx->barcode_summary_on;
     return count_keys_impl(ctx, d_keys_inout, n_keys, out, pr);
@@ -1167,6 +1175,7 @@ extern "C" int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint
 extern "C" int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
                                        uint32_t *d_processed_umi_out, uint32_t *d_read_count_out, uint8_t *d_dupflags_out) {
     if (!ctx || !recs || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     *out = nullptr;
     CR_REQUIRE(ctx, recs->n <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_records: at most 2^31-1 records per call");
     const uint64_t n = recs->n;
@@ -1249,6 +1258,7 @@ struct MatrixDevImpl {
 extern "C" int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, const uint32_t *d_feature,
                                          const uint32_t *d_count, uint64_t n_triplets, crgpu_matrix_dev **out) {
     if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     *out = nullptr;
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_assemble_matrix_dev: no whitelist set");
     CR_REQUIRE(ctx, n_triplets == 0 || (d_bc && d_feature && d_count), CRGPU_EINVAL, "NULL triplets");
@@ -1301,7 +1311,8 @@ extern "C" int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, c
 }
 
 extern "C" void crgpu_matrix_dev_free(crgpu_ctx *ctx, crgpu_matrix_dev *mv) {
-    if (!mv) return;
+    if (!mv || !ctx) return;
+    CR_ENTER(ctx);
     MatrixDevImpl *m = reinterpret_cast<MatrixDevImpl *>(mv);  // view is the first member
     cr_pool_free(ctx, m->d_rank);
     cr_pool_free(ctx, m->d_indptr);
@@ -1313,6 +1324,7 @@ extern "C" void crgpu_matrix_dev_free(crgpu_ctx *ctx, crgpu_matrix_dev *mv) {
 extern "C" int crgpu_matrix_dev_download(crgpu_ctx *ctx, const crgpu_matrix_dev *mv, uint32_t *rank_out, int64_t *indptr_out,
                                          int32_t *indices_out, int32_t *data_out) {
     if (!ctx || !mv) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     if (rank_out) CR_TRY(crgpu_memcpy_d2h(ctx, rank_out, mv->d_barcode_rank, mv->n_barcodes * sizeof(uint32_t)));
     if (indptr_out) CR_TRY(crgpu_memcpy_d2h(ctx, indptr_out, mv->d_indptr, (mv->n_barcodes + 1) * sizeof(int64_t)));
     if (indices_out) CR_TRY(crgpu_memcpy_d2h(ctx, indices_out, mv->d_indices, mv->nnz * sizeof(int32_t)));
@@ -1322,6 +1334,7 @@ extern "C" int crgpu_matrix_dev_download(crgpu_ctx *ctx, const crgpu_matrix_dev 
 
 extern "C" int crgpu_counts_info(crgpu_ctx *ctx, const crgpu_counts *c, uint64_t *n_triplets, uint64_t *n_molecules) {
     if (!ctx || !c) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     if (n_triplets) *n_triplets = c->n_triplets;
     if (n_molecules) *n_molecules = c->n_molecules;
     return CRGPU_OK;
@@ -1330,6 +1343,7 @@ extern "C" int crgpu_counts_info(crgpu_ctx *ctx, const crgpu_counts *c, uint64_t
 extern "C" int crgpu_counts_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t **d_bc, uint32_t **d_feature,
                                          uint32_t **d_count) {
     if (!ctx || !c) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     if (d_bc) *d_bc = c->d_bc;
     if (d_feature) *d_feature = c->d_feature;
     if (d_count) *d_count = c->d_count;
@@ -1339,6 +1353,7 @@ extern "C" int crgpu_counts_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, 
 extern "C" int crgpu_counts_triplets(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint32_t *feature_out,
                                      uint32_t *count_out) {
     if (!ctx || !c) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     const uint64_t b = c->n_triplets * sizeof(uint32_t);
     if (bc_out) CR_TRY(crgpu_memcpy_d2h(ctx, bc_out, c->d_bc, b));
     if (feature_out) CR_TRY(crgpu_memcpy_d2h(ctx, feature_out, c->d_feature, b));
@@ -1350,6 +1365,7 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
                                       uint32_t *feature_out, uint32_t *umi_out, uint32_t *read_count_out,
                                       uint8_t *utype_out) {
     if (!ctx || !c) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     const uint64_t nm = c->n_molecules;
     if (!nm) return CRGPU_OK;
     std::vector<uint64_t> keys(nm);
@@ -1387,6 +1403,7 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
 
 extern "C" int crgpu_enable_barcode_summary(crgpu_ctx *ctx, int on) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     ctx->barcode_summary_on = on != 0;
     return CRGPU_OK;
 }
@@ -1449,7 +1466,8 @@ extern "C" int crgpu_counts_barcode_summary(crgpu_ctx *ctx, const crgpu_counts *
 }
 
 extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
-    if (!c) return;
+    if (!c || !ctx) return;
+    CR_ENTER(ctx);
     cr_pool_free(ctx, c->d_bc);
     cr_pool_free(ctx, c->d_feature);
     cr_pool_free(ctx, c->d_count);

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(THREADS) void k_match_features_lds(const PatView p,
 extern "C" int crgpu_set_feature_pattern(crgpu_ctx *ctx, int pattern, const char *feat_seqs, uint32_t n_feat, uint32_t len,
                                          const uint32_t *feat_index, const double *feat_dist) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, pattern >= 0 && pattern < CRGPU_MAX_LIB, CRGPU_EINVAL, "pattern id %d out of range", pattern);
     CR_REQUIRE(ctx, feat_seqs && feat_index && n_feat > 0, CRGPU_EINVAL, "empty feature pattern");
     CR_REQUIRE(ctx, len >= 1 && len <= 16, CRGPU_ERANGE, "feature barcode length %u unsupported (<= 16 bases)", len);
@@ -269,6 +270,7 @@ extern "C" int crgpu_set_feature_pattern(crgpu_ctx *ctx, int pattern, const char
 extern "C" int crgpu_match_features_dev(crgpu_ctx *ctx, int pattern, const uint32_t *d_seq, const uint8_t *d_qualn,
                                         uint64_t n, uint32_t *d_feature_out) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, pattern >= 0 && pattern < CRGPU_MAX_LIB && ctx->pat[pattern].set, CRGPU_ESTATE,
                "feature pattern %d not set", pattern);
     if (n == 0) return CRGPU_OK;

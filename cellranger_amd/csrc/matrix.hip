@@ -41,6 +41,7 @@ extern "C" int crgpu_counts_molecule_info(crgpu_ctx *ctx, const crgpu_counts *c,
                                           uint64_t *barcode_idx_out, uint32_t *feature_idx_out, uint16_t *library_idx_out,
                                           uint32_t *umi_out, uint32_t *count_out, uint32_t *umi_type_out) {
     if (!ctx || !c) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_counts_molecule_info: no whitelist set");
     uint64_t nt = 0, nm = 0;
     CR_TRY(crgpu_counts_info(ctx, c, &nt, &nm));
@@ -64,6 +65,7 @@ extern "C" int crgpu_counts_molecule_info(crgpu_ctx *ctx, const crgpu_counts *c,
 extern "C" int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const uint32_t *feature, const uint32_t *count,
                                      uint64_t n_triplets, uint32_t n_features, crgpu_matrix **out) {
     if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     *out = nullptr;
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_assemble_matrix: no whitelist set");
     CR_REQUIRE(ctx, n_triplets == 0 || (bc && feature && count), CRGPU_EINVAL, "crgpu_assemble_matrix: NULL triplets");
@@ -143,6 +145,7 @@ extern "C" int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const u
 extern "C" int crgpu_concat_matrices(crgpu_ctx *ctx, const crgpu_matrix *const *mats, const uint16_t *gem_groups,
                                      uint32_t n_mats, crgpu_matrix **out) {
     if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     *out = nullptr;
     CR_REQUIRE(ctx, n_mats >= 1 && mats && gem_groups, CRGPU_EINVAL, "crgpu_concat_matrices: nothing to merge");
     for (uint32_t i = 0; i < n_mats; i++) {
@@ -197,6 +200,7 @@ static void finish_view(MatrixImpl *m, uint32_t n_features, uint32_t cb_len) {
 // matrices of the same shape (same features, same barcodes in the same order) -- the element-wise sum, canonical CSC.
 extern "C" int crgpu_sum_matrices(crgpu_ctx *ctx, const crgpu_matrix *a, const crgpu_matrix *b, crgpu_matrix **out) {
     if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     *out = nullptr;
     CR_REQUIRE(ctx, a && b, CRGPU_EINVAL, "crgpu_sum_matrices: NULL matrix");
     CR_REQUIRE(ctx, a->n_features == b->n_features && a->n_barcodes == b->n_barcodes && a->cb_len == b->cb_len, CRGPU_EINVAL,
@@ -240,6 +244,7 @@ extern "C" int crgpu_sum_matrices(crgpu_ctx *ctx, const crgpu_matrix *a, const c
 extern "C" int crgpu_select_barcodes(crgpu_ctx *ctx, const crgpu_matrix *a, const uint64_t *cols, uint64_t n_cols,
                                      crgpu_matrix **out) {
     if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     *out = nullptr;
     CR_REQUIRE(ctx, a && (cols || n_cols == 0), CRGPU_EINVAL, "crgpu_select_barcodes: NULL argument");
     for (uint64_t k = 0; k < n_cols; k++)
@@ -270,6 +275,7 @@ extern "C" void crgpu_matrix_free(crgpu_ctx *, crgpu_matrix *mv) {
 extern "C" int crgpu_write_mtx(crgpu_ctx *ctx, const crgpu_matrix *m, const char *metadata_line, const char *mtx_path,
                                const char *barcodes_tsv_path, uint16_t gem_group) {
     if (!ctx || !m) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     if (mtx_path) {
         FILE *f = fopen(mtx_path, "wb");
         if (!f) return cr_fail(ctx, CRGPU_EINVAL, "cannot open %s", mtx_path);
@@ -299,6 +305,7 @@ extern "C" int crgpu_write_mtx(crgpu_ctx *ctx, const crgpu_matrix *m, const char
 
 extern "C" int crgpu_count(crgpu_ctx *ctx, const crgpu_records *recs, uint32_t n_features, crgpu_matrix **out) {
     if (!ctx || !recs || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     *out = nullptr;
     CR_REQUIRE(ctx, ctx->layout.set && ctx->layout.n_features == n_features, CRGPU_ESTATE,
                "crgpu_count: call crgpu_set_key_layout with the same n_features first");
@@ -327,6 +334,7 @@ extern "C" int crgpu_write_barcode_summary_csv(crgpu_ctx *ctx, const crgpu_barco
                                                uint16_t gem_group, const uint32_t *library_type_order,
                                                const char *const *library_type_name, uint32_t n_libs, const char *path) {
     if (!ctx || !path || (n_rows && !rows)) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_write_barcode_summary_csv: no whitelist set");
     CR_REQUIRE(ctx, library_type_order && library_type_name && n_libs >= 1 && n_libs <= CRGPU_MAX_LIB, CRGPU_EINVAL,
                "crgpu_write_barcode_summary_csv: library types missing");

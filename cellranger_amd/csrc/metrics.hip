@@ -100,6 +100,7 @@ extern "C" int crgpu_shard_metrics_dev(crgpu_ctx *ctx, const uint32_t *d_cb, con
                                        const uint32_t *d_umi, const uint8_t *d_umi_qualn, uint32_t umi_len,
                                        const uint32_t *d_idx, uint64_t n, crgpu_shard_metrics *out) {
     if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     memset(out, 0, sizeof(*out));
     static_assert(sizeof(crgpu_shard_metrics) == SM_FIELDS * sizeof(uint64_t), "field count");
     if (n == 0) return CRGPU_OK;

@@ -415,14 +415,14 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
     {
         // the auxiliary 32-bit sort of the low-support stage is booked under that stage: the SORT slots are
         // the 64-bit molecule-key sort alone (bench.py prices them at 8 / 16 bytes per key)
-        CrTimer t(ctx, sizeof(K) == 8 ? CRGPU_T_SORT_HIST : CRGPU_T_DEDUP, n);
+        CrTimer t(ctx, sizeof(K) == 8 ? CRGPU_T_SORT_HIST : CRGPU_T_DEDUP, sizeof(K) == 8 ? n : 0);
         hipLaunchKernelGGL((k_radix_hist<K, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
     }
     {
         CrTimer t(ctx, CRGPU_T_SCAN);
         hipLaunchKernelGGL(k_scan_digits, dim3(1u << BITS), dim3(256), 0, ctx->stream, d_hist, nb, d_tot);
     }
-    CrTimer t(ctx, sizeof(K) == 8 ? CRGPU_T_SORT : CRGPU_T_DEDUP, n);
+    CrTimer t(ctx, sizeof(K) == 8 ? CRGPU_T_SORT : CRGPU_T_DEDUP, sizeof(K) == 8 ? n : 0);  // DEDUP counts its keys once
     // more than 64 KB of LDS per workgroup has to be requested per kernel, once
     const size_t lds_kv = SortCfg<K, true>::lds_bytes(BITS), lds_k = SortCfg<K, false>::lds_bytes(BITS);
     if (d_vin) {

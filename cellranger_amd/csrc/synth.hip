@@ -50,8 +50,10 @@ static int to_dev(crgpu_ctx *ctx, const T *h, size_t n, const T **d_out, std::ve
 extern "C" int crgpu_synth_dev(crgpu_ctx *ctx, const crgpu_synth_params *p, uint64_t first, uint64_t n,
                                const crgpu_synth_out *d_out) {
     if (!ctx || !d_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_TRY(check_params(ctx, p));
     if (n == 0) return CRGPU_OK;
+    cr_invalidate(ctx);  // the output buffers may be ones a kept by-product describes
     crgpu_synth_params dp = *p;
     std::vector<void *> owned;
     int rc = CRGPU_OK;

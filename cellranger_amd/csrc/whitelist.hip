@@ -43,6 +43,7 @@ static int upload(crgpu_ctx *ctx, T **d, const std::vector<T> &h) {
 extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_t *keys, uint32_t n, uint32_t len,
                                           const uint32_t *canon, uint32_t n_canon, const uint32_t *translate_to) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, lib >= 0 && lib < CRGPU_MAX_LIB, CRGPU_EINVAL, "library id %d out of range", lib);
     CR_REQUIRE(ctx, keys && canon && n > 0 && n_canon > 0, CRGPU_EINVAL, "empty whitelist");
     CR_REQUIRE(ctx, len >= 1 && len <= 16, CRGPU_ERANGE,
@@ -163,6 +164,7 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
 extern "C" int crgpu_set_whitelist(crgpu_ctx *ctx, int lib, const char *keys, uint32_t n, uint32_t len,
                                    const char *canon, uint32_t n_canon, const uint32_t *translate_to) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, keys && canon, CRGPU_EINVAL, "NULL whitelist");
     CR_REQUIRE(ctx, len >= 1 && len <= 16, CRGPU_ERANGE,
                "barcode length %u unsupported: this engine packs barcodes of <= 16 bases in 32 bits", len);
@@ -174,6 +176,7 @@ extern "C" int crgpu_set_whitelist(crgpu_ctx *ctx, int lib, const char *keys, ui
 
 extern "C" int crgpu_whitelist_info(crgpu_ctx *ctx, uint32_t *n_canon_out, uint32_t *len_out) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "no whitelist set");
     if (n_canon_out) *n_canon_out = ctx->n_canon;
     if (len_out) *len_out = ctx->cb_len;
@@ -182,6 +185,7 @@ extern "C" int crgpu_whitelist_info(crgpu_ctx *ctx, uint32_t *n_canon_out, uint3
 
 extern "C" int crgpu_get_canon_order(crgpu_ctx *ctx, uint32_t *order_out, uint32_t *seqs_out) {
     if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "no whitelist set");
     if (order_out) memcpy(order_out, ctx->canon_order.data(), sizeof(uint32_t) * ctx->n_canon);
     if (seqs_out) memcpy(seqs_out, ctx->canon_sorted.data(), sizeof(uint32_t) * ctx->n_canon);
@@ -210,6 +214,7 @@ static int table_ptr(crgpu_ctx *ctx, int lib, int which, bool for_write, uint32_
 
 extern "C" int crgpu_get_counts(crgpu_ctx *ctx, int lib, int which, uint32_t *counts_out) {
     if (!ctx || !counts_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     uint32_t *d;
     CR_TRY(table_ptr(ctx, lib, which, false, &d));
     return crgpu_memcpy_d2h(ctx, counts_out, d, sizeof(uint32_t) * ctx->n_canon);
@@ -217,6 +222,7 @@ extern "C" int crgpu_get_counts(crgpu_ctx *ctx, int lib, int which, uint32_t *co
 
 extern "C" int crgpu_set_counts(crgpu_ctx *ctx, int lib, int which, const uint32_t *counts) {
     if (!ctx || !counts) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     uint32_t *d;
     CR_TRY(table_ptr(ctx, lib, which, true, &d));
     return crgpu_memcpy_h2d(ctx, d, counts, sizeof(uint32_t) * ctx->n_canon);
@@ -224,12 +230,14 @@ extern "C" int crgpu_set_counts(crgpu_ctx *ctx, int lib, int which, const uint32
 
 extern "C" int crgpu_counts_dev(crgpu_ctx *ctx, int lib, int which, uint32_t **d_out) {
     if (!ctx || !d_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
     return table_ptr(ctx, lib, which, which == CRGPU_COUNTS_PRIOR ? false : false, d_out);
 }
 
 extern "C" int crgpu_reset_counts(crgpu_ctx *ctx) {
     if (!ctx) return CRGPU_EINVAL;
-    cr_drop_miss_records(ctx);
+    CR_ENTER(ctx);
+    cr_invalidate(ctx);
     for (auto &w : ctx->wl)
         if (w.set) {
             CR_HIP(ctx, hipMemsetAsync(w.d_valid, 0, sizeof(uint32_t) * ctx->n_canon, ctx->stream));

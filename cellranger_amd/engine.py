@@ -51,13 +51,17 @@ def ascii_matrix(seqs, length=None):
 
 
 class DeviceArray:
-    """A device allocation owned through crgpu_malloc/crgpu_free."""
+    """A device allocation owned through crgpu_malloc/crgpu_free (or adopted from a library call that returns a
+    library-owned buffer to be released with crgpu_free: `adopt`)."""
 
-    def __init__(self, ctx, shape, dtype):
+    def __init__(self, ctx, shape, dtype, adopt=None):
         self.ctx = ctx
         self.shape = (shape,) if np.isscalar(shape) else tuple(shape)
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        if adopt is not None:
+            self.ptr = int(adopt)
+            return
         p = C.c_void_p()
         ctx._check(ctx.L.crgpu_malloc(ctx.h, C.byref(p), max(self.nbytes, 1)))
         self.ptr = p.value
@@ -248,19 +252,92 @@ class Counts:
             pass
 
 
-class Context:
-    """crgpu_ctx: one per (process, device)."""
+def get_unique_id():
+    """rendezvous token of an RCCL communicator (rank 0 makes it and ships the bytes to the other processes)"""
+    L = _lib.load()
+    buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+    rc = L.crgpu_get_unique_id(buf)
+    if rc != 0:
+        raise CrgpuError(rc, (L.crgpu_last_error(None) or b"").decode())
+    return buf.raw
 
-    def __init__(self, device=0):
+
+def local_group_id(n_ranks):
+    """rendezvous token for n_ranks contexts inside THIS process (one host thread each)"""
+    L = _lib.load()
+    buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+    rc = L.crgpu_local_group_id(n_ranks, buf)
+    if rc != 0:
+        raise CrgpuError(rc, (L.crgpu_last_error(None) or b"").decode())
+    return buf.raw
+
+
+class Context:
+    """crgpu_ctx: one per (process, device, rank).  n_ranks / rank / unique_id: see crgpu_create in crgpu.h."""
+
+    def __init__(self, device=0, n_ranks=1, rank=0, unique_id=None):
         self.L = _lib.load()
         h = C.c_void_p()
-        rc = self.L.crgpu_create(C.byref(h), device)
+        uid = None
+        if unique_id is not None:
+            assert len(unique_id) == _lib.UNIQUE_ID_BYTES
+            uid = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
+        rc = self.L.crgpu_create(C.byref(h), device, n_ranks, rank, uid)
         if rc != 0:
             raise CrgpuError(rc, (self.L.crgpu_last_error(None) or b"").decode())
         self.h = h
         self.device = device
+        self.n_ranks, self.rank = n_ranks, rank
         self.cb_len = None
         self.n_canon = None
+
+    # ---- options / collectives (crgpu.h "collectives") ---------------------------------------------
+    def set_option(self, option, value):
+        self._check(self.L.crgpu_set_option(self.h, option, int(value)))
+
+    def trust_unchanged_buffers(self, on=True):
+        """promise that buffers handed from one call to the next are only written through this context"""
+        self.set_option(_lib.OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS, 1 if on else 0)
+
+    def invalidate(self):
+        self._check(self.L.crgpu_invalidate(self.h))
+
+    def barrier(self):
+        self._check(self.L.crgpu_barrier(self.h))
+
+    def allreduce_counts(self, lib=-1, which=COUNTS_VALID):
+        self._check(self.L.crgpu_allreduce_counts(self.h, lib, which))
+
+    def allreduce_max(self, value):
+        v = C.c_double(float(value))
+        self._check(self.L.crgpu_allreduce_max_f64(self.h, C.byref(v)))
+        return v.value
+
+    def exchange_keys(self, d_keys, n_keys):
+        """C2: (DeviceArray of this rank's keys, n, bounds)"""
+        p, n = C.c_void_p(), C.c_uint64()
+        bounds = np.zeros(self.n_ranks + 1, np.uint32)
+        self._check(self.L.crgpu_exchange_keys_dev(self.h, _p(d_keys), n_keys, C.byref(p), C.byref(n), ptr(bounds)))
+        return DeviceArray(self, max(n.value, 1), np.uint64, adopt=p.value), n.value, bounds
+
+    def gatherv(self, d_src, nbytes, dtype, root=0):
+        """C3 for one array: (DeviceArray on root / None elsewhere, per-rank element counts on root)"""
+        p = C.c_void_p()
+        per = np.zeros(self.n_ranks, np.uint64)
+        self._check(self.L.crgpu_gatherv_dev(self.h, _p(d_src), nbytes, root, C.byref(p), ptr(per)))
+        if self.rank != root:
+            return None, None
+        item = np.dtype(dtype).itemsize
+        counts = [int(x) // item for x in per]
+        return DeviceArray(self, max(sum(counts), 1), dtype, adopt=p.value), counts
+
+    def gather_triplets(self, counts, root=0):
+        """C3: on root ((bc, feature, count) DeviceArrays, n_total), elsewhere (None, 0)"""
+        a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.L.crgpu_gather_triplets_dev(self.h, counts.h, root, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        if self.rank != root:
+            return None, 0
+        return tuple(DeviceArray(self, max(n.value, 1), np.uint32, adopt=x.value) for x in (a, b, c)), n.value
 
     def close(self):
         if getattr(self, "h", None):

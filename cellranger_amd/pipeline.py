@@ -1,16 +1,17 @@
 """Host orchestration of one GEM well across the GPUs of a node.
 
-One process per GPU.  Reads are sharded; the path has three real exchange steps, issued through
-torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests):
+One process per GPU (or one host thread per GPU inside a process).  Reads are sharded; the path has three real exchange
+steps, all of them entry points of libcrgpu (comm.hip: RCCL over xGMI, or the in-process group):
 
-  C1  all-reduce(sum) of the per-library valid-barcode histogram  -> the corrector's GLOBAL prior
-      (make_shard.rs:343-358 join -> barcode_correction.rs:295-325)
-  C2  all-to-all of 64-bit molecule keys by barcode range          -> every barcode's reads on one GPU
-      (the reference gets this from barcode-sorted shards + make_chunks, align_and_count.rs:505-524)
-  C3  gather of the disjoint (barcode, feature, count) triplets    -> rank 0 assembles the CSC matrix
+  C1  crgpu_allreduce_counts     all-reduce(sum) of the per-library valid-barcode histogram -> the corrector's GLOBAL
+                                 prior (make_shard.rs:343-358 join -> barcode_correction.rs:295-325)
+  C2  crgpu_exchange_keys_dev    all-to-all of 64-bit molecule keys by barcode range -> every barcode's reads on one GPU
+                                 (the reference: barcode-sorted shards + make_chunks, align_and_count.rs:505-524)
+  C3  crgpu_gather_triplets_dev  gather of the disjoint (barcode, feature, count) triplets -> rank 0 assembles the CSC
 
-The compute calls go through a backend object.  `HipBackend` is the product (libcrgpu via the C ABI,
-no CPU fallback).  The tests drive the same orchestration with an oracle-backed stand-in under gloo.
+`CountPipeline` is only the order of the calls; a Rust host makes the same calls.  The calls go through a
+backend object: `HipBackend` is the product (libcrgpu via the C ABI, no CPU fallback); the CPU tests drive the same
+sequence with an oracle-backed stand-in whose collectives are torch.distributed/gloo (tests/oracle_backend.py).
 """
 import numpy as np
 
@@ -19,7 +20,7 @@ from ._lib import COUNTS_CORRECTED, COUNTS_VALID
 
 
 class _DevView:
-    """Alias of a device allocation with a torch-friendly dtype (for collectives)."""
+    """Alias of a device allocation with a torch-friendly dtype."""
 
     def __init__(self, ptr, shape, typestr, owner=None):
         self.ptr, self.shape, self.typestr, self.owner = ptr, tuple(shape), typestr, owner
@@ -30,49 +31,40 @@ class _DevView:
 
 
 class HipBackend:
-    """Compute backend = libcrgpu on one MI355X.  Tensors handed to collectives alias device memory."""
+    """Compute + collectives backend = libcrgpu on one MI355X (the context carries rank / n_ranks / communicator)."""
 
     def __init__(self, ctx, device_index=0):
         self.ctx = ctx
         self.device_index = device_index
+        self.world, self.rank = ctx.n_ranks, ctx.rank
         self._keep = []
-
-    # -- helpers ------------------------------------------------------------------------------------
-    def _tensor(self, ptr, n, typestr):
-        import torch
-
-        if n == 0:
-            dt = {"<i4": torch.int32, "<i8": torch.int64}[typestr]
-            return torch.empty(0, dtype=dt, device="cuda:%d" % self.device_index)
-        return torch.as_tensor(_DevView(ptr, (n,), typestr), device="cuda:%d" % self.device_index)
-
-    def before_collective(self):
-        self.ctx.synchronize()
-
-    def after_collective(self):
-        import torch
-
-        torch.cuda.synchronize(self.device_index)
 
     # -- barcode stage --------------------------------------------------------------------------------
     def reset(self):
         self.ctx.reset_counts()
         self._keep = []
 
-    def libs(self):
-        return self._libs
-
-    def set_libs(self, libs):
-        self._libs = list(libs)
-
     def match_and_count(self, shard):
         self.ctx.match_and_count(shard["cb"], shard.get("flags"), shard["n"], shard["idx"])
 
-    def hist_tensor(self, lib, which):
-        return self._tensor(self.ctx.counts_dev(lib, which), self.ctx.n_canon, "<i4")
-
     def correct(self, shard):
         self.ctx.correct(shard["cb"], shard["cb_qualn"], shard.get("flags"), shard["n"], shard["idx"], shard.get("corrected"))
+
+    # -- collectives (crgpu.h "collectives") -------------------------------------------------------------
+    def allreduce_hist(self, libs, which):
+        for lib in libs:
+            self.ctx.allreduce_counts(lib, which)
+
+    def exchange_keys(self, keys, n_keys):
+        recv, n_recv, _ = self.ctx.exchange_keys(keys, n_keys)
+        self._keep.append(recv)
+        return recv, n_recv
+
+    def gather_triplets(self, counts):
+        arrs, total = self.ctx.gather_triplets(counts, root=0)
+        if arrs is not None:
+            self._keep.extend(arrs)
+        return arrs, total
 
     # -- count stage ------------------------------------------------------------------------------------
     def build_keys(self, shard):
@@ -85,22 +77,6 @@ class HipBackend:
         n_keys = self.ctx.build_keys(recs, keys)
         return keys, n_keys
 
-    def partition(self, keys, n_keys, n_ranks):
-        out = self.ctx.empty(max(n_keys, 1), np.uint64)
-        self._keep.append(out)
-        # read-balanced barcode ranges from the (already all-reduced) histograms: identical on every rank
-        bounds = self.ctx.balanced_bounds(n_ranks)
-        counts = self.ctx.partition_keys(keys, n_keys, n_ranks, out, bounds=bounds)
-        return out, [int(x) for x in counts]
-
-    def keys_tensor(self, keys, n_keys):
-        return self._tensor(keys.ptr, n_keys, "<i8")
-
-    def alloc_keys(self, n):
-        k = self.ctx.empty(max(n, 1), np.uint64)
-        self._keep.append(k)
-        return k
-
     def count_keys(self, keys, n_keys):
         counts = self.ctx.count_keys(keys, n_keys)
         self._keep.append(counts)
@@ -109,93 +85,65 @@ class HipBackend:
     def triplet_arrays(self, counts):
         return counts.triplets_dev()
 
-    def triplet_tensors(self, counts):
-        b, f, c = counts.triplets_dev()
-        n = counts.n_triplets
-        return self._tensor(b, n, "<i4"), self._tensor(f, n, "<i4"), self._tensor(c, n, "<i4")
-
-    def alloc_triplets(self, n):
-        arrs = [self.ctx.empty(max(n, 1), np.uint32) for _ in range(3)]
-        self._keep.extend(arrs)
-        return arrs, [self._tensor(a.ptr, n, "<i4") for a in arrs]
-
     def assemble(self, d_bc, d_feature, d_count, n_triplets):
         m = self.ctx.assemble_matrix_dev(d_bc, d_feature, d_count, n_triplets)
         self._keep.append(m)
         return m
 
-    def csc_tensors(self, m):
-        """(barcode rank [V], indptr [V+1] i64, indices [nnz], data [nnz]) of a device CSC as aliasing tensors"""
+    def _tensor(self, ptr, n, typestr):
+        import torch
+
+        if n == 0:
+            dt = {"<i4": torch.int32, "<i8": torch.int64}[typestr]
+            return torch.empty(0, dtype=dt, device="cuda:%d" % self.device_index)
+        return torch.as_tensor(_DevView(ptr, (n,), typestr), device="cuda:%d" % self.device_index)
+
+    def gather_wells(self, m):
+        """run_wells: the per-well CSC blocks of every rank on rank 0 (C3 on the four arrays), merged into one matrix:
+        dict of tensors (barcode_rank, gem_group, indptr, indices, data) on rank 0, None elsewhere."""
+        import torch
+
         v = m._mv.contents
-        return (self._tensor(v.d_barcode_rank, m.n_barcodes, "<i4"), self._tensor(v.d_indptr, m.n_barcodes + 1, "<i8"),
-                self._tensor(v.d_indices, m.nnz, "<i4"), self._tensor(v.d_data, m.nnz, "<i4"))
+        V, nnz = m.n_barcodes, m.nnz
+        ranks, Vs = self.ctx.gatherv(v.d_barcode_rank, V * 4, np.uint32)
+        ends, _ = self.ctx.gatherv(v.d_indptr + 8, V * 8, np.int64)  # column ends relative to the well's own block
+        indices, NZs = self.ctx.gatherv(v.d_indices, nnz * 4, np.int32)
+        data, _ = self.ctx.gatherv(v.d_data, nnz * 4, np.int32)
+        if self.rank != 0:
+            return None
+        self._keep.extend([ranks, ends, indices, data])
+        self.ctx.synchronize()
+        tV, tNZ = sum(Vs), sum(NZs)
+        dev = "cuda:%d" % self.device_index
+        ends_t = self._tensor(ends.ptr, tV, "<i8")
+        shift = torch.zeros(tV, dtype=torch.int64, device=dev)
+        gg = torch.zeros(tV, dtype=torch.int32, device=dev)
+        v0 = nz0 = 0
+        for r in range(self.world):
+            shift[v0:v0 + Vs[r]] = nz0
+            gg[v0:v0 + Vs[r]] = r + 1
+            v0 += Vs[r]
+            nz0 += NZs[r]
+        indptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), ends_t + shift])
+        return dict(barcode_rank=self._tensor(ranks.ptr, tV, "<i4"), gem_group=gg, indptr=indptr,
+                    indices=self._tensor(indices.ptr, tNZ, "<i4"), data=self._tensor(data.ptr, tNZ, "<i4"))
 
 
 class CountPipeline:
-    """barcode-correct -> UMI-dedup -> matrix for one shard of reads per rank."""
+    """barcode-correct -> UMI-dedup -> matrix for one shard of reads per rank: the order of the calls."""
 
-    def __init__(self, backend, libs=(0,), dist=None, force_collectives=False):
+    def __init__(self, backend, libs=(0,), force_collectives=False):
         self.be = backend
         self.libs = list(libs)
-        self.dist = dist  # torch.distributed module (initialised) or None for a single process
-        self.world = dist.get_world_size() if dist is not None else 1
-        self.rank = dist.get_rank() if dist is not None else 0
-        # exercise C1/C2/C3 even with one rank (tests: a 1-rank RCCL group on the single-GPU box)
-        self.collective = dist is not None and (self.world > 1 or force_collectives)
+        self.world, self.rank = backend.world, backend.rank
+        # exercise C1/C2/C3 even with one rank (tests: a 1-rank RCCL communicator on the single-GPU box)
+        self.collective = self.world > 1 or force_collectives
 
-    # -- collectives -------------------------------------------------------------------------------------
-    def _allreduce_hist(self, which):
-        if not self.collective:
-            return
-        self.be.before_collective()
-        for lib in self.libs:
-            t = self.be.hist_tensor(lib, which)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        self.be.after_collective()
-
-    def _all_to_all_keys(self, keys, n_keys):
-        """C2: returns (keys buffer, n) holding every key of the barcode range this rank owns."""
-        import torch
-
-        part, send_counts = self.be.partition(keys, n_keys, self.world)
-        self.be.before_collective()
-        dev = self.be.keys_tensor(part, n_keys).device
-        send_t = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-        recv_t = torch.empty(self.world, dtype=torch.int64, device=dev)
-        self.dist.all_to_all_single(recv_t, send_t)
-        recv_counts = [int(x) for x in recv_t.tolist()]
-        n_recv = sum(recv_counts)
-        recv = self.be.alloc_keys(n_recv)
-        self.dist.all_to_all_single(self.be.keys_tensor(recv, n_recv), self.be.keys_tensor(part, n_keys),
-                                    output_split_sizes=recv_counts, input_split_sizes=send_counts)
-        self.be.after_collective()
-        return recv, n_recv
-
-    def _gather_triplets(self, counts):
-        """C3: rank 0 receives every rank's triplets, concatenated in rank order (== barcode order)."""
-        import torch
-
-        tb, tf, tc = self.be.triplet_tensors(counts)
-        n = int(tb.numel())
-        self.be.before_collective()
-        sizes = torch.zeros(self.world, dtype=torch.int64, device=tb.device)
-        mine = torch.tensor([n], dtype=torch.int64, device=tb.device)
-        self.dist.all_gather_into_tensor(sizes, mine)
-        sizes = [int(x) for x in sizes.tolist()]
-        total = sum(sizes) if self.rank == 0 else 0
-        arrs, outs = self.be.alloc_triplets(total)
-        in_splits = [n] + [0] * (self.world - 1)
-        out_splits = sizes if self.rank == 0 else [0] * self.world
-        for src, dst in zip((tb, tf, tc), outs):
-            self.dist.all_to_all_single(dst, src, output_split_sizes=out_splits, input_split_sizes=in_splits)
-        self.be.after_collective()
-        return arrs, total
-
-    # -- the step ---------------------------------------------------------------------------------------
     def correct_barcodes(self, shard):
         """cfg2: pass A + C1 + pass B.  shard['idx'] receives the corrected barcode ranks."""
         self.be.match_and_count(shard)
-        self._allreduce_hist(COUNTS_VALID)
+        if self.collective:
+            self.be.allreduce_hist(self.libs, COUNTS_VALID)
         self.be.correct(shard)
 
     def run_wells(self, shard):
@@ -204,65 +152,27 @@ class CountPipeline:
         is the gather of the per-well CSC blocks.  Rank 0 returns the merged matrix as a dict of tensors
         (barcode_rank, gem_group, indptr, indices, data): column concatenation in (gem_group, barcode) order
         (barcode/src/lib.rs:119-124); other ranks return None."""
-        import torch
-
         self.be.match_and_count(shard)
         self.be.correct(shard)
         keys, n_keys = self.be.build_keys(shard)
         counts = self.be.count_keys(keys, n_keys)
         b, f, c = self.be.triplet_arrays(counts)
         m = self.be.assemble(b, f, c, counts.n_triplets)
-        rank_t, indptr_t, indices_t, data_t = self.be.csc_tensors(m)
-        dev = rank_t.device
-        if self.dist is None:
-            V = int(rank_t.numel())
-            return dict(barcode_rank=rank_t, gem_group=torch.ones(V, dtype=torch.int32, device=dev), indptr=indptr_t,
-                        indices=indices_t, data=data_t)
-        self.be.before_collective()
-        mine = torch.tensor([rank_t.numel(), indices_t.numel()], dtype=torch.int64, device=dev)
-        sizes = torch.zeros(2 * self.world, dtype=torch.int64, device=dev)
-        self.dist.all_gather_into_tensor(sizes, mine)
-        sizes = [int(x) for x in sizes.tolist()]
-        Vs, NZs = sizes[0::2], sizes[1::2]
-
-        def gather(src, per_rank, dtype):
-            n = int(src.numel())
-            total = sum(per_rank) if self.rank == 0 else 0
-            dst = torch.empty(total, dtype=dtype, device=dev)
-            self.dist.all_to_all_single(dst, src.contiguous(), output_split_sizes=per_rank if self.rank == 0 else [0] * self.world,
-                                        input_split_sizes=[n] + [0] * (self.world - 1))
-            return dst
-
-        ranks = gather(rank_t, Vs, torch.int32)
-        ends = gather(indptr_t[1:], Vs, torch.int64)  # column ends relative to the well's own block
-        indices = gather(indices_t, NZs, torch.int32)
-        data = gather(data_t, NZs, torch.int32)
-        self.be.after_collective()
-        if self.rank != 0:
-            return None
-        shift = torch.zeros(sum(Vs), dtype=torch.int64, device=dev)
-        gg = torch.zeros(sum(Vs), dtype=torch.int32, device=dev)
-        v0 = nz0 = 0
-        for r in range(self.world):
-            shift[v0:v0 + Vs[r]] = nz0
-            gg[v0:v0 + Vs[r]] = r + 1
-            v0 += Vs[r]
-            nz0 += NZs[r]
-        indptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), ends + shift])
-        return dict(barcode_rank=ranks, gem_group=gg, indptr=indptr, indices=indices, data=data)
+        return self.be.gather_wells(m)
 
     def run(self, shard):
         """Full path.  Returns the device CSC on rank 0 (None elsewhere)."""
         self.correct_barcodes(shard)
-        self._allreduce_hist(COUNTS_CORRECTED)   # matrix columns = barcodes seen on ANY rank
+        if self.collective:
+            self.be.allreduce_hist(self.libs, COUNTS_CORRECTED)   # matrix columns = barcodes seen on ANY rank
         keys, n_keys = self.be.build_keys(shard)
         if self.collective:
-            keys, n_keys = self._all_to_all_keys(keys, n_keys)
+            keys, n_keys = self.be.exchange_keys(keys, n_keys)
         counts = self.be.count_keys(keys, n_keys)
         if not self.collective:
             b, f, c = self.be.triplet_arrays(counts)
             return self.be.assemble(b, f, c, counts.n_triplets)
-        arrs, total = self._gather_triplets(counts)
+        arrs, total = self.be.gather_triplets(counts)
         if self.rank != 0:
             return None
         return self.be.assemble(arrs[0], arrs[1], arrs[2], total)

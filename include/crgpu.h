@@ -29,7 +29,18 @@
  *     (exercised with 2.5 G reads in one call), the count stage (crgpu_build_keys_dev, crgpu_count_keys_dev,
  *     crgpu_count_records_dev, crgpu_partition_keys_dev) up to 2^31 - 1 records / keys per call (exercised with 1 G);
  *     larger inputs are CRGPU_ERANGE, never truncated.
- *   - one context per (process, device).  Calls on one context must be serialised by the caller.
+ *   - one context per (process, device, rank).  Every entry point that takes a context locks it (a recursive mutex)
+ *     and makes the context's device current for the duration of the call (restoring the caller's device afterwards),
+ *     so a context may be shared by several host threads -- ALIGN_AND_COUNT's four workers per chunk
+ *     (cr_lib/src/stages/align_and_count.rs:698-732) -- whose calls are then executed one at a time in arrival order on
+ *     the context's one stream.  Objects a call returns (crgpu_counts, crgpu_matrix*) belong to the thread that
+ *     asked for them until it frees them.
+ *   - the library keeps by-products of one call for the next one (K1's miss records for K2, the sort's digit histograms
+ *     counted while the keys were built).  They are only used when the caller has promised, with
+ *     crgpu_set_option(ctx, CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS, 1), that the buffers it hands from one call to the
+ *     next are not written in between by anything but crgpu_* calls on this context (which drop the by-products
+ *     themselves); the default is 0 and every call then works from the buffers alone.  crgpu_invalidate drops them
+ *     explicitly (after a write the library cannot see: a torch copy, an RCCL receive issued by the host).
  */
 #ifndef CRGPU_H
 #define CRGPU_H
@@ -41,7 +52,7 @@
 extern "C" {
 #endif
 
-#define CRGPU_ABI_VERSION 1
+#define CRGPU_ABI_VERSION 2
 #define CRGPU_MAX_LIB 16
 #define CRGPU_MISS 0xFFFFFFFFu
 #define CRGPU_NO_FEATURE 0xFFFFFFFFu
@@ -54,6 +65,7 @@ extern "C" {
 #define CRGPU_ENOMEM (-4)   /* host or device allocation failed */
 #define CRGPU_ESTATE (-5)   /* call sequence error (e.g. whitelist not set) */
 #define CRGPU_ERANGE (-6)   /* value does not fit the engine's key layout */
+#define CRGPU_ECOMM (-7)    /* a collective failed (RCCL error, a rank of an in-process group went away) */
 
 /* per-read flag byte */
 #define CRGPU_FLAG_LIB_MASK 0x0Fu   /* bits 0..3: library-type id */
@@ -64,8 +76,23 @@ typedef struct crgpu_ctx crgpu_ctx;
 
 /* ---- context ------------------------------------------------------------------------------ */
 int crgpu_abi_version(void);
-int crgpu_create(crgpu_ctx **out, int device_id);
+/* The signature of SURVEY.md 8(b).  n_ranks / rank: this context's place among the GPUs that share ONE GEM well (reads
+ * sharded over the ranks); unique_id (CRGPU_UNIQUE_ID_BYTES bytes, the same on every rank): the rendezvous
+ * token, from crgpu_get_unique_id (one process per GPU, RCCL over xGMI: rank 0 makes it and ships the bytes to the other
+ * processes by whatever channel the host has -- a file, MPI, the Martian stage args) or from crgpu_local_group_id
+ * (several contexts inside one process, one host thread each).  n_ranks == 1 with unique_id == NULL: a single GPU, no
+ * communicator (the collective entry points below are then no-ops / plain copies).  With n_ranks > 1 the call blocks
+ * until every rank has arrived (ncclCommInitRank). */
+#define CRGPU_UNIQUE_ID_BYTES 128
+int crgpu_get_unique_id(void *id_out);
+int crgpu_local_group_id(uint32_t n_ranks, void *id_out);
+int crgpu_create(crgpu_ctx **out, int device_id, int n_ranks, int rank, const void *unique_id);
 void crgpu_destroy(crgpu_ctx *ctx);
+int crgpu_comm_info(crgpu_ctx *ctx, uint32_t *n_ranks_out, uint32_t *rank_out);
+/* options (see the conventions above) */
+#define CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS 0
+int crgpu_set_option(crgpu_ctx *ctx, int option, int64_t value);
+int crgpu_invalidate(crgpu_ctx *ctx);
 /* ctx may be NULL: returns the message of the last failed crgpu_create on this thread. */
 const char *crgpu_last_error(const crgpu_ctx *ctx);
 int crgpu_synchronize(crgpu_ctx *ctx);
@@ -94,7 +121,8 @@ int crgpu_memset(crgpu_ctx *ctx, void *d_dst, int value, uint64_t bytes);
 #define CRGPU_T_SYNTH 7       /* synthetic data generation */
 #define CRGPU_T_SORT_HIST 8   /* radix sort: digit histogram kernel (one span per pass) */
 #define CRGPU_T_SCAN 9        /* small scans of block histograms / block counts */
-#define CRGPU_T_NSLOTS 10
+#define CRGPU_T_COMM 10       /* collectives (C1 all-reduce, C2 key exchange, C3 gather) incl. their waiting time */
+#define CRGPU_T_NSLOTS 11
 int crgpu_timing_enable(crgpu_ctx *ctx, int on);
 int crgpu_timing_reset(crgpu_ctx *ctx);
 /* ms_out / launches_out / units_out [CRGPU_T_NSLOTS] (any may be NULL); synchronises.  units = the
@@ -193,6 +221,32 @@ int crgpu_reset_counts(crgpu_ctx *ctx);
 /* device pointer of the table, for collectives issued by the host (RCCL all-reduce of the prior) */
 int crgpu_counts_dev(crgpu_ctx *ctx, int lib, int which, uint32_t **d_out);
 
+/* ---- collectives between the ranks of one GEM well ---------------------------------------------------
+ * All of them are collective calls: every rank of the communicator must make the same call in the same order.  They run
+ * on the context's stream (RCCL) and return when the result is usable by the next crgpu call.
+ *
+ * C1  crgpu_allreduce_counts: element-wise sum over the ranks of one histogram table, in place -- the corrector's prior
+ *     must be the GLOBAL valid-barcode histogram before pass B (the make_shard join, make_shard.rs:343-358, feeding
+ *     barcode_correction.rs:295-325), and the matrix columns are the barcodes seen on ANY rank (barcode_correction.rs:
+ *     401-407).  lib < 0: every library that has a whitelist.  which: CRGPU_COUNTS_VALID or CRGPU_COUNTS_CORRECTED.
+ * C2  crgpu_exchange_keys_dev: all-to-all of the molecule keys by contiguous barcode-rank range so that every barcode's
+ *     reads meet on one GPU (what the reference gets from barcode-sorted shards + make_chunks, align_and_count.rs:505-524).
+ *     The ranges are read-balanced from the all-reduced VALID + CORRECTED tables (crgpu_balanced_bounds: identical on
+ *     every rank).  *d_recv_out: library-owned buffer with this rank's keys (free it with crgpu_free), *n_recv_out keys,
+ *     ordered by source rank; bounds_out (nullable, n_ranks + 1 entries): the ranges used.  d_keys is left unchanged.
+ * C3  crgpu_gatherv_dev: concatenation in rank order of every rank's device array on `root` (the disjoint triplet /
+ *     CSC blocks of the ranks).  *d_out (root only, else NULL): library-owned, crgpu_free; bytes_out (nullable,
+ *     n_ranks entries, root only): bytes received from each rank.
+ *     crgpu_gather_triplets_dev: the three triplet arrays of a crgpu_counts; rank order == barcode order because the
+ *     ranges of C2 are contiguous, so root can hand the result straight to crgpu_assemble_matrix_dev. */
+int crgpu_barrier(crgpu_ctx *ctx);
+int crgpu_allreduce_counts(crgpu_ctx *ctx, int lib, int which);
+int crgpu_exchange_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n_keys, uint64_t **d_recv_out,
+                            uint64_t *n_recv_out, uint32_t *bounds_out);
+int crgpu_gatherv_dev(crgpu_ctx *ctx, const void *d_src, uint64_t bytes, int root, void **d_out, uint64_t *bytes_out);
+/* max over the ranks of a host double (bench timing) */
+int crgpu_allreduce_max_f64(crgpu_ctx *ctx, double *value_inout);
+
 /* ---- host-buffer convenience: the signatures of SURVEY.md 8(b) ------------------------------------
  * seq/qual are n x len ASCII host arrays exactly as the Rust host holds them (RnaRead raw barcode
  * and quality); the library id applies to the whole batch.  These upload, pack, run K1 / K2 and
@@ -257,6 +311,10 @@ int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys
 int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
                             uint32_t *d_processed_umi_out, uint32_t *d_read_count_out, uint8_t *d_dupflags_out);
 int crgpu_counts_info(crgpu_ctx *ctx, const crgpu_counts *c, uint64_t *n_triplets, uint64_t *n_molecules);
+/* C3 (see "collectives"): root receives every rank's triplets concatenated in rank order; the three arrays are
+ * library-owned (crgpu_free each); on the other ranks they come back NULL with *n_total_out = 0. */
+int crgpu_gather_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, int root, uint32_t **d_bc_out,
+                              uint32_t **d_feature_out, uint32_t **d_count_out, uint64_t *n_total_out);
 /* device views (valid until crgpu_counts_free): bc rank u32[nt], feature u32[nt], count u32[nt] */
 int crgpu_counts_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t **d_bc, uint32_t **d_feature,
                               uint32_t **d_count);

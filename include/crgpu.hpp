@@ -34,8 +34,10 @@ class Error : public std::runtime_error {
 
 class Context {
    public:
-    explicit Context(int device_id = 0) {
-        const int rc = crgpu_create(&h_, device_id);
+    // one GPU: Context(device); one rank of a multi-GPU well: Context(device, n_ranks, rank, id) with the id of
+    // crgpu_get_unique_id (processes) or crgpu_local_group_id (threads of this process)
+    explicit Context(int device_id = 0, int n_ranks = 1, int rank = 0, const void *unique_id = nullptr) {
+        const int rc = crgpu_create(&h_, device_id, n_ranks, rank, unique_id);
         if (rc != CRGPU_OK) throw Error(rc, crgpu_last_error(nullptr));
     }
     ~Context() { crgpu_destroy(h_); }

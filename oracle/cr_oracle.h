@@ -188,6 +188,8 @@ void oracle_matrix_free(oracle_matrix *m);
 
 /* write_matrix_mtx body (write_matrix_market.rs:96-118) without the %metadata_json line's
  * version text (caller passes the full second line).  Returns bytes written or <0. */
+/* wall-clock seconds of the spans of the last barcode / count stage call (pipeline.c: g_timing), 8 doubles */
+void oracle_get_timing(double *out8);
 int64_t oracle_write_mtx(const oracle_matrix *m, uint32_t n_features, const char *metadata_line,
                          const char *path);
 

@@ -29,6 +29,19 @@
 
 #define MAX_LIB 16
 
+/* wall-clock spans of the last oracle_barcode_stage / oracle_count_stage call (bench.py's cpu_baseline reports the
+ * stages separately): 0 pass A, 1 histogram join, 2 pass B, 3 corrected-histogram join, 4 barcode index + bringing the
+ * valid reads into barcode order (the reference gets that order from shardio's sorted shards, outside its hot path),
+ * 5 per-barcode dedup + counting, 6 matrix assembly */
+static double g_timing[8];
+#include <time.h>
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void oracle_get_timing(double *out8) { memcpy(out8, g_timing, sizeof(g_timing)); }
+
 static int clamp_threads(int n_threads) {
     if (n_threads < 1) n_threads = 1;
 #ifndef _OPENMP
@@ -46,9 +59,10 @@ int oracle_barcode_stage(const oracle_reads *reads, const oracle_whitelist *cons
     n_threads = clamp_threads(n_threads);
 
     /* pass A: exact whitelist check (make_shard) */
-    oracle_hist *tl_valid[64][MAX_LIB];
-    memset(tl_valid, 0, sizeof(tl_valid));
-    if (n_threads > 64) n_threads = 64;
+    typedef oracle_hist *hist_row[MAX_LIB];
+    hist_row *tl_valid = (hist_row *)calloc((size_t)n_threads, sizeof(hist_row));
+    hist_row *tl_corr = (hist_row *)calloc((size_t)n_threads, sizeof(hist_row));
+    double t0 = now_s();
 #pragma omp parallel num_threads(n_threads)
     {
 #ifdef _OPENMP
@@ -71,6 +85,8 @@ int oracle_barcode_stage(const oracle_reads *reads, const oracle_whitelist *cons
             }
         }
     }
+    g_timing[0] = now_s() - t0;
+    t0 = now_s();
     /* make_shard join: Metric::merge of the per-chunk histograms (make_shard.rs:343-358) */
     for (int t = 0; t < n_threads; t++)
         for (int lib = 0; lib < MAX_LIB; lib++)
@@ -85,9 +101,9 @@ int oracle_barcode_stage(const oracle_reads *reads, const oracle_whitelist *cons
                 oracle_hist_free(tl_valid[t][lib]);
             }
 
+    g_timing[1] = now_s() - t0;
+    t0 = now_s();
     /* pass B: posterior correction of the invalid reads with the GLOBAL prior */
-    oracle_hist *tl_corr[64][MAX_LIB];
-    memset(tl_corr, 0, sizeof(tl_corr));
 #pragma omp parallel num_threads(n_threads)
     {
 #ifdef _OPENMP
@@ -112,6 +128,8 @@ int oracle_barcode_stage(const oracle_reads *reads, const oracle_whitelist *cons
             }
         }
     }
+    g_timing[2] = now_s() - t0;
+    t0 = now_s();
     for (int t = 0; t < n_threads; t++)
         for (int lib = 0; lib < MAX_LIB; lib++)
             if (tl_corr[t][lib]) {
@@ -125,6 +143,9 @@ int oracle_barcode_stage(const oracle_reads *reads, const oracle_whitelist *cons
                 free(cnt);
                 oracle_hist_free(tl_corr[t][lib]);
             }
+    g_timing[3] = now_s() - t0;
+    free(tl_valid);
+    free(tl_corr);
     return 0;
 }
 
@@ -196,7 +217,10 @@ static void process_barcode(const oracle_reads *reads, const bcref *refs, uint64
     oracle_dupinfo *di = (oracle_dupinfo *)malloc(sizeof(oracle_dupinfo) * (m + 1));
     oracle_umicount *uc = (oracle_umicount *)malloc(sizeof(oracle_umicount) * (m + 1));
 
+    uint32_t libs_present = 0;
+    for (uint64_t j = 0; j < m; j++) libs_present |= 1u << (reads->lib ? reads->lib[refs[j].idx] : 0);
     for (int lib = 0; lib < MAX_LIB; lib++) {
+        if (!((libs_present >> lib) & 1u)) continue;
         uint64_t k = 0;
         for (uint64_t j = 0; j < m; j++) {
             uint64_t i = refs[j].idx;
@@ -261,6 +285,7 @@ oracle_matrix *oracle_count_stage(const oracle_reads *reads, const oracle_bc_res
     const uint32_t L = reads->cb_len;
     n_threads = clamp_threads(n_threads);
     if (dup_out) memset(dup_out, 0, sizeof(oracle_dupinfo) * n);
+    double t0 = now_s();
 
     /* BarcodeIndex: sorted, dedup'd union of the barcodes in corrected_barcode_counts
      * (= raw valid counts merged with corrected counts, barcode_correction.rs:401-407) */
@@ -288,16 +313,61 @@ oracle_matrix *oracle_count_stage(const oracle_reads *reads, const oracle_bc_res
     for (uint64_t k = 0; k < nc; k++)
         if (k == 0 || cols[k] != cols[k - 1]) cols[V++] = cols[k];
 
-    /* shardio barcode order: only valid barcodes reach counting (align_and_count.rs:312) */
+    /* shardio barcode order: only valid barcodes reach counting (align_and_count.rs:312).  The reference reads its
+     * records already sorted by barcode; here the order is made by a bucket partition on the leading bases (per-thread
+     * counts, one scatter) and a qsort per bucket on the worker threads -- the total order (barcode, read index) makes
+     * the result independent of the thread count. */
     bcref *refs = (bcref *)malloc(sizeof(bcref) * (n + 1));
     uint64_t nv = 0;
-    for (uint64_t i = 0; i < n; i++)
-        if (bc->bc_state[i]) {
-            refs[nv].key = encode_bc(bc->corrected_cb + i * L, L);
-            refs[nv].idx = i;
-            nv++;
+    {
+        const uint32_t key_bits = 2 * L, bbits = key_bits < 12 ? key_bits : 12, nbk = 1u << bbits;
+        const int T = n_threads;
+        uint64_t *cnt = (uint64_t *)calloc((size_t)T * nbk + 1, sizeof(uint64_t));
+        uint64_t *bstart = (uint64_t *)calloc((size_t)nbk + 1, sizeof(uint64_t));
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num();
+#else
+            const int t = 0;
+#endif
+            const uint64_t lo = n * (uint64_t)t / (uint64_t)T, hi = n * (uint64_t)(t + 1) / (uint64_t)T;
+            uint64_t *c = cnt + (size_t)t * nbk;
+            for (uint64_t i = lo; i < hi; i++)
+                if (bc->bc_state[i]) c[encode_bc(bc->corrected_cb + i * L, L) >> (key_bits - bbits)]++;
         }
-    qsort(refs, nv, sizeof(bcref), cmp_bcref);
+        for (uint32_t b = 0; b < nbk; b++) { /* bucket-major, thread-minor exclusive prefix */
+            bstart[b] = nv;
+            for (int t = 0; t < T; t++) {
+                const uint64_t c = cnt[(size_t)t * nbk + b];
+                cnt[(size_t)t * nbk + b] = nv;
+                nv += c;
+            }
+        }
+        bstart[nbk] = nv;
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num();
+#else
+            const int t = 0;
+#endif
+            const uint64_t lo = n * (uint64_t)t / (uint64_t)T, hi = n * (uint64_t)(t + 1) / (uint64_t)T;
+            uint64_t *c = cnt + (size_t)t * nbk;
+            for (uint64_t i = lo; i < hi; i++)
+                if (bc->bc_state[i]) {
+                    const uint64_t key = encode_bc(bc->corrected_cb + i * L, L);
+                    const uint64_t o = c[key >> (key_bits - bbits)]++;
+                    refs[o].key = key;
+                    refs[o].idx = i;
+                }
+        }
+#pragma omp parallel for schedule(dynamic, 8) num_threads(T)
+        for (int64_t b = 0; b < (int64_t)nbk; b++)
+            qsort(refs + bstart[b], bstart[b + 1] - bstart[b], sizeof(bcref), cmp_bcref);
+        free(cnt);
+        free(bstart);
+    }
 
     /* group boundaries */
     uint64_t *gstart = (uint64_t *)malloc(sizeof(uint64_t) * (nv + 2));
@@ -307,11 +377,15 @@ oracle_matrix *oracle_count_stage(const oracle_reads *reads, const oracle_bc_res
     gstart[ng] = nv;
 
     group_result *res = (group_result *)calloc(ng + 1, sizeof(group_result));
+    g_timing[4] = now_s() - t0;
+    t0 = now_s();
     /* par_proc.rs:106-164: groups fanned out to worker threads */
 #pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
     for (int64_t g = 0; g < (int64_t)ng; g++)
         process_barcode(reads, refs + gstart[g], gstart[g + 1] - gstart[g], multiplexing_lib_mask, dup_out, &res[g]);
 
+    g_timing[5] = now_s() - t0;
+    t0 = now_s();
     oracle_matrix *M = (oracle_matrix *)calloc(1, sizeof(oracle_matrix));
     M->n_barcodes = V;
     M->cb_len = L;
@@ -372,6 +446,7 @@ oracle_matrix *oracle_count_stage(const oracle_reads *reads, const oracle_bc_res
     free(gstart);
     free(refs);
     free(cols);
+    g_timing[6] = now_s() - t0;
     return M;
 }
 

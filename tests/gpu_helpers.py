@@ -14,12 +14,18 @@ def ctx():
     """One context per test process (contexts are cheap but the GPU box allows few processes)."""
     global _ctx
     if _ctx is None:
-        _ctx = E.Context(0)
+        _ctx = fresh_ctx()
     return _ctx
 
 
-def fresh_ctx():
-    return E.Context(0)
+def fresh_ctx(trust=True):
+    """trust: CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS -- the tests write their buffers only through the context, so
+    the by-product paths (K1's miss records for K2, the key histograms for the sort) are what most of them exercise;
+    tests/test_gpu_barcode.py covers the default (off) and the invalidation rules."""
+    c = E.Context(0)
+    if trust:
+        c.trust_unchanged_buffers(True)
+    return c
 
 
 def oracle_reads_from_packed(r, cb_len, umi_len):

@@ -1,6 +1,7 @@
 """Test-only stand-in for cellranger_amd.pipeline.HipBackend: the same backend protocol implemented
-with numpy + the C oracle, so that the multi-rank orchestration of CountPipeline (C1 all-reduce, C2
-all-to-all by barcode range, C3 gather) can be exercised under gloo on CPUs.
+with numpy + the C oracle, its collectives (C1 all-reduce, C2 all-to-all by barcode range, C3 gather) with
+torch.distributed/gloo, so that the multi-rank call sequence of CountPipeline can be exercised on CPUs and its
+result compared with the single-process oracle.  The product's collectives are libcrgpu's (comm.hip).
 
 TEST INFRASTRUCTURE: lives in tests/, never imported by the cellranger_amd package."""
 import numpy as np
@@ -25,7 +26,10 @@ class _Matrix:
 
 
 class OracleBackend:
-    def __init__(self, wl_packed, cb_len, n_features, umi_len, n_libs=1, mux_mask=0):
+    def __init__(self, wl_packed, cb_len, n_features, umi_len, n_libs=1, mux_mask=0, dist=None):
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
         self.cb_len, self.umi_len, self.n_features, self.n_libs, self.mux_mask = cb_len, umi_len, n_features, n_libs, mux_mask
         self.canon_sorted = np.sort(np.asarray(wl_packed, dtype=np.uint32))
         self.canon_ascii = E.unpack_seqs(self.canon_sorted, cb_len)
@@ -52,11 +56,53 @@ class OracleBackend:
         self.hist = {COUNTS_VALID: [np.zeros(self.n_canon, np.int32) for _ in range(self.n_libs)],
                      COUNTS_CORRECTED: [np.zeros(self.n_canon, np.int32) for _ in range(self.n_libs)]}
 
-    def before_collective(self):
-        pass
+    # -- collectives: the semantics of crgpu_allreduce_counts / crgpu_exchange_keys_dev / crgpu_gather_triplets_dev ----
+    def allreduce_hist(self, libs, which):
+        for lib in libs:
+            self.dist.all_reduce(torch.from_numpy(self.hist[which][lib]), op=self.dist.ReduceOp.SUM)
 
-    def after_collective(self):
-        pass
+    def exchange_keys(self, keys, n_keys):
+        part, send_counts = self.partition(keys, n_keys, self.world)
+        send_t = torch.tensor(send_counts, dtype=torch.int64)
+        recv_t = torch.empty(self.world, dtype=torch.int64)
+        self.dist.all_to_all_single(recv_t, send_t)
+        recv_counts = [int(x) for x in recv_t.tolist()]
+        recv = np.zeros(sum(recv_counts), np.uint64)
+        self.dist.all_to_all_single(torch.from_numpy(recv.view(np.int64)), torch.from_numpy(part[:n_keys].view(np.int64)),
+                                    output_split_sizes=recv_counts, input_split_sizes=send_counts)
+        return recv, len(recv)
+
+    def _gatherv(self, arr):
+        """rank 0: (concatenation in rank order, per-rank sizes); others: (None, None)"""
+        src = torch.from_numpy(np.ascontiguousarray(arr))
+        n = int(src.numel())
+        sizes = torch.zeros(self.world, dtype=torch.int64)
+        self.dist.all_gather_into_tensor(sizes, torch.tensor([n], dtype=torch.int64))
+        sizes = [int(x) for x in sizes.tolist()]
+        total = sum(sizes) if self.rank == 0 else 0
+        dst = torch.empty(total, dtype=src.dtype)
+        self.dist.all_to_all_single(dst, src, output_split_sizes=sizes if self.rank == 0 else [0] * self.world,
+                                    input_split_sizes=[n] + [0] * (self.world - 1))
+        return (dst.numpy(), sizes) if self.rank == 0 else (None, None)
+
+    def gather_triplets(self, counts):
+        outs = [self._gatherv(a.view(np.int32))[0] for a in (counts.bc, counts.ft, counts.ct)]
+        if self.rank != 0:
+            return None, 0
+        return [o.view(np.uint32) for o in outs], len(outs[0])
+
+    def gather_wells(self, m):
+        ranks, Vs = self._gatherv(m.barcode_rank.view(np.int32))
+        ends, _ = self._gatherv(m.indptr[1:].astype(np.int64))
+        indices, NZs = self._gatherv(m.indices.astype(np.int32))
+        data, _ = self._gatherv(m.data.astype(np.int32))
+        if self.rank != 0:
+            return None
+        shift = np.repeat(np.concatenate([[0], np.cumsum(NZs)[:-1]]), Vs).astype(np.int64)
+        gg = np.repeat(np.arange(1, self.world + 1), Vs).astype(np.int32)
+        indptr = np.concatenate([[0], ends + shift]).astype(np.int64)
+        return dict(barcode_rank=torch.from_numpy(ranks), gem_group=torch.from_numpy(gg), indptr=torch.from_numpy(indptr),
+                    indices=torch.from_numpy(indices), data=torch.from_numpy(data))
 
     def match_and_count(self, shard):
         pk = shard["cb"]
@@ -67,9 +113,6 @@ class OracleBackend:
         lib = shard["flags"] & 0x0F
         for l in range(self.n_libs):
             np.add.at(self.hist[COUNTS_VALID][l], pos[hit & (lib == l)], 1)
-
-    def hist_tensor(self, lib, which):
-        return torch.from_numpy(self.hist[which][lib])
 
     def correct(self, shard):
         seq, qual = S.to_ascii(shard["cb"], shard["cb_qualn"], self.cb_len)
@@ -123,12 +166,6 @@ class OracleBackend:
         order = np.argsort(owner, kind="stable")
         return np.ascontiguousarray(keys[:n_keys][order]), [int((owner == r).sum()) for r in range(n_ranks)]
 
-    def keys_tensor(self, keys, n_keys):
-        return torch.from_numpy(keys[:n_keys].view(np.int64))
-
-    def alloc_keys(self, n):
-        return np.zeros(n, np.uint64)
-
     def count_keys(self, keys, n_keys):
         k = keys[:n_keys]
         bc = (k >> np.uint64(self.sh_bc)).astype(np.uint32)
@@ -162,17 +199,6 @@ class OracleBackend:
 
     def triplet_arrays(self, counts):
         return counts.bc, counts.ft, counts.ct
-
-    def triplet_tensors(self, counts):
-        return tuple(torch.from_numpy(a.view(np.int32)) for a in (counts.bc, counts.ft, counts.ct))
-
-    def alloc_triplets(self, n):
-        arrs = [np.zeros(n, np.uint32) for _ in range(3)]
-        return arrs, [torch.from_numpy(a.view(np.int32)) for a in arrs]
-
-    def csc_tensors(self, m):
-        return (torch.from_numpy(m.barcode_rank.view(np.int32)), torch.from_numpy(m.indptr.astype(np.int64)),
-                torch.from_numpy(m.indices.astype(np.int32)), torch.from_numpy(m.data.astype(np.int32)))
 
     def assemble(self, bc, ft, ct, n_triplets):
         seen = np.zeros(self.n_canon, bool)

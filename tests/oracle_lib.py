@@ -265,6 +265,18 @@ class PipelineResult:
     pass
 
 
+TIMING_NAMES = ["pass_a", "hist_join", "pass_b", "corrected_join", "barcode_order", "dedup", "assembly"]
+
+
+def last_timing():
+    """wall-clock seconds of the stages of the last run_pipeline call (oracle_get_timing)"""
+    t = (C.c_double * 8)()
+    f = lib().oracle_get_timing
+    f.restype, f.argtypes = None, [C.POINTER(C.c_double)]
+    f(t)
+    return {k: float(t[i]) for i, k in enumerate(TIMING_NAMES)}
+
+
 def run_pipeline(reads, whitelists, n_lib=1, multiplexing_lib_mask=0, n_threads=1,
                  max_expected_errors=DBL_MAX, threshold=0.975, count=True, want_dupinfo=False):
     """reads: dict with cb (n,L) u8, cb_qual (n,L) u8, optional umi/umi_qual/feature/lib/utype.

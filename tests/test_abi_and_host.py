@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and the Python binding table covers exactly the header
     assert sorted(_lib.SYMBOLS) == declared
-    assert _lib.load().crgpu_abi_version() == 1
+    assert _lib.load().crgpu_abi_version() == 2
 
 
 def test_create_fails_loudly_without_gpu():
@@ -113,3 +113,23 @@ def test_oracle_parallel_equals_serial():
     # sanity of the restated semantics on this data set
     assert (a.bc_state == 2).sum() > 500 and a.dupinfo["is_corrected"].sum() > 100
     assert a.data.sum() == len(a.mol) and a.indptr[-1] == len(a.data)
+
+
+def test_bench_launcher_starts_its_own_ranks_and_refuses_a_world_mismatch():
+    """`bench.py --gpus N` without torchrun must start N rank processes itself and fail when a rank fails (here: no GPU),
+    and must refuse a WORLD_SIZE that differs from --gpus instead of silently measuring one GPU."""
+    import subprocess
+    import sys
+
+    import torch
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 2 and "--gpus 2 but WORLD_SIZE=4" in r.stderr
+    if torch.cuda.device_count() > 0:
+        return  # on a GPU box the launcher is exercised for real by tests/test_gpu_pipeline.py
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads-per-gpu", "1000"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "ranks failed" in r.stderr  # the first rank to die ends the other one, too

@@ -1,6 +1,7 @@
-"""N>1 path on CPUs: CountPipeline's collectives (C1 all-reduce of the prior, C2 all-to-all of molecule
+"""N>1 path on CPUs: CountPipeline's call sequence (C1 all-reduce of the prior, C2 all-to-all of molecule
 keys by barcode range, C3 gather of triplets) under gloo with world_size 2, 3 and 8 (the size of the scaling run), driven through the
-oracle-backed stand-in backend; the assembled matrix must equal the single-process oracle's."""
+oracle-backed stand-in backend (whose collectives restate libcrgpu's with torch.distributed); the assembled matrix must equal
+the single-process oracle's.  The product's own collectives (comm.hip) need a GPU: tests/test_gpu_pipeline.py."""
 import os
 import socket
 import sys
@@ -40,8 +41,8 @@ def _worker(rank, world, port, n, seed, out_path):
         r = w.host_reads(rank * per, per)
         shard = dict(n=per, umi_len=w.umi_len, cb=r["cb"], cb_qualn=r["cb_qualn"], flags=r["flags"],
                      idx=np.zeros(per, np.uint32), umi=r["umi"], umi_qualn=r["umi_qualn"], feature=r["feature"])
-        be = OracleBackend(w.wl_packed, w.cb_len, w.n_genes, w.umi_len, n_libs=2, mux_mask=0b10)
-        pipe = CountPipeline(be, libs=(0, 1), dist=dist)
+        be = OracleBackend(w.wl_packed, w.cb_len, w.n_genes, w.umi_len, n_libs=2, mux_mask=0b10, dist=dist)
+        pipe = CountPipeline(be, libs=(0, 1))
         for _ in range(2):  # a second step must reset cleanly
             be.reset()
             m = pipe.run(shard)
@@ -96,8 +97,8 @@ def _wells_worker(rank, world, port, n, out_path):
         r = _well_reads(rank, n)
         shard = dict(n=n, umi_len=6, cb=r["cb"], cb_qualn=r["cb_qualn"], flags=r["flags"], idx=np.zeros(n, np.uint32),
                      umi=r["umi"], umi_qualn=r["umi_qualn"], feature=r["feature"])
-        be = OracleBackend(w.wl_packed, 16, 25, 6)
-        m = CountPipeline(be, dist=dist).run_wells(shard)
+        be = OracleBackend(w.wl_packed, 16, 25, 6, dist=dist)
+        m = CountPipeline(be).run_wells(shard)
         if rank == 0:
             np.savez(out_path, **{k: v.numpy() for k, v in m.items()})
         else:

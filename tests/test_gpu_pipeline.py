@@ -1,9 +1,6 @@
-"""GPU tests of the host orchestration with the product backend (HipBackend -> libcrgpu): the plain
-single-GPU path, and the collective path (C1/C2/C3) on a 1-rank RCCL group, which exercises the
-device-memory aliasing, dtype views and split-size plumbing the 8-GPU run uses."""
-import os
-import socket
-
+"""GPU tests of the call sequence with the product backend (HipBackend -> libcrgpu): the plain single-GPU path, the
+collective path (C1/C2/C3 = comm.hip) on a 1-rank RCCL communicator, and on 3 and 4 thread-ranks joined by the in-process
+group (the same orchestration code the 8-GPU RCCL run uses; only the transport differs)."""
 import numpy as np
 import pytest
 
@@ -55,153 +52,80 @@ def test_pipeline_single_gpu_device_csc():
     c.close()
 
 
-def test_pipeline_collective_path_on_one_rank_rccl_group():
-    import torch
-    import torch.distributed as dist
-
+def test_pipeline_collective_path_on_one_rank_rccl_communicator():
+    """C1/C2/C3 through libcrgpu's own RCCL communicator (crgpu_create with a unique id, one rank): ncclAllReduce,
+    the count exchange, grouped ncclSend/ncclRecv to self and the gather run for real."""
     import gpu_helpers as G
+    from cellranger_amd import engine as E
     from cellranger_amd import synth as S
     from cellranger_amd.pipeline import CountPipeline, HipBackend
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        n = 200_000
-        w = S.Workload(n_total=n, seed=42, n_wl=60_000, n_cells=150, n_ambient=5000, n_genes=500)
-        c = G.fresh_ctx()
-        c.set_whitelist(0, w.wl_packed, length=16)
-        c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
-        r = w.host_reads(0, n)
-        shard = _make_shard(c, w, r, n)
-        be = HipBackend(c, 0)
-        pipe = CountPipeline(be, dist=dist, force_collectives=True)
-        for _ in range(2):
-            be.reset()
-            m = pipe.run(shard)
-        _check_against_oracle(c, w, r, m)
-        # one-well-per-rank mode (BASELINE configs[4]): the CSC gather on the 1-rank group returns the same matrix
+    n = 200_000
+    w = S.Workload(n_total=n, seed=42, n_wl=60_000, n_cells=150, n_ambient=5000, n_genes=500)
+    c = E.Context(0, n_ranks=1, rank=0, unique_id=E.get_unique_id())
+    c.set_whitelist(0, w.wl_packed, length=16)
+    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+    r = w.host_reads(0, n)
+    shard = _make_shard(c, w, r, n)
+    be = HipBackend(c, 0)
+    pipe = CountPipeline(be, force_collectives=True)
+    for _ in range(2):
         be.reset()
-        merged = pipe.run_wells(shard)
-        rank, indptr, indices, data = m.download()
-        assert np.array_equal(merged["barcode_rank"].cpu().numpy().view(np.uint32), rank)
-        assert np.array_equal(merged["indptr"].cpu().numpy(), indptr)
-        assert np.array_equal(merged["indices"].cpu().numpy(), indices) and np.array_equal(merged["data"].cpu().numpy(), data)
-        assert (merged["gem_group"].cpu().numpy() == 1).all()
-        c.close()
-    finally:
-        dist.destroy_process_group()
+        m = pipe.run(shard)
+    _check_against_oracle(c, w, r, m)
+    # one-well-per-rank mode (BASELINE configs[4]): the CSC gather on the 1-rank communicator returns the same matrix
+    be.reset()
+    merged = pipe.run_wells(shard)
+    rank, indptr, indices, data = m.download()
+    assert np.array_equal(merged["barcode_rank"].cpu().numpy().view(np.uint32), rank)
+    assert np.array_equal(merged["indptr"].cpu().numpy(), indptr)
+    assert np.array_equal(merged["indices"].cpu().numpy(), indices) and np.array_equal(merged["data"].cpu().numpy(), data)
+    assert (merged["gem_group"].cpu().numpy() == 1).all()
+    assert c.allreduce_max(3.5) == 3.5
+    c.barrier()
+    c.close()
 
 
-class _Hub:
-    """In-process stand-in for a process group: the ranks are threads, the collectives copy between the ranks'
-    device tensors (all on the one GPU of the test box).  Everything except RCCL itself is the product path."""
-
-    def __init__(self, world):
-        import threading
-
-        self.world = world
-        self.barrier = threading.Barrier(world)
-        self.slots = [None] * world
-
-
-class _ThreadDist:
-    class ReduceOp:
-        SUM = "sum"
-
-    def __init__(self, hub, rank):
-        self.hub, self.rank = hub, rank
-
-    def get_world_size(self):
-        return self.hub.world
-
-    def get_rank(self):
-        return self.rank
-
-    def _post(self, x):
-        self.hub.slots[self.rank] = x
-        self.hub.barrier.wait()
-        got = list(self.hub.slots)
-        return got
-
-    def all_reduce(self, t, op=None):
-        import torch
-
-        got = self._post(t)
-        total = torch.stack([g.clone() for g in got]).sum(0)
-        self.hub.barrier.wait()  # everybody has read the inputs
-        t.copy_(total)
-        torch.cuda.synchronize()
-        self.hub.barrier.wait()
-
-    def all_gather_into_tensor(self, out, inp):
-        import torch
-
-        got = self._post(inp)
-        out.copy_(torch.cat([g.reshape(-1) for g in got]))
-        torch.cuda.synchronize()
-        self.hub.barrier.wait()
-
-    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
-        import torch
-
-        W = self.hub.world
-        if input_split_sizes is None:
-            input_split_sizes = [inp.numel() // W] * W
-        if output_split_sizes is None:
-            output_split_sizes = [out.numel() // W] * W
-        got = self._post((inp, list(input_split_sizes)))
-        o = 0
-        for src in range(W):
-            s_inp, s_splits = got[src]
-            a = sum(s_splits[: self.rank])
-            n = s_splits[self.rank]
-            assert n == output_split_sizes[src]
-            if n:
-                out[o:o + n].copy_(s_inp[a:a + n])
-            o += n
-        torch.cuda.synchronize()
-        self.hub.barrier.wait()
-
-
-def test_three_virtual_ranks_share_one_gpu():
-    """The multi-rank orchestration with the PRODUCT backend on real device memory: three ranks as threads with their
-    own contexts, streams and pools; C1 all-reduce, C2 all-to-all over histogram-balanced barcode ranges, C3 gather;
-    the matrix on rank 0 equals the single-process oracle on all reads."""
+@pytest.mark.parametrize("world", [3, 4])
+def test_thread_ranks_share_one_gpu_through_the_local_group(world):
+    """The multi-rank path end to end inside libcrgpu: `world` ranks as host threads with their own contexts, streams and
+    pools, joined by crgpu_local_group_id (the transport a one-process, thread-per-GPU host uses; here all ranks sit on
+    the one GPU of the test box).  C1 all-reduce, C2 exchange over histogram-balanced barcode ranges (partition, count
+    exchange, offsets, ordering), C3 gather are the code the RCCL transport runs under, too; the matrix on rank 0 equals
+    the single-process oracle on all reads."""
     import threading
 
     import gpu_helpers as G
+    from cellranger_amd import engine as E
     from cellranger_amd import synth as S
     from cellranger_amd.pipeline import CountPipeline, HipBackend
 
-    world, per = 3, 120_000
+    per = 120_000
     n = world * per
     w = S.Workload(n_total=n, seed=43, n_wl=60_000, n_cells=150, n_ambient=5000, n_genes=500)
     r_all = w.host_reads(0, n)
-    hub = _Hub(world)
+    gid = E.local_group_id(world)
     results, errors = [None] * world, []
 
     def worker(rank):
+        c = None
         try:
-            c = G.fresh_ctx()
+            c = E.Context(0, n_ranks=world, rank=rank, unique_id=gid)
             c.set_whitelist(0, w.wl_packed, length=16)
             c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
             r = {k: v[rank * per:(rank + 1) * per] for k, v in r_all.items()}
             shard = _make_shard(c, w, r, per)
             be = HipBackend(c, 0)
-            pipe = CountPipeline(be, dist=_ThreadDist(hub, rank))
+            pipe = CountPipeline(be)
             for _ in range(2):
                 be.reset()
                 m = pipe.run(shard)
+            assert c.allreduce_max(float(rank)) == float(world - 1)
             results[rank] = (c, m)
-        except Exception as e:  # noqa: BLE001 - surfaced below; a dead rank must not leave the others at a barrier
+        except Exception as e:  # noqa: BLE001 - surfaced below; closing the context breaks the group, so the others fail instead of waiting
             errors.append(e)
-            hub.barrier.abort()
+            if c is not None:
+                c.close()
 
     threads = [threading.Thread(target=worker, args=(k,)) for k in range(world)]
     for t in threads:
@@ -209,8 +133,40 @@ def test_three_virtual_ranks_share_one_gpu():
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors
-    assert results[1][1] is None and results[2][1] is None
+    assert all(results[k][1] is None for k in range(1, world))
     c0, m0 = results[0]
     _check_against_oracle(c0, w, r_all, m0)
     for c, _ in results:
         c.close()
+
+
+def test_a_rank_that_leaves_breaks_the_local_group_instead_of_hanging_it():
+    import threading
+
+    from cellranger_amd import engine as E
+    from cellranger_amd._lib import CrgpuError
+
+    gid = E.local_group_id(2)
+    out = {}
+
+    def stay():
+        c = E.Context(0, n_ranks=2, rank=0, unique_id=gid)
+        try:
+            c.barrier()          # both arrive
+            c.barrier()          # the other rank has left
+            out["second"] = "returned"
+        except CrgpuError as e:
+            out["second"] = e.code
+        c.close()
+
+    def leave():
+        c = E.Context(0, n_ranks=2, rank=1, unique_id=gid)
+        c.barrier()
+        c.close()
+
+    ts = [threading.Thread(target=stay), threading.Thread(target=leave)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert out["second"] == -7  # CRGPU_ECOMM
