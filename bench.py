@@ -323,7 +323,9 @@ def main():
         value = n_total * args.steps / dt / 1e6
         # dominant kernel family by device time (HIP events on the context's stream, the library's own ledger);
         # algorithmic bytes of the timed launches / their summed durations == per-launch bytes / average launch duration
-        fam = {k: v for k, v in ledger.items() if k in KERNEL_BYTES and v[1] > 0 and v[2] > 0}
+        # (a family that ran for less than 0.1 ms per step is bookkeeping -- e.g. the scan of the digit histograms that
+        # k_build_keys already counted -- not a candidate)
+        fam = {k: v for k, v in ledger.items() if k in KERNEL_BYTES and v[1] > 0 and v[2] > 0 and v[0] / args.steps >= 0.1}
         roof = None
         if fam:
             name = max(fam, key=lambda k: fam[k][0])

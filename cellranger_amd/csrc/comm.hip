@@ -354,6 +354,7 @@ extern "C" int crgpu_exchange_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, u
     *n_recv_out = 0;
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_exchange_keys: call crgpu_set_key_layout first");
     CR_REQUIRE(ctx, n_keys == 0 || d_keys, CRGPU_EINVAL, "crgpu_exchange_keys: NULL keys");
+    cr_invalidate(ctx);
     const int W = ctx->n_ranks;
     std::vector<uint32_t> bounds(W + 1);
     CR_TRY(crgpu_balanced_bounds(ctx, (uint32_t)W, bounds.data()));
@@ -403,6 +404,7 @@ extern "C" int crgpu_gatherv_dev(crgpu_ctx *ctx, const void *d_src, uint64_t byt
     const int W = ctx->n_ranks;
     CR_REQUIRE(ctx, root >= 0 && root < W, CRGPU_EINVAL, "crgpu_gatherv: root %d of %d ranks", root, W);
     CR_REQUIRE(ctx, bytes == 0 || d_src, CRGPU_EINVAL, "crgpu_gatherv: NULL source");
+    cr_invalidate(ctx);
     CrTimer t(ctx, CRGPU_T_COMM, bytes);
     std::vector<uint64_t> all(W);
     CR_TRY(comm_allgather_u64(ctx, &bytes, 1, all.data()));

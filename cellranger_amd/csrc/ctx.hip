@@ -185,6 +185,7 @@ extern "C" int crgpu_malloc(crgpu_ctx *ctx, void **d_out, uint64_t bytes) {
 extern "C" int crgpu_free(crgpu_ctx *ctx, void *d_ptr) {
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
+    cr_invalidate(ctx);  // a by-product must not outlive the buffer it describes (the pool hands the address out again)
     cr_pool_free(ctx, d_ptr);
     return CRGPU_OK;
 }

@@ -318,3 +318,80 @@ def test_one_library_per_call_in_a_three_library_well(monkeypatch, hot):
     ia, ib, cr, _ = G.gpu_barcode_stage(c, r, n)
     assert np.array_equal(ia, exp_a) and np.array_equal(ib, exp_b) and np.array_equal(cr, corr)
     c.close()
+
+
+@pytest.mark.parametrize("mode", ["default_external_write", "trusted_write_through_context", "trusted_then_invalidate"])
+def test_kept_by_products_never_describe_rewritten_buffers(mode, monkeypatch):
+    """The two-pass flow of the reference (all MAKE_SHARD batches first so that the prior is complete, then all
+    BARCODE_CORRECTION batches) re-uses fixed device buffers: pass A runs on batch A, the SAME buffers are refilled with
+    batch B, pass B runs.  K1's miss records describe batch A and must not be used:
+      default_external_write         the option is off: the records are never kept, whoever writes the buffers;
+      trusted_write_through_context  the option is on and the refill goes through crgpu_memcpy_h2d, which drops them;
+      trusted_then_invalidate        the option is on, the refill bypasses the context, the host calls crgpu_invalidate."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import MISS
+
+    monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")  # the table lookup (and with it the records) at a test-sized batch
+    n = 400_000
+    w = S.Workload(n_total=2 * n, seed=77, n_wl=50_000, n_cells=500, n_ambient=5000)
+    ra, rb = w.host_reads(0, n), w.host_reads(n, n)
+    c = G.fresh_ctx(trust=(mode != "default_external_write"))
+    other = G.fresh_ctx(trust=False)  # a second context stands in for "somebody else writes the buffers" (a torch copy, RCCL)
+    c.set_whitelist(0, w.wl_packed, length=16)
+    _, canon_sorted = c.canon_order()
+    d_cb, d_cbq, d_fl = c.upload(ra["cb"]), c.upload(ra["cb_qualn"]), c.upload(ra["flags"])
+    d_idx = c.empty(n, np.uint32)
+    c.match_and_count(d_cb, d_fl, n, d_idx)          # pass A on batch A (its counts stay: the prior covers A)
+    c.synchronize()
+    writer = c if mode == "trusted_write_through_context" else other
+    for dst, src in ((d_cb, rb["cb"]), (d_cbq, rb["cb_qualn"]), (d_fl, rb["flags"]), (d_idx, np.full(n, MISS, np.uint32))):
+        a = np.ascontiguousarray(src)
+        writer._check(writer.L.crgpu_memcpy_h2d(writer.h, dst.ptr, a.ctypes.data, a.nbytes))
+    other.synchronize()
+    if mode == "trusted_then_invalidate":
+        c.invalidate()
+    c.correct(d_cb, d_cbq, d_fl, n, d_idx)           # pass B on batch B, every read a MISS to start from
+    got = d_idx.to_host()
+    # oracle: the prior is batch A's valid histogram; every read of B goes through the corrector
+    owl = O.Whitelist(E.unpack_seqs(w.wl_packed, 16))
+    res_a = O.run_pipeline(G.oracle_reads_from_packed(ra, 16, 12), [owl], count=False, n_threads=4)
+    seq_b, qual_b = S.to_ascii(rb["cb"], rb["cb_qualn"], 16)
+    exp = np.full(n, MISS, np.uint32)
+    for i in range(0, n, 37):  # a sample of the reads, through the scalar oracle call
+        fixed = O.posterior_correct(owl, res_a.valid_hist[0], bytes(seq_b[i]), qual_b[i])
+        if fixed is not None:
+            exp[i] = G.ranks_of(canon_sorted, np.frombuffer(fixed, np.uint8).reshape(1, 16))[0]
+    sample = np.arange(0, n, 37)
+    assert np.array_equal(got[sample], exp[sample])
+    assert (got[sample] != MISS).sum() > 100
+    c.close()
+    other.close()
+
+
+def test_n_barcode_packed_without_flags_is_refused_not_matched():
+    """an N packs as code 0 ('A'); without a flags array nothing marks the read, and pass A would look the
+    barcode up as if N were A.  The pack kernels remember that they met an N without flags and the flag-less
+    crgpu_match_and_count_dev that follows fails with CRGPU_EINVAL."""
+    import gpu_helpers as G
+    from cellranger_amd._lib import CrgpuError
+
+    c = G.fresh_ctx()
+    wl = ["AAAAAAAAAAAAAAAA", "ACGTACGTACGTACGT"]
+    c.set_whitelist_ascii(0, wl)
+    seq = np.frombuffer(b"NAAAAAAAAAAAAAAA" + b"ACGTACGTACGTACGT", np.uint8).reshape(2, 16).copy()
+    qual = np.full((2, 16), 70, np.uint8)
+    d_seq, d_qual = c.upload(seq), c.upload(qual)
+    d_pk, d_qn, d_idx = c.empty(2, np.uint32), c.empty((2, 16), np.uint8), c.empty(2, np.uint32)
+    c.pack(d_seq, d_qual, 2, 16, d_pk, d_qn, None)
+    with pytest.raises(CrgpuError) as ei:
+        c.match_and_count(d_pk, None, 2, d_idx)
+    assert ei.value.code == -1 and "flags" in str(ei.value)
+    # with flags the N read is a miss and the other one a hit
+    d_fl = c.zeros(2, np.uint8)
+    c.pack(d_seq, d_qual, 2, 16, d_pk, d_qn, d_fl)
+    c.match_and_count(d_pk, d_fl, 2, d_idx)
+    assert list(d_idx.to_host()) == [0xFFFFFFFF, 1]
+    c.close()

@@ -170,3 +170,60 @@ def test_a_rank_that_leaves_breaks_the_local_group_instead_of_hanging_it():
     for t in ts:
         t.join(timeout=120)
     assert out["second"] == -7  # CRGPU_ECOMM
+
+
+def test_four_host_threads_share_one_context():
+    """ALIGN_AND_COUNT runs four worker threads per chunk (cr_lib/src/stages/align_and_count.rs:698-732).  One context
+    may be shared by them: every entry point locks it, so the calls execute one at a time in arrival order.  Four
+    threads hammer one context with whole count-stage calls on their own batches; every result equals the one the same
+    batch gives alone."""
+    import threading
+
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+
+    n, T, rounds = 60_000, 4, 3
+    w = S.Workload(n_total=n * T, seed=91, n_wl=20_000, n_cells=100, n_ambient=2000, n_genes=300)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+    # the barcode stage once for all batches (its histograms are context state, not per thread)
+    batches = []
+    for t in range(T):
+        r = w.host_reads(t * n, n)
+        d = {k: c.upload(r[k]) for k in ("cb", "cb_qualn", "flags", "umi", "umi_qualn", "feature")}
+        d["idx"] = c.empty(n, np.uint32)
+        c.match_and_count(d["cb"], d["flags"], n, d["idx"])
+        batches.append(d)
+    for d in batches:
+        c.correct(d["cb"], d["cb_qualn"], d["flags"], n, d["idx"])
+
+    def count(d):
+        recs = c.records(n, w.umi_len, d["idx"], d["umi"], d["umi_qualn"], d["feature"], d["flags"])
+        keys = c.empty(n, np.uint64)
+        nk = c.build_keys(recs, keys)
+        cnt = c.count_keys(keys, nk)
+        out = cnt.triplets() + (cnt.molecules()["read_count"],)
+        cnt.free()
+        return out
+
+    expect = [count(d) for d in batches]
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(rounds):
+                got = count(batches[t])
+                for a, b in zip(got, expect[t]):
+                    assert np.array_equal(a, b)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=300)
+    assert not errors, errors
+    assert len(expect[0][0]) > 100
+    c.close()
