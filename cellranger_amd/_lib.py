@@ -129,6 +129,7 @@ SYMBOLS = {
     "crgpu_comm_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "crgpu_set_option": (_i, [_vp, _i, C.c_int64]),
     "crgpu_invalidate": (_i, [_vp]),
+    "crgpu_get_stat": (_i, [_vp, _i, C.POINTER(_u64)]),
     "crgpu_barrier": (_i, [_vp]),
     "crgpu_allreduce_counts": (_i, [_vp, _i, _i]),
     "crgpu_exchange_keys_dev": (_i, [_vp, _vp, _u64, C.POINTER(_vp), C.POINTER(_u64), _vp]),

@@ -130,6 +130,7 @@ struct crgpu_ctx {
     KeyHistograms ghist;
     std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
+    uint64_t sort_fallbacks = 0;           // sorts whose look-back watchdog fired and that were finished by the classic passes
 
     double max_expected_errors = 1.7976931348623157e308;  // corrector.rs:104 (f64::MAX)
     double confidence_threshold = 0.975;                   // corrector.rs:83

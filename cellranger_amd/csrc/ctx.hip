@@ -110,6 +110,18 @@ extern "C" int crgpu_set_option(crgpu_ctx *ctx, int option, int64_t value) {
     }
 }
 
+extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
+    if (!ctx || !value_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    switch (which) {
+        case CRGPU_STAT_SORT_FALLBACKS:
+            *value_out = ctx->sort_fallbacks;
+            return CRGPU_OK;
+        default:
+            return cr_fail(ctx, CRGPU_EINVAL, "crgpu_get_stat: unknown counter %d", which);
+    }
+}
+
 void cr_invalidate(crgpu_ctx *ctx) {
     cr_drop_miss_records(ctx);
     ctx->ghist.valid = false;

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                                                               DIG dig, const uint32_t *__restrict__ block_offs,
                                                               const uint32_t *__restrict__ digit_totals,
                                                               uint32_t n_blocks, unsigned long long *__restrict__ status,
-                                                              uint32_t *__restrict__ ticket) {
+                                                              uint32_t *__restrict__ ticket, uint32_t *__restrict__ abort_word,
+                                                              uint32_t pass_tag) {
     constexpr int ITEMS = SortCfg<K, HAS_VALS>::ITEMS;
     constexpr uint32_t CHUNK = SortCfg<K, HAS_VALS>::CHUNK;
     constexpr uint32_t RADIX_T = 1u << BITS;
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
     uint32_t *s_chunk = lds + SORT_WAVES;     // ONESWEEP: the ticket of the current chunk
+    uint32_t *s_abort = s_chunk + 1;          // ONESWEEP: a waiter of this workgroup saw (or raised) the abort word
+    if (ONESWEEP && tid == 0) *s_abort = 0u;  // ordered before its first use by the barrier behind the ticket
 
     if (!ONESWEEP) {
         const uint32_t digit_base = block_excl_scan<SORT_BLOCK>(tid < RADIX_T ? digit_totals[tid] : 0u, lds, nullptr);
@@ -240,7 +243,12 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             // on arbitrary XCDs and every run boundary went to HBM as two partial lines).  The look-back still
             // follows the global chunk order; a chunk's predecessors are either earlier tickets of its own XCD or
             // chunks of other XCDs that their counters reach without waiting on anything later.
-            if (tid == 0) {
+            // abort_word (shared by all passes of one sort): 0, or 1 + the pass whose look-back watchdog fired.  Once it is
+            // set nobody takes another chunk -- of this pass or of the passes queued behind it -- so the buffers stay as
+            // the failed pass found them and the host redoes the sort from that pass on with the classic kernels.
+            if (tid == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                *s_chunk = 0xFFFFFFFFu;
+            } else if (tid == 0) {
                 uint32_t xcc = 0;
                 if (n_blocks > 1) {
                     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -299,7 +307,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         {
             if (tid < RADIX_T)
                 for (int w = 0; w < SORT_WAVES; w++) tot += wcount[w][tid];
-            if (ONESWEEP && tid < RADIX_T)  // let the successors go on as early as possible
+            // (pass_tag bit 31: test switch CRGPU_SORT_FORCE_ABORT -- chunk 0 never publishes, the chain stalls)
+            if (ONESWEEP && tid < RADIX_T && !((pass_tag >> 31) && cidx == 0))  // let the successors go on as early as possible
                 __hip_atomic_store(&status[cidx * RADIX_T + tid], (cidx == 0 ? OS_INC : OS_AGG) | tot, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             uint32_t run = block_excl_scan<SORT_BLOCK>(tot, lds, nullptr);  // chunk-local start of digit tid
@@ -329,18 +338,21 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                 unsigned long long excl = 0;
                 if (cidx > 0) {
                     // Watchdog: the chain cannot stall as long as every XCD receives workgroups (each of them takes its
-                    // XCD's chunks in ascending order).  Should that ever not hold, a waiter gives up after ~2^22 polls,
-                    // raises the abort word behind the tickets, everybody stops waiting, and the host reports an error
-                    // instead of a hung GPU.
-                    uint32_t *abort_word = ticket + 16 * 32 - 1;
+                    // XCD's chunks in ascending order).  Should that ever not hold (CU masking, a shared device), a waiter
+                    // gives up after ~2^22 polls and raises the abort word; everybody stops waiting and stops taking
+                    // chunks, and the host redoes the sort from this pass on with the classic kernels -- no hung GPU,
+                    // no failed call.
                     auto wait_for = [&](uint64_t c, unsigned long long sv) {
                         uint32_t polls = 0;
                         while ((sv >> 62) == 0ull) {
                             __builtin_amdgcn_s_sleep(1);
                             sv = __hip_atomic_load(&status[c * RADIX_T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((++polls & 0xFFFu) == 0u) {
-                                if (polls >= (1u << 22)) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return OS_INC;
+                                if (polls >= (1u << 22)) atomicCAS(abort_word, 0u, pass_tag & 0x7FFFFFFFu);
+                                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                    *s_abort = 1u;
+                                    return OS_INC;
+                                }
                             }
                         }
                         return sv;
@@ -380,6 +392,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             gdelta[tid] = g - run0;
         }
         __syncthreads();
+        if (ONESWEEP && *s_abort) break;  // uniform: nothing of this chunk is written, the pass is redone
         for (uint32_t p = tid; p < chunk_n; p += SORT_BLOCK) {
             const K k = skeys[p];
             const uint32_t pos = p + gdelta[dig(k)];
@@ -428,11 +441,11 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
     if (d_vin) {
         cr_allow_lds(ctx, (const void *)k_radix_scatter<K, true, DIG, BITS>, lds_kv);
         hipLaunchKernelGGL((k_radix_scatter<K, true, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), lds_kv, ctx->stream,
-                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb, nullptr, nullptr);
+                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb, nullptr, nullptr, nullptr, 0u);
     } else {
         cr_allow_lds(ctx, (const void *)k_radix_scatter<K, false, DIG, BITS>, lds_k);
         hipLaunchKernelGGL((k_radix_scatter<K, false, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), lds_k, ctx->stream,
-                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb, nullptr, nullptr);
+                           d_in, d_out, d_vin, d_vout, n, tile, dig, d_hist, d_tot, nb, nullptr, nullptr, nullptr, 0u);
     }
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
@@ -520,8 +533,8 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     void *d_small = nullptr, *d_status = nullptr;
     if (!ctx->n_xcc) ctx->n_xcc = probe_xccs(ctx);
     const uint32_t n_xcc = ctx->n_xcc;
-    // histograms + per pass 16 ticket counters, a cache line each
-    const size_t small_bytes = (size_t)OS_MAX_PASSES * RADIX_MAX * 4 + OS_MAX_PASSES * 16 * 128;
+    // histograms + per pass 16 ticket counters, a cache line each + the abort word (a line of its own)
+    const size_t small_bytes = (size_t)OS_MAX_PASSES * RADIX_MAX * 4 + OS_MAX_PASSES * 16 * 128 + 128;
     CR_TRY(cr_pool_alloc(ctx, &d_small, small_bytes));
     int rc = cr_pool_alloc(ctx, &d_status, n_chunks * RADIX_MAX * sizeof(unsigned long long));
     if (rc != CRGPU_OK) {
@@ -530,6 +543,10 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     }
     uint32_t *ghist = (uint32_t *)d_small;
     uint32_t *tickets = ghist + OS_MAX_PASSES * RADIX_MAX;
+    uint32_t *d_abort = tickets + OS_MAX_PASSES * 16 * 32;
+    // test switch: CRGPU_SORT_FORCE_ABORT=<pass> stalls the look-back chain of that pass (chunk 0 never publishes)
+    int force_pass = -1;
+    if (const char *fa = getenv("CRGPU_SORT_FORCE_ABORT")) force_pass = atoi(fa);
     hipError_t e = hipMemsetAsync(d_small, 0, small_bytes, ctx->stream);
     {
         CrTimer t(ctx, CRGPU_T_SORT_HIST, n);
@@ -548,6 +565,7 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         const size_t lds = Cfg::lds_bytes(wide ? 9 : 8);
         const uint32_t radix = wide ? 512u : 256u;
         RadixDigit dig{plan.shift[p], plan.mask[p]};
+        const uint32_t tag = (p + 1u) | ((int)p == force_pass && n_chunks > 1 ? 0x80000000u : 0u);
         CrTimer t(ctx, CRGPU_T_SORT, n);
         e = hipMemsetAsync(d_status, 0, n_chunks * radix * sizeof(unsigned long long), ctx->stream);
         // one workgroup fits per CU, the rest queue up for tickets.  With per-XCD tickets every XCD must receive
@@ -557,12 +575,12 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
             cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 9, true>, lds);
             hipLaunchKernelGGL((k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 9, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
                                out, vin, vout, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
-                               (unsigned long long *)d_status, tickets + p * 16 * 32);
+                               (unsigned long long *)d_status, tickets + p * 16 * 32, d_abort, tag);
         } else {
             cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 8, true>, lds);
             hipLaunchKernelGGL((k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 8, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
                                out, vin, vout, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
-                               (unsigned long long *)d_status, tickets + p * 16 * 32);
+                               (unsigned long long *)d_status, tickets + p * 16 * 32, d_abort, tag);
         }
         if (e == hipSuccess) e = hipGetLastError();
         uint64_t *t2 = in;
@@ -573,17 +591,35 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         vout = tv;
         *result_in_tmp = !*result_in_tmp;
     }
-    uint32_t aborted = 0;
-    if (e == hipSuccess) {
-        // abort words: the last ticket word of every pass
-        std::vector<uint32_t> tk(OS_MAX_PASSES * 16 * 32);
-        if (crgpu_memcpy_d2h(ctx, tk.data(), tickets, tk.size() * sizeof(uint32_t)) == CRGPU_OK)
-            for (uint32_t p = 0; p < plan.n_passes; p++) aborted |= tk[p * 16 * 32 + 16 * 32 - 1];
-    }
+    uint32_t aborted = 0;  // 0, or 1 + the pass whose watchdog fired: that pass and all later ones wrote nothing usable
+    if (e == hipSuccess && crgpu_memcpy_d2h(ctx, &aborted, d_abort, sizeof(aborted)) != CRGPU_OK) e = hipErrorUnknown;
     cr_pool_free(ctx, d_status);
     cr_pool_free(ctx, d_small);
     if (e != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "onesweep sort: %s", hipGetErrorString(e));
-    if (aborted) return cr_fail(ctx, CRGPU_EHIP, "onesweep sort: look-back watchdog fired (set CRGPU_SORT=classic)");
+    if (aborted) {
+        // the input of the failed pass is intact (later passes left at once): finish with the classic three-kernel passes
+        const uint32_t p0 = aborted - 1u;
+        static const bool verbose = getenv("CRGPU_SORT_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[crgpu sort] look-back watchdog fired in pass %u of %u: finishing with the classic passes\n", p0, plan.n_passes);
+        in = (p0 & 1u) ? d_tmp : d_keys;
+        out = (p0 & 1u) ? d_keys : d_tmp;
+        vin = (p0 & 1u) ? d_vals_tmp : d_vals;
+        vout = (p0 & 1u) ? d_vals : d_vals_tmp;
+        for (uint32_t p = p0; p < plan.n_passes; p++) {
+            RadixDigit dig{plan.shift[p], plan.mask[p]};
+            if (widths[p] == 9)
+                CR_TRY((radix_pass<uint64_t, RadixDigit, 9>(ctx, in, out, HAS_VALS ? vin : nullptr, vout, n, dig)));
+            else
+                CR_TRY((radix_pass<uint64_t, RadixDigit, 8>(ctx, in, out, HAS_VALS ? vin : nullptr, vout, n, dig)));
+            uint64_t *t2 = in;
+            in = out;
+            out = t2;
+            uint32_t *tv = vin;
+            vin = vout;
+            vout = tv;
+        }
+        ctx->sort_fallbacks++;
+    }
     return CRGPU_OK;
 }
 

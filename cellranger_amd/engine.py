@@ -302,6 +302,11 @@ class Context:
     def invalidate(self):
         self._check(self.L.crgpu_invalidate(self.h))
 
+    def stat(self, which=0):
+        v = C.c_uint64()
+        self._check(self.L.crgpu_get_stat(self.h, which, C.byref(v)))
+        return v.value
+
     def barrier(self):
         self._check(self.L.crgpu_barrier(self.h))
 

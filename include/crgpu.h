@@ -93,6 +93,9 @@ int crgpu_comm_info(crgpu_ctx *ctx, uint32_t *n_ranks_out, uint32_t *rank_out);
 #define CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS 0
 int crgpu_set_option(crgpu_ctx *ctx, int option, int64_t value);
 int crgpu_invalidate(crgpu_ctx *ctx);
+/* counters since the context was made */
+#define CRGPU_STAT_SORT_FALLBACKS 0  /* sorts whose look-back watchdog fired and that the classic passes finished */
+int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out);
 /* ctx may be NULL: returns the message of the last failed crgpu_create on this thread. */
 const char *crgpu_last_error(const crgpu_ctx *ctx);
 int crgpu_synchronize(crgpu_ctx *ctx);

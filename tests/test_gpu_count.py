@@ -364,3 +364,46 @@ def test_random_key_layouts_bit_exact():
         _compare_with_oracle(c, w, r, n, n_genes, n_libs=n_libs)
         c.close()
     assert len(seen_bits) >= 8 and max(seen_bits) >= 58 and min(seen_bits) <= 30
+
+
+@pytest.mark.parametrize("bad_pass", [0, 2, 5])
+def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, monkeypatch):
+    """The look-back chain of one onesweep pass is stalled on purpose (CRGPU_SORT_FORCE_ABORT: chunk 0 never publishes).
+    The watchdog raises the abort word, that pass and the ones queued behind it write nothing, and the host finishes the
+    sort from the failed pass on with the classic histogram / scan / scatter passes inside the same call: the call
+    succeeds and its results are identical to an undisturbed run."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+
+    n = 400_000
+    w = S.Workload(n_total=n, seed=58, n_wl=60_000, n_cells=150, n_ambient=5000, n_genes=500)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)   # 16 + 9 + 24 + 1 = 50 bits: six passes
+    r = w.host_reads(0, n)
+    _, _, _, dev = G.gpu_barcode_stage(c, r, n)
+    d_umi, d_uq, d_ft = c.upload(r["umi"]), c.upload(r["umi_qualn"]), c.upload(r["feature"])
+    recs = c.records(n, w.umi_len, dev["idx"], d_umi, d_uq, d_ft, dev["flags"])
+
+    def run():
+        keys = c.empty(n, np.uint64)
+        nk = c.build_keys(recs, keys)
+        assert nk > 200_000   # more than one 16 K-key chunk, or nothing can stall
+        cnt = c.count_keys(keys, nk)
+        out = cnt.triplets() + tuple(cnt.molecules()[k] for k in ("bc", "feature", "umi", "read_count", "utype"))
+        cnt.free()
+        return out
+
+    ref = run()
+    assert c.stat(0) == 0
+    monkeypatch.setenv("CRGPU_SORT_FORCE_ABORT", str(bad_pass))
+    got = run()
+    monkeypatch.delenv("CRGPU_SORT_FORCE_ABORT")
+    assert c.stat(0) == 1, "the forced stall did not reach the fallback"
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    again = run()       # and the context keeps working with the fast path
+    assert c.stat(0) == 1
+    for a, b in zip(again, ref):
+        assert np.array_equal(a, b)
+    c.close()
