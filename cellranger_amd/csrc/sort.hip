@@ -342,13 +342,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                     // gives up after ~2^22 polls and raises the abort word; everybody stops waiting and stops taking
                     // chunks, and the host redoes the sort from this pass on with the classic kernels -- no hung GPU,
                     // no failed call.
+                    const uint32_t poll_limit = (pass_tag >> 31) ? (1u << 16) : (1u << 22);  // the forced stall need not take seconds
                     auto wait_for = [&](uint64_t c, unsigned long long sv) {
                         uint32_t polls = 0;
                         while ((sv >> 62) == 0ull) {
                             __builtin_amdgcn_s_sleep(1);
                             sv = __hip_atomic_load(&status[c * RADIX_T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((++polls & 0xFFFu) == 0u) {
-                                if (polls >= (1u << 22)) atomicCAS(abort_word, 0u, pass_tag & 0x7FFFFFFFu);
+                                if (polls >= poll_limit) atomicCAS(abort_word, 0u, pass_tag & 0x7FFFFFFFu);
                                 if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                                     *s_abort = 1u;
                                     return OS_INC;

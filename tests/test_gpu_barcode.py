@@ -395,3 +395,19 @@ def test_n_barcode_packed_without_flags_is_refused_not_matched():
     c.match_and_count(d_pk, d_fl, 2, d_idx)
     assert list(d_idx.to_host()) == [0xFFFFFFFF, 1]
     c.close()
+
+
+@pytest.mark.parametrize("hot", [False, True])
+def test_3m_whitelist_1m_reads_bit_exact(hot, monkeypatch):
+    """The SC3Pv3 list (3M-february-2018, cr_types/src/chemistry/chemistry_defs.json:72) has 6 794 880 entries: ~104 keys
+    per pigeonhole bin instead of ~11, tables of ~55 MB instead of ~6, a 23-bit barcode rank.  1 M reads of the cfg2
+    model drawn from a random list of that size: per-read index and both histograms equal the oracle's, with the plain
+    kernels and with K1's LDS table + miss records forced on."""
+    from cellranger_amd import synth as S
+
+    if hot:
+        monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")
+    w = S.Workload(n_total=1_000_000, seed=S.SEED0 + 6, n_wl=6_794_880)
+    st = _compare_barcode_stage(w, 1_000_000)
+    # a denser list: more reads with an error land on ANOTHER whitelist entry or find two candidates
+    assert st["corrected"] > 20_000 and st["invalid"] > 1_000 and st["valid"] > 800_000

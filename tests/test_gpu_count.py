@@ -407,3 +407,20 @@ def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, monkeypatc
     for a, b in zip(again, ref):
         assert np.array_equal(a, b)
     c.close()
+
+
+def test_3m_whitelist_64_bit_keys_bit_exact():
+    """3M-february-2018-sized list x 36 601 features x 12-base UMIs: the molecule key needs 23 + 16 + 24 + 1 = 64 bits
+    (eight radix passes).  500 k records: every read's index and DupInfo, the matrix, the molecule table and the
+    BarcodeSummary rows equal the oracle's."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+
+    n = 500_000
+    w = S.Workload(n_total=n, seed=S.SEED0 + 7, n_wl=6_794_880, n_cells=2000, n_ambient=50_000)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    res, m = _compare_with_oracle(c, w, r, n, w.n_genes)
+    assert m.nnz > 50_000
+    c.close()
