@@ -803,6 +803,42 @@ __global__ __launch_bounds__(512) void k_hist_buckets(const WlViewSet vs, const 
 #define MB_STAGE_BUDGET (8ull << 30)  // bytes of u16 staging per super-batch: 6 launch rounds per 1 B reads (2 GB = 22 rounds cost 1.1 ms more in ramp-up / table loads)
 #endif
 
+// Histogram of a dense array of canonical ranks (CRGPU_MISS entries are skipped) into v[0].valid of `vs`, with the
+// staging kernels of K1: k_stage_idx (needs plan.n_buckets <= SI_MISS_BUCKET) + k_hist_buckets.
+static int hist_from_idx(crgpu_ctx *ctx, const WlViewSet &vs, BinPlan plan, const uint32_t *d_idx, uint64_t n) {
+    if (n == 0) return CRGPU_OK;
+    uint64_t sb = MB_STAGE_BUDGET / 2 / plan.n_buckets;
+    sb = sb / MB_TILE * MB_TILE;
+    if (sb < MB_TILE) sb = MB_TILE;
+    if (sb > n) sb = (n + MB_TILE - 1) / MB_TILE * MB_TILE;
+    plan.cap = sb;
+    uint16_t *d_stage = nullptr;
+    uint32_t *d_cursor = nullptr;
+    CR_TRY(cr_pool_alloc(ctx, (void **)&d_stage, (uint64_t)plan.n_buckets * plan.cap * sizeof(uint16_t)));
+    int rc = cr_pool_alloc(ctx, (void **)&d_cursor, plan.n_buckets * MB_CURSOR_STRIDE * sizeof(uint32_t));
+    if (rc != CRGPU_OK) {
+        cr_pool_free(ctx, d_stage);
+        return rc;
+    }
+    uint32_t slices = 512 / plan.n_buckets;
+    if (slices < 1) slices = 1;
+    cr_allow_lds(ctx, (const void *)k_hist_buckets, BIN_SIZE * 4);
+    hipError_t e = hipSuccess;
+    for (uint64_t off = 0; off < n && e == hipSuccess; off += sb) {
+        const uint64_t m = n - off < sb ? n - off : sb;
+        e = hipMemsetAsync(d_cursor, 0, plan.n_buckets * MB_CURSOR_STRIDE * sizeof(uint32_t), ctx->stream);
+        hipLaunchKernelGGL(k_stage_idx, dim3(cr_grid((m + SI_TILE - 1) / SI_TILE, 1, 256u * 6u)), dim3(256), 0, ctx->stream, plan,
+                           d_idx + off, m, d_stage, d_cursor);
+        hipLaunchKernelGGL(k_hist_buckets, dim3(plan.n_buckets * slices), dim3(512), BIN_SIZE * 4, ctx->stream, vs, plan, slices,
+                           d_stage, d_cursor);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    cr_pool_free(ctx, d_stage);
+    cr_pool_free(ctx, d_cursor);
+    if (e != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "histogram of ranks: %s", hipGetErrorString(e));
+    return CRGPU_OK;
+}
+
 extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_flags, uint64_t n,
                                          uint32_t *d_idx_out) {
     if (!ctx) return CRGPU_EINVAL;
@@ -1043,10 +1079,14 @@ struct K2Params {
     uint32_t *idx_inout;
     uint8_t *corrected_out;
 };
+// where a corrected read's rank is counted: rank_sink == NULL -> one device-scope atomicAdd on the library's CORRECTED
+// table per corrected read (scattered atomics run at ~20 G/s: 17 % of K2's time at 1 B reads); otherwise the rank is
+// stored in *rank_sink (a compact, coalesced array) and the table is built afterwards by K1's staged LDS histogram
 
 // one missing read: i = index in the caller's arrays, key = packed barcode, f = flag byte
 template <bool UNIFORM>
-__device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Params &P, uint64_t i, uint32_t key, uint32_t f) {
+__device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Params &P, uint64_t i, uint32_t key, uint32_t f,
+                                               uint32_t *rank_sink = nullptr) {
     const uint8_t *__restrict__ qualn = P.qualn;
     const uint32_t len = P.len;
     const double *__restrict__ ptab = P.ptab;
@@ -1061,7 +1101,11 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
 
     // qualities (bit 7 = N), kept in two 64-bit registers: byte k of (qlo,qhi) = position k
     unsigned long long qlo, qhi;
+#ifdef K2_EXP_NO_QUAL
+    if (false) {
+#else
     if (qualn) {
+#endif
         if (len == 16) {
             const cr_u32x4 qv = CR_LOAD_STREAM(reinterpret_cast<const cr_u32x4 *>(qualn + i * 16));
             const uint4 q4 = make_uint4(qv.x, qv.y, qv.z, qv.w);
@@ -1163,9 +1207,16 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
         for (uint32_t k = 0; k < len; k++)
             expected += ptab[(uint32_t)((k < 8u ? qlo : qhi) >> (8u * (k & 7u))) & 0x7Fu];
     if (expected < max_expected && best_like / total >= thresh) {
+#ifndef K2_EXP_NO_IDX   // cost-attribution builds (scripts/ab.sh): results are wrong without these stores
         CR_STORE_STREAM(best_rank, &idx_inout[i]);
+#endif
         if (corrected_out) corrected_out[i] = 1;
-        atomicAdd(&w.corrected[best_rank], 1u);
+#ifndef K2_EXP_NO_ATOMIC
+        if (rank_sink)
+            CR_STORE_STREAM(best_rank, rank_sink);
+        else
+            atomicAdd(&w.corrected[best_rank], 1u);
+#endif
     }
 }
 
@@ -1185,18 +1236,46 @@ __global__ __launch_bounds__(256) void k_correct(const WlViewSet vs, const uint3
 // ... and the misses as the records K1's lookup kernel left behind (coalesced reads instead of two random
 // 128-byte lines per miss for cb and flags).  Does nothing when the records overflowed (k_collect_miss + k_correct
 // then cover everything).
+// rank_out (nullable) + rec_off: the rank every record was corrected to (CRGPU_MISS: not corrected), compact in record
+// order: slot = rec_off[region] + position (rec_off = exclusive prefix of the region counts, k_region_offsets)
 __global__ __launch_bounds__(256) void k_correct_records(const WlViewSet vs, const uint32_t *__restrict__ rec_i,
                                                          const uint32_t *__restrict__ rec_key, const uint8_t *__restrict__ rec_fl,
                                                          const uint32_t *__restrict__ rec_count, uint32_t rec_cap,
-                                                         uint32_t rec_regions, const K2Params P) {
+                                                         uint32_t rec_regions, const K2Params P,
+                                                         const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rank_out) {
     if (rec_count[rec_regions] != 0u) return;
     for (uint32_t r = blockIdx.x; r < rec_regions; r += gridDim.x) {
         const uint32_t cnt = rec_count[r];
+        const uint32_t base = rank_out ? rec_off[r] : 0u;
         for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
             const uint64_t o = (uint64_t)r * rec_cap + p;
-            k2_correct_one<true>(vs, P, CR_LOAD_STREAM(&rec_i[o]), CR_LOAD_STREAM(&rec_key[o]), CR_LOAD_STREAM(&rec_fl[o]));
+            uint32_t *sink = rank_out ? rank_out + base + p : nullptr;
+            if (sink) *sink = CRGPU_MISS;
+            k2_correct_one<true>(vs, P, CR_LOAD_STREAM(&rec_i[o]), CR_LOAD_STREAM(&rec_key[o]), CR_LOAD_STREAM(&rec_fl[o]), sink);
         }
     }
+}
+
+// exclusive prefix of the per-region record counts (a few thousand regions): off[r], off[n] = total; all zero when the
+// records overflowed (k_correct_records then does nothing)
+__global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *__restrict__ count, uint32_t n, uint32_t *__restrict__ off) {
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const bool overflow = count[n] != 0u;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t r = base + threadIdx.x;
+        const uint32_t v = (r < n && !overflow) ? count[r] : 0u;
+        uint32_t tot;
+        const uint32_t pre = block_excl_scan<1024>(v, lds, &tot);
+        const uint32_t carry = carry_s;
+        if (r < n) off[r] = carry + pre;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[n] = carry_s;
 }
 
 extern "C" int crgpu_set_posterior(crgpu_ctx *ctx, double max_expected_barcode_errors, double bc_confidence_threshold) {
@@ -1261,11 +1340,41 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
         hipLaunchKernelGGL(k_correct<true>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, miss_list, n_miss, P);
     else
         hipLaunchKernelGGL(k_correct<false>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, miss_list, n_miss, P);
-    if (use_rec)
+    if (use_rec) {
+        // the corrected ranks of the records go to a compact array and are counted by K1's staged LDS histogram (when its
+        // bucket plan applies: one library, at most 31 rank buckets) instead of one scattered atomic per corrected read
+        BinPlan plan;
+        for (int l = 0; l < CRGPU_MAX_LIB; l++) plan.lib_slot[l] = l == 0 ? 0u : 0xFFFFFFFFu;
+        plan.buckets_per_lib = (ctx->n_canon + BIN_SIZE - 1) / BIN_SIZE;
+        plan.n_buckets = plan.buckets_per_lib;
+        uint32_t *d_off = nullptr, *d_rank = nullptr;
+        const uint64_t rec_total_cap = (uint64_t)rec.regions * rec.cap;
+        static const bool no_staged = getenv("CRGPU_K2_ATOMIC_HIST") != nullptr;  // A/B switch
+        bool staged = !no_staged && plan.n_buckets <= SI_MISS_BUCKET && rec_total_cap < 0xFFFFFFFFull;
+        if (staged && (cr_pool_alloc(ctx, (void **)&d_off, (rec.regions + 1) * sizeof(uint32_t)) != CRGPU_OK ||
+                       cr_pool_alloc(ctx, (void **)&d_rank, rec_total_cap * sizeof(uint32_t)) != CRGPU_OK)) {
+            cr_pool_free(ctx, d_off);
+            d_off = d_rank = nullptr;
+            staged = false;  // not fatal: atomics as before
+        }
+        if (staged) hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, rec.d_count, rec.regions, d_off);
         hipLaunchKernelGGL(k_correct_records, dim3(2048), dim3(256), 0, ctx->stream, vs, rec.d_i, rec.d_key, rec.d_fl, rec.d_count,
-                           rec.cap, rec.regions, P);
+                           rec.cap, rec.regions, P, d_off, d_rank);
+        int rc = CRGPU_OK;
+        if (hipGetLastError() != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "crgpu_correct: launch failed");
+        uint32_t total = 0;
+        if (rc == CRGPU_OK && staged) rc = crgpu_memcpy_d2h(ctx, &total, d_off + rec.regions, sizeof(total));
+        if (rc == CRGPU_OK && staged && total) {
+            WlViewSet vc = vs;
+            vc.v[0].valid = vc.v[0].corrected;  // k_hist_buckets adds to `valid` of the call's library (v[0])
+            rc = hist_from_idx(ctx, vc, plan, d_rank, total);
+        }
+        cr_pool_free(ctx, d_off);
+        cr_pool_free(ctx, d_rank);
+        cr_drop_miss_records(ctx);  // stream-ordered: the pool reuses the blocks only for later work
+        return rc;
+    }
     CR_HIP(ctx, hipGetLastError());
-    if (use_rec) cr_drop_miss_records(ctx);  // stream-ordered: the pool reuses the blocks only for later work
     return CRGPU_OK;
 }
 

@@ -406,6 +406,27 @@ static int compact(crgpu_ctx *ctx, Flag flag, Emit emit, uint64_t n, uint32_t *d
     return CRGPU_OK;
 }
 
+// ---- per-key state after UMI correction ---------------------------------------------------------------------------------
+// st[k] (16 bits, zeroed before the kernels run): bit 0 = key k is corrected away (corr[k] holds its target -- corr is
+// written ONLY for such keys and must not be read otherwise), bit 1 = low support, bits 2.. = inc1 = number of keys
+// corrected onto k (phase 1 of BarcodeDupMarker::new moves one read of each, mark_dups.rs:228-232; at most 3 L).
+// inc_all[k] (zeroed) = reads of all keys corrected onto k (phases 1 + 2, :242-246); meaningful where inc1 > 0.
+// Corrections are rare (a few per cent of the keys), so everything here is a scattered atomic on a zeroed array and the
+// common key writes nothing; the streaming passes afterwards read 2 bytes per key instead of four arrays.
+#define ST_CORRECTED 1u
+#define ST_LOW 2u
+__device__ __forceinline__ uint32_t st_inc1(uint32_t s) { return s >> 2; }
+__device__ __forceinline__ void st_or(uint16_t *st, uint64_t k, uint32_t bits) {
+    atomicOr(reinterpret_cast<uint32_t *>(st) + (k >> 1), bits << (16u * (uint32_t)(k & 1u)));
+}
+__device__ __forceinline__ void move_reads(uint32_t *corr, uint16_t *st, uint32_t *inc_all, uint64_t k, uint32_t target,
+                                           uint32_t my_cnt) {
+    corr[k] = target;
+    st_or(st, k, ST_CORRECTED);
+    atomicAdd(reinterpret_cast<uint32_t *>(st) + (target >> 1), 4u << (16u * (target & 1u)));  // inc1[target] += 1
+    atomicAdd(&inc_all[target], my_cnt);
+}
+
 // ---- functors --------------------------------------------------------------------------------------
 struct HeadFlag {  // first element of a run of equal (key >> shift)
     const uint64_t *keys;
@@ -427,45 +448,47 @@ struct EmitRun {  // distinct key + start position of its run
     }
 };
 struct MolFlag {  // distinct key that yields a UmiCount (mark_dups.rs:322-325 with rate 1.0, no target filter)
-    const uint32_t *corr, *inc1;
-    const uint8_t *low;
+    const uint16_t *st;  // state word of umi_correct.h
     __device__ __forceinline__ bool operator()(uint64_t k) const {
-        const uint32_t c = corr[k], i1 = inc1[k], l = low[k];  // three independent loads
-        const bool landed = (c == NONE32) | (i1 > 0u);          // some read's corrected key is k
-        return landed & (l == 0u);
+        const uint32_t s = st[k];
+        const bool landed = !(s & ST_CORRECTED) | (st_inc1(s) > 0u);  // some read's corrected key is k
+        return landed & !(s & ST_LOW);
     }
 };
 struct EmitMol {
     const uint64_t *ukey;
-    const uint32_t *upos, *corr, *inc_all;
-    const unsigned long long *minraw;
+    const uint32_t *upos, *inc_all, *minidx;
+    const uint16_t *st;
     uint64_t n_keys, n_dist;
     uint64_t *mkeys;
     uint32_t *mreads;
     struct Pre {
-        unsigned long long mr;
         uint64_t key;
-        uint32_t p0, p1, corr, inc_all;
+        uint32_t p0, p1, s;
     };
     __device__ __forceinline__ Pre pre(uint64_t k) const {
         Pre p;
-        p.mr = minraw[k];
         p.key = ukey[k];
         p.p0 = upos[k];
         p.p1 = upos[k + 1 < n_dist ? k + 1 : k];
-        p.corr = corr[k];
-        p.inc_all = inc_all[k];
+        p.s = st[k];
         return p;
     }
     __device__ __forceinline__ void operator()(uint64_t k, uint32_t o, const Pre &p) const {
+        // Only a key that other keys were corrected onto (a few per cent) has anything in inc_all / minidx.
         // UmiType of the representative read (mark_dups.rs:250-268,326-329): the min (utype, qname)
         // read of the smallest qualifying raw UMI corrected onto k, else of k itself.
-        const uint64_t bit = (p.mr != ~0ull ? ukey[p.mr & 0xFFFFFFFFull] : p.key) & 1ull;
+        uint32_t inc = 0u, mi = NONE32;
+        if (st_inc1(p.s)) {
+            inc = inc_all[k];
+            mi = minidx[k];
+        }
+        const uint64_t bit = (mi != NONE32 ? ukey[mi] : p.key) & 1ull;
         mkeys[o] = (p.key & ~1ull) | bit;
         const uint32_t end = k + 1 < n_dist ? p.p1 : (uint32_t)n_keys;
         const uint32_t cnt = end - p.p0;
         // umigene_counts after both moves (mark_dups.rs:226-246): own reads stay only if not corrected away
-        mreads[o] = (p.corr == NONE32 ? cnt : 0u) + p.inc_all;
+        mreads[o] = ((p.s & ST_CORRECTED) ? 0u : cnt) + inc;
     }
 };
 struct EmitTriplet {
@@ -521,27 +544,27 @@ __device__ __forceinline__ uint32_t run_count(const uint32_t *__restrict__ upos,
 
 // Representative-read bookkeeping (mark_dups.rs:248-268): for a corrected key K the representative
 // is the min-(utype, qname) read of the lexicographically smallest raw UMI R corrected onto K with
-// (R < K or K itself corrected away).  Keep min over such R of (R << 32 | distinct-key index of R).
-__global__ __launch_bounds__(256) void k_rep_utype(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
-                                                   const uint32_t *__restrict__ corr,
-                                                   unsigned long long *__restrict__ minraw) {
+// (R < K or K itself corrected away).  R and K lie in one (barcode, feature, library) segment, where the distinct keys
+// are sorted by UMI: the smallest such R is the smallest INDEX, kept by a 32-bit atomicMin in minidx[K].
+__global__ __launch_bounds__(256) void k_rep_utype(const uint64_t *__restrict__ ukey, uint64_t nd,
+                                                   const uint32_t *__restrict__ corr, const uint16_t *__restrict__ st,
+                                                   uint32_t *__restrict__ minidx) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 8;
-    const uint64_t umi_mask = lowmask(kl.bits_umi);
-    // 8 keys per thread per round: the corr loads are all issued before the first one is looked at (only ~2 % of
-    // the keys are corrected and take the second, dependent round of loads)
+    // 8 keys per thread per round: the state loads are all issued before the first one is looked at (only ~2 % of
+    // the keys are corrected and take the dependent loads)
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x * 8; base < nd; base += stride) {
         uint32_t t[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint64_t k = base + (uint64_t)j * blockDim.x + threadIdx.x;
-            t[j] = corr[k < nd ? k : nd - 1];
+            t[j] = st[k < nd ? k : nd - 1];
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint64_t k = base + (uint64_t)j * blockDim.x + threadIdx.x;
-            if (k >= nd || t[j] == NONE32) continue;
-            const uint64_t raw = (ukey[k] >> kl.sh_umi) & umi_mask, tgt = (ukey[t[j]] >> kl.sh_umi) & umi_mask;
-            if (raw < tgt || corr[t[j]] != NONE32) atomicMin(&minraw[t[j]], (unsigned long long)((raw << 32) | k));
+            if (k >= nd || !(t[j] & ST_CORRECTED)) continue;
+            const uint32_t tgt = corr[k];
+            if (k < tgt || (st[tgt] & ST_CORRECTED)) atomicMin(&minidx[tgt], (uint32_t)k);
         }
     }
 }
@@ -678,37 +701,34 @@ struct CandFlag {
     const uint8_t *cand;
     __device__ __forceinline__ bool operator()(uint64_t k) const { return cand[k] != 0; }
 };
-struct EmitIdx {
-    uint32_t *out;
-    struct Pre {};
-    __device__ __forceinline__ Pre pre(uint64_t) const { return Pre(); }
-    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o, Pre) const { out[o] = (uint32_t)k; }
-};
-
-// val = (extra hash bits << vbits) | index: the bits of the u32 payload the index does not need carry more
-// hash bits, so that most false collisions of the 32-bit sort key are rejected without touching ukey.
-__global__ __launch_bounds__(256) void k_group_hashes(const KL kl, const uint64_t *__restrict__ ukey,
-                                                      const uint32_t *__restrict__ cand_idx, uint64_t n_cand,
-                                                      uint32_t vbits, uint32_t *__restrict__ hash,
-                                                      uint32_t *__restrict__ val) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_cand; j += stride) {
-        const uint32_t k = cand_idx[j];
+// Candidates are sorted by a 32-bit hash of their group (four passes over 8-byte pairs); members of a group are
+// then adjacent inside a run of equal hashes (27 bits in three 9-bit passes were tried: the sort got 0.5 ms faster and
+// k_low_support 0.6 ms slower on its longer runs).  val = (extra hash bits << vbits) | index: the bits of the u32 payload the
+// index does not need carry more hash bits, so that most false collisions of the sort key are rejected without touching
+// ukey; every comparison re-checks the exact (barcode, library, UMI) anyway.
+#define LS_HASH_BITS 32u
+struct EmitHash {  // emit of the candidate compaction: (hash, val) of candidate k straight from its key
+    KL kl;
+    const uint64_t *ukey;
+    uint32_t vbits;
+    uint32_t *hash, *val;
+    typedef uint64_t Pre;
+    __device__ __forceinline__ Pre pre(uint64_t k) const { return ukey[k]; }
+    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o, Pre key) const {
         // the high half of the mix: independent of the low bits the candidate filter consumed
-        const uint64_t g = mix64(group_id(kl, ukey[k]) ^ 0x9E3779B97F4A7C15ull);
-        hash[j] = (uint32_t)g;
+        const uint64_t g = mix64(group_id(kl, key) ^ 0x9E3779B97F4A7C15ull);
+        hash[o] = LS_HASH_BITS >= 32u ? (uint32_t)g : ((uint32_t)g & ((1u << (LS_HASH_BITS & 31u)) - 1u));
         const uint32_t extra = vbits >= 32u ? 0u : ((uint32_t)(g >> 32) << vbits);
-        val[j] = extra | k;
+        val[o] = extra | (uint32_t)k;
     }
-}
+};
 
 __global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint32_t *__restrict__ hash,
                                                      const uint32_t *__restrict__ val, uint64_t n_cand, uint64_t nd,
                                                      uint32_t vbits,
                                                      const uint64_t *__restrict__ ukey,
                                                      const uint32_t *__restrict__ upos, uint64_t n_keys,
-                                                     const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc1,
-                                                     uint8_t *__restrict__ low) {
+                                                     uint16_t *__restrict__ st) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_cand; j += stride) {
         const uint32_t h = hash[j];
@@ -729,13 +749,15 @@ __global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint32_t
         const uint32_t me = my_val & vmask;
         const uint64_t g = group_id(kl, ukey[me]);
         // counts after moving ONE read of each corrected key (mark_dups.rs:226-232); zero-count keys stay
-        const uint32_t my_c1 = run_count(upos, nd, n_keys, me) - (corr[me] != NONE32 ? 1u : 0u) + inc1[me];
+        const uint32_t my_s = st[me];
+        const uint32_t my_c1 = run_count(upos, nd, n_keys, me) - ((my_s & ST_CORRECTED) ? 1u : 0u) + st_inc1(my_s);
         uint32_t mx = my_c1, n_members = 0, n_max = 0;
         for (uint64_t t = s; t < e; t++) {
             if (((val[t] ^ my_val) & ~vmask) != 0u) continue;  // differs in the extra hash bits
             const uint32_t k = val[t] & vmask;
             if (group_id(kl, ukey[k]) != g) continue;  // hash collision: a different group
-            const uint32_t c1 = run_count(upos, nd, n_keys, k) - (corr[k] != NONE32 ? 1u : 0u) + inc1[k];
+            const uint32_t ks = st[k];
+            const uint32_t c1 = run_count(upos, nd, n_keys, k) - ((ks & ST_CORRECTED) ? 1u : 0u) + st_inc1(ks);
             n_members++;
             if (c1 > mx) {
                 mx = c1;
@@ -746,7 +768,7 @@ __global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint32_t
         }
         if (n_members < 2) continue;
         // low iff below the group's maximum, or the maximum is shared (mark_dups.rs:96-106)
-        if (my_c1 < mx || n_max >= 2) low[me] = 1;
+        if (my_c1 < mx || n_max >= 2) st_or(st, me, ST_LOW);
     }
 }
 
@@ -790,27 +812,30 @@ struct __attribute__((aligned(4))) DupRec {
 __global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ vals,
                                                   const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
                                                   const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc_all,
-                                                  const uint8_t *__restrict__ low,
-                                                  const unsigned long long *__restrict__ minraw,
+                                                  const uint16_t *__restrict__ st, const uint32_t *__restrict__ minidx,
                                                   const uint32_t *__restrict__ rep_read, DupRec *__restrict__ packed) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
         const uint32_t b = upos[k], e = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
-        const uint32_t K = corr[k] != NONE32 ? corr[k] : (uint32_t)k;  // the key this run's reads land on
+        const bool corrected = (st[k] & ST_CORRECTED) != 0u;
+        const uint32_t K = corrected ? corr[k] : (uint32_t)k;  // the key this run's reads land on
+        const uint32_t sK = st[K];
         const uint32_t endK = (uint64_t)K + 1 < nd ? upos[K + 1] : (uint32_t)n_keys;
         const uint32_t cntK = endK - upos[K];
-        const uint32_t read_count = (corr[K] == NONE32 ? cntK : 0u) + inc_all[K];  // umigene_counts[corrected_key]
+        const bool is_target = st_inc1(sK) != 0u;
+        const uint32_t read_count = ((sK & ST_CORRECTED) ? 0u : cntK) + (is_target ? inc_all[K] : 0u);  // umigene_counts[corrected_key]
         const uint32_t umi = (uint32_t)((ukey[K] >> kl.sh_umi) & lowmask(kl.bits_umi));
-        const unsigned long long mr = minraw[K];
-        const uint32_t rep_key = mr != ~0ull ? (uint32_t)(mr & 0xFFFFFFFFull) : K;  // umigene_min_key[corrected_key]
+        const uint32_t mi = is_target ? minidx[K] : NONE32;
+        const uint32_t rep_key = mi != NONE32 ? mi : K;  // umigene_min_key[corrected_key]
         const uint32_t rep = rep_read[rep_key];
-        const uint8_t base = (uint8_t)(CRGPU_DUP_HAS | (corr[k] != NONE32 ? CRGPU_DUP_CORRECTED : 0) |
-                                       (low[K] ? CRGPU_DUP_LOW_SUPPORT : 0));
+        const bool lowK = (sK & ST_LOW) != 0u;
+        const uint8_t base = (uint8_t)(CRGPU_DUP_HAS | (corrected ? CRGPU_DUP_CORRECTED : 0) |
+                                       (lowK ? CRGPU_DUP_LOW_SUPPORT : 0));
         for (uint32_t i = b; i < e; i++) {
             const uint32_t r = vals[i];
             // one 12-byte store per read: the position of a read in sorted order has nothing to do with its ordinal,
             // and three separate scattered stores cost three partial-line writes per read (38 GB per 200 M reads)
-            packed[r] = DupRec{umi, read_count, (uint32_t)(base | ((!low[K] && r == rep) ? CRGPU_DUP_UMI_COUNT : 0))};
+            packed[r] = DupRec{umi, read_count, (uint32_t)(base | ((!lowK && r == rep) ? CRGPU_DUP_UMI_COUNT : 0))};
         }
     }
 }
@@ -834,11 +859,11 @@ __global__ __launch_bounds__(256) void k_unpack_dupinfo(const DupRec *__restrict
 // key of umi_corrections.  Corrections are rare (the UMI error rate), so these are few scattered atomics.
 __global__ __launch_bounds__(256) void k_corrected_reads(const KL kl, const uint64_t *__restrict__ ukey,
                                                          const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
-                                                         const uint32_t *__restrict__ corr, uint32_t W,
+                                                         const uint16_t *__restrict__ st, uint32_t W,
                                                          uint32_t *__restrict__ tab) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
-        if (corr[k] == NONE32) continue;
+        if (!(st[k] & ST_CORRECTED)) continue;
         const uint64_t key = ukey[k];
         const uint32_t run = (k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys) - upos[k];
         const uint32_t lib = (uint32_t)((key >> kl.sh_lib) & lowmask(kl.bits_lib));
@@ -989,27 +1014,26 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     CR_TRY(read_u32(ctx, d_total, &nd32));
     const uint64_t nd = nd32;
 
-    // 3. UMI correction + the read moves
-    DevBuf corr_b, inc1_b, incall_b, low_b, minraw_b;
-    CR_TRY(dmalloc(ctx, minraw_b, nd * sizeof(unsigned long long)));
-    CR_TRY(dmalloc(ctx, corr_b, nd * sizeof(uint32_t)));
-    CR_TRY(dmalloc(ctx, inc1_b, nd * sizeof(uint32_t)));
+    // 3. UMI correction + the read moves (state layout: umi_correct.h)
+    DevBuf corr_b, incall_b, st_b, minidx_b;
+    const uint64_t st_bytes = ((nd + 1) & ~1ull) * sizeof(uint16_t) + 4;
+    CR_TRY(dmalloc(ctx, minidx_b, nd * sizeof(uint32_t)));
+    CR_TRY(dmalloc(ctx, corr_b, nd * sizeof(uint32_t)));   // written (and valid) only where st says "corrected"
     CR_TRY(dmalloc(ctx, incall_b, nd * sizeof(uint32_t)));
-    CR_TRY(dmalloc(ctx, low_b, nd));
-    uint32_t *corr = corr_b.as<uint32_t>(), *inc1 = inc1_b.as<uint32_t>(), *inc_all = incall_b.as<uint32_t>();
-    uint8_t *low = low_b.as<uint8_t>();
+    CR_TRY(dmalloc(ctx, st_b, st_bytes));
+    uint32_t *corr = corr_b.as<uint32_t>(), *inc_all = incall_b.as<uint32_t>(), *minidx = minidx_b.as<uint32_t>();
+    uint16_t *st = st_b.as<uint16_t>();
     {
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        CR_HIP(ctx, hipMemsetAsync(inc1, 0, nd * sizeof(uint32_t), ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(inc_all, 0, nd * sizeof(uint32_t), ctx->stream));
-        CR_HIP(ctx, hipMemsetAsync(low, 0, nd, ctx->stream));
-        CR_HIP(ctx, hipMemsetAsync(minraw_b.p, 0xFF, nd * sizeof(unsigned long long), ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(st, 0, st_bytes, ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(minidx, 0xFF, nd * sizeof(uint32_t), ctx->stream));
         const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
         DevBuf heads_b;  // per tile: first / last segment head
         CR_TRY(dmalloc(ctx, heads_b, 2 * n_tiles * sizeof(uint32_t)));
         uint32_t *tile_first = heads_b.as<uint32_t>(), *tile_last = tile_first + n_tiles;
         hipLaunchKernelGGL(k_correct_umis_tiled, dim3(cr_grid(n_tiles, 1, 256u * 4u)), dim3(256), 0, ctx->stream, kl, ukey,
-                           upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all);
+                           upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all);
         if (n_tiles > 1) {
             const size_t lds_small = (2 * UES_CAP + UES_BUCKETS * 8) * sizeof(uint32_t);
             const size_t lds_large = (2 * UE_CAP + UE_BUCKETS * 8) * sizeof(uint32_t);
@@ -1025,10 +1049,10 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             unsigned long long *best = best_b.as<unsigned long long>();
             CR_HIP(ctx, hipMemsetAsync(n_giant, 0, sizeof(uint32_t), ctx->stream));
             hipLaunchKernelGGL(k_correct_umis_edges<true>, dim3(cr_grid(n_tiles - 1, 1, 256u * 6u)), dim3(UES_THREADS),
-                               lds_small, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all,
+                               lds_small, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all,
                                items, n_giant);
             hipLaunchKernelGGL(k_correct_umis_edges<false>, dim3(cr_grid(n_tiles - 1, 1, 256u * 2u)), dim3(UE_THREADS),
-                               lds_large, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, inc1, inc_all,
+                               lds_large, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all,
                                items, n_giant);
             // the three kernels loop over the device-side item count (usually a few hundred, often zero)
             hipLaunchKernelGGL(k_giant_init, dim3(512), dim3(UE_THREADS), 0, ctx->stream, kl, ukey, upos, nd, n_keys, items,
@@ -1036,19 +1060,20 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             hipLaunchKernelGGL(k_giant_probe, dim3(512), dim3(UE_THREADS), lds_large, ctx->stream, kl, ukey, upos, nd, n_keys,
                                items, n_giant, best);
             hipLaunchKernelGGL(k_giant_final, dim3(512), dim3(UE_THREADS), 0, ctx->stream, upos, nd, n_keys, items, n_giant, best,
-                               corr, inc1, inc_all);
+                               corr, st, inc_all);
         }
-        hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256 * 8)), dim3(256), 0, ctx->stream, kl, ukey, nd, corr,
-                           minraw_b.as<unsigned long long>());
+        hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256 * 8)), dim3(256), 0, ctx->stream, ukey, nd, corr, st, minidx);
         CR_HIP(ctx, hipGetLastError());
     }
 
     // 4. low support: candidate keys (UMI seen under several features of a barcode) -> grouped by
     //    (barcode, library, UMI) through a 32-bit hash sort -> exact comparison of the phase-1 counts
     {
-        DevBuf cand_b, cidx_b;
+        DevBuf cand_b, h_b, v_b;
         CR_TRY(dmalloc(ctx, cand_b, nd));
-        CR_TRY(dmalloc(ctx, cidx_b, nd * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, h_b, nd * sizeof(uint32_t)));   // room for every key; the candidates are ~1/5 of them
+        CR_TRY(dmalloc(ctx, v_b, nd * sizeof(uint32_t)));
+        const uint32_t vbits = cr_ceil_log2(nd ? nd : 1);  // bits the distinct-key index needs inside the payload
         uint32_t n_cand32 = 0;
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
@@ -1056,32 +1081,23 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             hipLaunchKernelGGL(k_group_candidates, dim3(cr_grid(n_ftiles, 1, 256u * 2u)), dim3(LF_THREADS), 0, ctx->stream, kl, ukey,
                                nd, cand_b.as<uint8_t>());
             CR_HIP(ctx, hipGetLastError());
-            CR_TRY(compact(ctx, CandFlag{cand_b.as<uint8_t>()}, EmitIdx{cidx_b.as<uint32_t>()}, nd, d_block, d_total));
+            CR_TRY(compact(ctx, CandFlag{cand_b.as<uint8_t>()}, EmitHash{kl, ukey, vbits, h_b.as<uint32_t>(), v_b.as<uint32_t>()}, nd,
+                           d_block, d_total));
         }
         CR_TRY(read_u32(ctx, d_total, &n_cand32));
         const uint64_t n_cand = n_cand32;
         if (n_cand >= 2) {
-            const uint32_t vbits = cr_ceil_log2(nd ? nd : 1);  // bits the distinct-key index needs inside the payload
-            DevBuf h_b, ht_b, v_b, vt_b;
-            CR_TRY(dmalloc(ctx, h_b, n_cand * sizeof(uint32_t)));
+            DevBuf ht_b, vt_b;
             CR_TRY(dmalloc(ctx, ht_b, n_cand * sizeof(uint32_t)));
-            CR_TRY(dmalloc(ctx, v_b, n_cand * sizeof(uint32_t)));
             CR_TRY(dmalloc(ctx, vt_b, n_cand * sizeof(uint32_t)));
-            {
-                CrTimer t(ctx, CRGPU_T_DEDUP);
-                hipLaunchKernelGGL(k_group_hashes, dim3(cr_grid(n_cand, 256)), dim3(256), 0, ctx->stream, kl, ukey,
-                                   cidx_b.as<uint32_t>(), n_cand, vbits, h_b.as<uint32_t>(), v_b.as<uint32_t>());
-                CR_HIP(ctx, hipGetLastError());
-            }
             bool s_in_tmp = false;
             CR_TRY(cr_radix_sort_u32(ctx, h_b.as<uint32_t>(), ht_b.as<uint32_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(), n_cand,
-                                     0, 32, &s_in_tmp));
+                                     0, LS_HASH_BITS, &s_in_tmp));
             {
                 CrTimer t(ctx, CRGPU_T_DEDUP);
                 hipLaunchKernelGGL(k_low_support, dim3(cr_grid(n_cand, 256)), dim3(256), 0, ctx->stream, kl,
                                    s_in_tmp ? ht_b.as<uint32_t>() : h_b.as<uint32_t>(),
-                                   s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), n_cand, nd, vbits, ukey, upos, n_keys,
-                                   corr, inc1, low);
+                                   s_in_tmp ? vt_b.as<uint32_t>() : v_b.as<uint32_t>(), n_cand, nd, vbits, ukey, upos, n_keys, st);
                 CR_HIP(ctx, hipGetLastError());
             }
         }
@@ -1094,9 +1110,8 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     uint32_t nm32 = 0;
     {
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        CR_TRY(compact(ctx, MolFlag{corr, inc1, low},
-                       EmitMol{ukey, upos, corr, inc_all, minraw_b.as<unsigned long long>(), n_keys, nd, mkeys_b.as<uint64_t>(),
-                               mreads_b.as<uint32_t>()}, nd,
+        CR_TRY(compact(ctx, MolFlag{st},
+                       EmitMol{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()}, nd,
                        d_block, d_total));
     }
     CR_TRY(read_u32(ctx, d_total, &nm32));
@@ -1113,7 +1128,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
                            rep_b.as<uint32_t>());
         hipLaunchKernelGGL(k_per_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys, corr,
-                           inc_all, low, minraw_b.as<unsigned long long>(), rep_b.as<uint32_t>(), packed_b.as<DupRec>());
+                           inc_all, st, minidx, rep_b.as<uint32_t>(), packed_b.as<DupRec>());
         hipLaunchKernelGGL(k_unpack_dupinfo, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream, packed_b.as<DupRec>(),
                            pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
         CR_HIP(ctx, hipGetLastError());
@@ -1126,7 +1141,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_corr_reads, bytes));
         CrTimer t(ctx, CRGPU_T_DEDUP);
         CR_HIP(ctx, hipMemsetAsync(res->d_corr_reads, 0, bytes, ctx->stream));
-        hipLaunchKernelGGL(k_corrected_reads, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, corr,
+        hipLaunchKernelGGL(k_corrected_reads, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, st,
                            ctx->n_canon, res->d_corr_reads);
         CR_HIP(ctx, hipGetLastError());
     }

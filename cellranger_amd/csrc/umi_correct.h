@@ -1,5 +1,5 @@
 // umi_correct.h -- UMI correction kernels (correct_umis, tx_annotation/src/mark_dups.rs:19-59).
-// Included by dedup.hip after KL / lowmask / segment_bounds / run_count are defined.
+// Included by dedup.hip after KL / lowmask / segment_bounds / run_count and the per-key state helpers (st_*) are defined.
 //
 // For every distinct key (barcode, feature, library, UMI) with read count c: among the EXISTING keys of
 // the same (barcode, feature, library) segment whose UMI is exactly one base away, pick the maximum by
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
                                                             uint64_t n_keys, uint32_t *__restrict__ tile_first,
                                                             uint32_t *__restrict__ tile_last, uint32_t *__restrict__ corr,
-                                                            uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all) {
+                                                            uint16_t *__restrict__ st, uint32_t *__restrict__ inc_all) {
     __shared__ uint32_t s_umi[UC_TILE];
     __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
     __shared__ uint16_t s_start[UC_TILE];  // segment start inside the tile, UC_OPEN = not fully inside the tile
@@ -297,11 +297,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
                                                                               s_umi[p], my_cnt, sp);
                 if (bp != p) target = (uint32_t)(t0 + bp);
             }
-            corr[k] = target;
-            if (target != NONE32) {
-                atomicAdd(&inc1[target], 1u);          // phase 1 moves one read (mark_dups.rs:228-232)
-                atomicAdd(&inc_all[target], my_cnt);   // phases 1+2 move them all (:242-246)
-            }
+            if (target != NONE32) move_reads(corr, st, inc_all, k, target, my_cnt);
         }
         __syncthreads();
         if (s_any_long) {
@@ -318,7 +314,7 @@ template <bool SMALL>
 __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
     const KL kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
     const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_last, uint32_t *__restrict__ corr,
-    uint32_t *__restrict__ inc1, uint32_t *__restrict__ inc_all, GiantItem *__restrict__ giant_items,
+    uint16_t *__restrict__ st, uint32_t *__restrict__ inc_all, GiantItem *__restrict__ giant_items,
     uint32_t *__restrict__ n_giant) {
     constexpr uint32_t UE_T = EdgeCfg<SMALL>::THREADS, CAP = EdgeCfg<SMALL>::CAP, BUCKETS = EdgeCfg<SMALL>::BUCKETS,
                        POSBITS = EdgeCfg<SMALL>::POSBITS;
@@ -352,10 +348,7 @@ __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
         const uint64_t m = e - s;
         if (SMALL ? m > UES_CAP : m <= UES_CAP) continue;  // the other instantiation's segment
         const uint32_t lib = (uint32_t)((ukey[s] >> kl.sh_lib) & lowmask(kl.bits_lib));
-        if ((kl.mux_mask >> lib) & 1u) {  // UmiCorrection::Disable (aligner.rs:315-318)
-            for (uint64_t k = s + tid; k < e; k += UE_T) corr[k] = NONE32;
-            continue;
-        }
+        if ((kl.mux_mask >> lib) & 1u) continue;  // UmiCorrection::Disable (aligner.rs:315-318): nothing moves
         if (m <= CAP) {
             const uint32_t mm = (uint32_t)m;
             const bool use_hash = mm > UC_SMALL;
@@ -376,12 +369,7 @@ __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
                 const uint32_t my_cnt = s_cnt[p];
                 const uint32_t bp = best_neighbour_lds<BUCKETS, POSBITS>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p,
                                                                               s_umi[p], my_cnt, sp);
-                const uint32_t target = bp != p ? (uint32_t)(s + bp) : NONE32;
-                corr[s + p] = target;
-                if (target != NONE32) {
-                    atomicAdd(&inc1[target], 1u);
-                    atomicAdd(&inc_all[target], my_cnt);
-                }
+                if (bp != p) move_reads(corr, st, inc_all, s + p, (uint32_t)(s + bp), my_cnt);
             }
             __syncthreads();
             continue;
@@ -493,7 +481,7 @@ __global__ __launch_bounds__(UE_THREADS) void k_giant_final(const uint32_t *__re
                                                             const GiantItem *__restrict__ items,
                                                             const uint32_t *__restrict__ n_items_ptr,
                                                             const unsigned long long *__restrict__ best,
-                                                            uint32_t *__restrict__ corr, uint32_t *__restrict__ inc1,
+                                                            uint32_t *__restrict__ corr, uint16_t *__restrict__ st,
                                                             uint32_t *__restrict__ inc_all) {
     const uint32_t n_items = *n_items_ptr;
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -501,11 +489,7 @@ __global__ __launch_bounds__(UE_THREADS) void k_giant_final(const uint32_t *__re
         const uint64_t c1 = (uint64_t)g.c0 + UE_CAP < g.e ? (uint64_t)g.c0 + UE_CAP : g.e;
         for (uint64_t k = g.c0 + threadIdx.x; k < c1; k += UE_THREADS) {
             const uint32_t target = (uint32_t)best[k];
-            corr[k] = target != (uint32_t)k ? target : NONE32;
-            if (target != (uint32_t)k) {
-                atomicAdd(&inc1[target], 1u);
-                atomicAdd(&inc_all[target], run_count(upos, nd, n_keys, k));
-            }
+            if (target != (uint32_t)k) move_reads(corr, st, inc_all, k, target, run_count(upos, nd, n_keys, k));
         }
     }
 }
