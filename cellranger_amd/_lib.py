@@ -119,6 +119,11 @@ class SynthOut(C.Structure):
     ]
 
 
+class BcCorrectionMetrics(C.Structure):
+    _fields_ = [("valid_reads", C.c_uint64), ("corrected_reads", C.c_uint64), ("barcodes_detected", C.c_uint64),
+                ("effective_barcode_diversity", C.c_double)]
+
+
 # every symbol include/crgpu.h declares: (restype, argtypes)
 _vp, _u8p, _u32, _u64, _i, _dbl = C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
 SYMBOLS = {
@@ -163,6 +168,8 @@ SYMBOLS = {
     "crgpu_set_counts": (_i, [_vp, _i, _i, _vp]),
     "crgpu_reset_counts": (_i, [_vp]),
     "crgpu_counts_dev": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "crgpu_barcode_correction_metrics": (_i, [_vp, _i, C.POINTER(BcCorrectionMetrics)]),
+    "crgpu_total_barcode_counts": (_i, [_vp, C.c_int64, _vp, _vp, _u64, C.POINTER(_u64)]),
     "crgpu_match_and_count": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
     "crgpu_correct": (_i, [_vp, _i, _vp, _vp, _u64, _vp, _vp]),
     "crgpu_set_key_layout": (_i, [_vp, _u32, _u32, _u32, _u32]),

@@ -251,6 +251,69 @@ extern "C" int crgpu_reset_counts(crgpu_ctx *ctx) {
     return CRGPU_OK;
 }
 
+// ---- BARCODE_CORRECTION join outputs derived from the tables (barcode_correction.rs:372-448) ------------------------------
+// Bookkeeping over 2 x n_libs tables of n_canon u32 (a few MB): done on the host after one download per table.
+extern "C" int crgpu_barcode_correction_metrics(crgpu_ctx *ctx, int lib, crgpu_bc_correction_metrics *out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, lib >= 0 && lib < CRGPU_MAX_LIB && ctx->wl[lib].set, CRGPU_ESTATE, "library %d has no whitelist", lib);
+    const uint32_t W = ctx->n_canon;
+    std::vector<uint32_t> v(W), c(W);
+    CR_TRY(crgpu_memcpy_d2h(ctx, v.data(), ctx->wl[lib].d_valid, sizeof(uint32_t) * W));
+    CR_TRY(crgpu_memcpy_d2h(ctx, c.data(), ctx->wl[lib].d_corrected, sizeof(uint32_t) * W));
+    memset(out, 0, sizeof(*out));
+    // effective_diversity (metric/src/histogram.rs:161-171) sums f64 over a HashMap in arbitrary order; here the sums are
+    // exact integers converted once (the reference's own result varies in the last bits with its iteration order)
+    unsigned __int128 s2 = 0;
+    uint64_t s = 0;
+    for (uint32_t r = 0; r < W; r++) {
+        out->valid_reads += v[r];
+        out->corrected_reads += c[r];
+        const uint64_t t = (uint64_t)v[r] + c[r];  // bc_counts_corrected = raw valid merged with corrected (:401-404)
+        if (t) {
+            out->barcodes_detected++;
+            s += t;
+            s2 += (unsigned __int128)t * t;
+        }
+    }
+    out->effective_barcode_diversity = s2 ? ((double)s * (double)s) / (double)s2 : 0.0 / 0.0;  // 0/0 = NaN as in the reference
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_total_barcode_counts(crgpu_ctx *ctx, int64_t min_reads_to_report_bc, uint32_t *rank_out, uint64_t *count_out,
+                                          uint64_t cap, uint64_t *n_out) {
+    if (!ctx || !n_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_total_barcode_counts: no whitelist set");
+    const uint32_t W = ctx->n_canon;
+    std::vector<uint64_t> corr(W, 0), total(W, 0);
+    std::vector<uint32_t> tmp(W);
+    for (int l = 0; l < CRGPU_MAX_LIB; l++) {
+        if (!ctx->wl[l].set) continue;
+        // join (:380-390): every library's raw valid counts, each filtered by the threshold on its own
+        CR_TRY(crgpu_memcpy_d2h(ctx, tmp.data(), ctx->wl[l].d_valid, sizeof(uint32_t) * W));
+        for (uint32_t r = 0; r < W; r++)
+            if ((int64_t)tmp[r] >= min_reads_to_report_bc) total[r] += tmp[r];
+        // chunk (:345,360): the barcodes of the corrected reads, all libraries in one histogram
+        CR_TRY(crgpu_memcpy_d2h(ctx, tmp.data(), ctx->wl[l].d_corrected, sizeof(uint32_t) * W));
+        for (uint32_t r = 0; r < W; r++) corr[r] += tmp[r];
+    }
+    uint64_t n = 0;
+    for (uint32_t r = 0; r < W; r++) {
+        if (corr[r] && (int64_t)corr[r] >= min_reads_to_report_bc) total[r] += corr[r];
+        if (!total[r]) continue;
+        if (rank_out && count_out && n < cap) {
+            rank_out[n] = r;
+            count_out[n] = total[r];
+        }
+        n++;
+    }
+    *n_out = n;
+    CR_REQUIRE(ctx, !(rank_out && count_out) || n <= cap, CRGPU_ERANGE, "crgpu_total_barcode_counts: %llu barcodes, room for %llu",
+               (unsigned long long)n, (unsigned long long)cap);
+    return CRGPU_OK;
+}
+
 // fill the device views used by the kernels
 int cr_make_views(crgpu_ctx *ctx, WlView *views) {
     for (int l = 0; l < CRGPU_MAX_LIB; l++) {

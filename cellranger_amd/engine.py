@@ -457,6 +457,21 @@ class Context:
         self._check(self.L.crgpu_counts_dev(self.h, lib, which, C.byref(p)))
         return p.value
 
+    def barcode_correction_metrics(self, lib=0):
+        """BARCODE_CORRECTION summary pieces of one library (barcode_correction.rs:409-448) as a dict"""
+        m = _lib.BcCorrectionMetrics()
+        self._check(self.L.crgpu_barcode_correction_metrics(self.h, lib, C.byref(m)))
+        return {f: getattr(m, f) for f, _ in _lib.BcCorrectionMetrics._fields_}
+
+    def total_barcode_counts(self, min_reads_to_report_bc=1000):
+        """(ranks, counts) of total_barcode_counts restricted to whitelist barcodes (barcode_correction.rs:360,380-390)"""
+        n = C.c_uint64()
+        self._check(self.L.crgpu_total_barcode_counts(self.h, min_reads_to_report_bc, None, None, 0, C.byref(n)))
+        ranks, counts = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint64)
+        if n.value:
+            self._check(self.L.crgpu_total_barcode_counts(self.h, min_reads_to_report_bc, ptr(ranks), ptr(counts), n.value, C.byref(n)))
+        return ranks, counts
+
     def match_and_count_host(self, lib, seq_ascii, qual):
         s = ascii_matrix(seq_ascii)
         q = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)

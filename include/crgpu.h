@@ -224,6 +224,27 @@ int crgpu_reset_counts(crgpu_ctx *ctx);
 /* device pointer of the table, for collectives issued by the host (RCCL all-reduce of the prior) */
 int crgpu_counts_dev(crgpu_ctx *ctx, int lib, int which, uint32_t **d_out);
 
+/* ---- BARCODE_CORRECTION's join outputs (cr_lib/src/stages/barcode_correction.rs:372-448) ---------------------------------
+ * crgpu_barcode_correction_metrics: what the stage's summary is made of, per library, from the VALID + CORRECTED tables:
+ *   valid_reads / corrected_reads   the numerators of good_bc and corrected_bc (barcode_correction_metrics.rs:17-38,66-87:
+ *                                   corrected_bc = corrected / all reads, good_bc = (valid + corrected) / all reads; the
+ *                                   caller knows "all reads" of the library, reads that stay invalid are in no table),
+ *   barcodes_detected, effective_barcode_diversity   BarcodeDiversityMetrics over bc_counts_corrected (:418-435;
+ *                                   inverse Simpson index, metric/src/histogram.rs:161-171).
+ * crgpu_total_barcode_counts: the total_barcode_counts histogram restricted to whitelist barcodes -- per barcode the sum of
+ *   every library's raw valid count that reaches min_reads_to_report_bc (the join, :380-390) and of the corrected reads
+ *   of all libraries when THEY reach it (the chunk's histogram, :345,360; the CORRECTED tables of the context count as one
+ *   chunk: call per chunk and add up to follow a chunked run exactly).  Sequences that stay invalid (and are reported by
+ *   the reference when one of them occurs min_reads times inside a chunk) are not covered: they are in no table.
+ *   Ascending ranks; rank_out / count_out may be NULL to get *n_out only. */
+typedef struct {
+    uint64_t valid_reads, corrected_reads, barcodes_detected;
+    double effective_barcode_diversity;
+} crgpu_bc_correction_metrics;
+int crgpu_barcode_correction_metrics(crgpu_ctx *ctx, int lib, crgpu_bc_correction_metrics *out);
+int crgpu_total_barcode_counts(crgpu_ctx *ctx, int64_t min_reads_to_report_bc, uint32_t *rank_out, uint64_t *count_out,
+                               uint64_t cap, uint64_t *n_out);
+
 /* ---- collectives between the ranks of one GEM well ---------------------------------------------------
  * All of them are collective calls: every rank of the communicator must make the same call in the same order.  They run
  * on the context's stream (RCCL) and return when the result is usable by the next crgpu call.

@@ -112,6 +112,19 @@ def _compare_barcode_stage(w, n, first=0, threshold=0.975, max_err=None):
                           G.hist_as_rank_counts(res.corrected_hist[0], w.cb_len, canon_sorted))
     stats = dict(valid=int((res.bc_state == 1).sum()), corrected=int((res.bc_state == 2).sum()),
                  invalid=int((res.bc_state == 0).sum()))
+    # BARCODE_CORRECTION's join outputs (barcode_correction.rs:372-448) from the same tables
+    v = G.hist_as_rank_counts(res.valid_hist[0], w.cb_len, canon_sorted).astype(np.uint64)
+    cc = G.hist_as_rank_counts(res.corrected_hist[0], w.cb_len, canon_sorted).astype(np.uint64)
+    m = c.barcode_correction_metrics(0)
+    assert m["valid_reads"] == stats["valid"] and m["corrected_reads"] == stats["corrected"]
+    t = v + cc
+    assert m["barcodes_detected"] == int((t > 0).sum())
+    exp_div = float(int(t.sum())) ** 2 / float(sum(int(x) * int(x) for x in t[t > 0]))   # inverse Simpson index
+    assert abs(m["effective_barcode_diversity"] - exp_div) <= 1e-12 * exp_div
+    for thr in (1, 25, 1000):
+        ranks, counts = c.total_barcode_counts(thr)
+        exp = np.where(v >= thr, v, 0) + np.where(cc >= thr, cc, 0)
+        assert np.array_equal(ranks, np.nonzero(exp)[0].astype(np.uint32)) and np.array_equal(counts, exp[exp > 0])
     c.close()
     return stats
 
