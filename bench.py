@@ -266,9 +266,6 @@ def main():
     pipe = CountPipeline(be, libs=(0,))
     dup_out = None
     if args.dupinfo and workload == "cfg3":
-        if world > 1:
-            sys.stderr.write("bench.py: --dupinfo is a single-GPU measurement\n")
-            sys.exit(2)
         dup_out = (ctx.empty(n, np.uint32), ctx.empty(n, np.uint32), ctx.empty(n, np.uint8))
 
     def step():
@@ -276,16 +273,8 @@ def main():
         if workload == "cfg2":
             pipe.correct_barcodes(shard)
             return None
-        if dup_out is not None:
-            # the drop-in's path: per-read DupInfo for the UB / duplicate-flag / xf tags (tx_annotation/src/read.rs:536-590)
-            pipe.correct_barcodes(shard)
-            recs = ctx.records(n, w.umi_len, shard["idx"], shard["umi"], shard["umi_qualn"], shard["feature"], shard["flags"])
-            counts = ctx.count_records(recs, *dup_out)
-            b, f, c = counts.triplets_dev()
-            m = ctx.assemble_matrix_dev(b, f, c, counts.n_triplets)
-            be._keep.extend([counts])
-            return m
-        return pipe.run(shard)
+        # dup_out: the drop-in's path -- per-read DupInfo for the UB / duplicate-flag / xf tags (tx_annotation/src/read.rs:536-590)
+        return pipe.run(shard, dupinfo=dup_out)
 
     def sync():
         ctx.synchronize()

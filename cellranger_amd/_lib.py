@@ -178,6 +178,7 @@ SYMBOLS = {
     "crgpu_balanced_bounds": (_i, [_vp, _u32, _vp]),
     "crgpu_count_keys_dev": (_i, [_vp, _vp, _u64, C.POINTER(_vp)]),
     "crgpu_count_records_dev": (_i, [_vp, C.POINTER(Records), C.POINTER(_vp), _vp, _vp, _vp]),
+    "crgpu_count_records_sharded_dev": (_i, [_vp, C.POINTER(Records), C.POINTER(_vp), _vp, _vp, _vp]),
     "crgpu_counts_info": (_i, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "crgpu_counts_triplets_dev": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "crgpu_counts_triplets": (_i, [_vp, _vp, _vp, _vp, _vp]),

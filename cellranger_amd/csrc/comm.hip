@@ -303,6 +303,14 @@ static int comm_alltoallv(crgpu_ctx *ctx, const void *d_send, const uint64_t *se
     return CRGPU_OK;
 }
 
+int cr_comm_allgather_u64(crgpu_ctx *ctx, const uint64_t *mine, uint32_t k, uint64_t *all_out) {
+    return comm_allgather_u64(ctx, mine, k, all_out);
+}
+int cr_comm_alltoallv(crgpu_ctx *ctx, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
+                      const uint64_t *recv_off, const uint64_t *recv_bytes) {
+    return comm_alltoallv(ctx, d_send, send_off, send_bytes, d_recv, recv_off, recv_bytes);
+}
+
 // ---- entry points ----------------------------------------------------------------------------------------------------------
 extern "C" int crgpu_barrier(crgpu_ctx *ctx) {
     if (!ctx) return CRGPU_EINVAL;

@@ -74,6 +74,23 @@ static KL make_kl(const KeyLayout &L) {
 }
 __device__ __forceinline__ uint64_t lowmask(uint32_t bits) { return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull); }
 
+struct DevBuf {  // pooled temporary, returned to the context's pool at scope exit
+    crgpu_ctx *ctx = nullptr;
+    void *p = nullptr;
+    ~DevBuf() { cr_pool_free(ctx, p); }
+    template <typename T>
+    T *as() { return (T *)p; }
+};
+
+static int dmalloc(crgpu_ctx *ctx, DevBuf &b, uint64_t bytes) {
+    b.ctx = ctx;
+    return cr_pool_alloc(ctx, &b.p, bytes);
+}
+
+static int read_u32(crgpu_ctx *ctx, const uint32_t *d, uint32_t *h) {
+    return crgpu_memcpy_d2h(ctx, h, d, sizeof(uint32_t));
+}
+
 // ------------------------------------------------------------------------------------------------
 // build keys (compacting)
 // ------------------------------------------------------------------------------------------------
@@ -84,15 +101,25 @@ template <int LQW>
 struct __attribute__((aligned(4))) QRow {
     uint32_t w[LQW ? LQW : 1];
 };
-template <int LQW, bool HIST>
+// ORDERED (the keys travel with their read ordinals: the DupInfo paths): the compaction keeps the read order -- chunks
+// are handed out by a ticket counter and get their output offset from a decoupled look-back over `status` (one word
+// per chunk: flag in the top two bits, 1 = this chunk's count, 2 = inclusive prefix), so equal keys leave in qname
+// order.  The sharded path relies on it: the owner of a barcode sees only the position of a key in its receive buffer.
+// Without ORDERED a chunk reserves its space with one atomic and the chunks land in arrival order.
+#define BK_AGG (1ull << 62)
+#define BK_INC (2ull << 62)
+template <int LQW, bool HIST, bool ORDERED = false>
 __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t *__restrict__ bc_idx,
                                                     const uint32_t *__restrict__ umi, const uint8_t *__restrict__ umi_q,
                                                     const uint32_t *__restrict__ feature, const uint8_t *__restrict__ flags,
                                                     uint64_t n, uint64_t *__restrict__ keys_out,
                                                     uint32_t *__restrict__ vals_out,
                                                     unsigned long long *__restrict__ n_out, const SweepPlan plan,
-                                                    uint32_t *__restrict__ ghist) {
+                                                    uint32_t *__restrict__ ghist, unsigned long long *__restrict__ status,
+                                                    uint32_t *__restrict__ ticket) {
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
+    __shared__ unsigned long long s_c;  // ORDERED: the chunk of this round, then its output offset
+    __shared__ uint32_t s_ws[KEY_ITEMS * 4];  // ORDERED: kept keys of (item slot, wave), then their exclusive prefix
     // ghist != NULL: the digits of every emitted key are counted for all passes of the sort that follows, which
     // then needs no histogram read of its own (k_global_hist)
     __shared__ uint32_t s_hist[HIST ? OS_MAX_PASSES * RADIX_MAX : 1];
@@ -104,7 +131,14 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
     const uint64_t chunk = 256ull * KEY_ITEMS;
     const uint64_t n_chunks = (n + chunk - 1) / chunk;
     const uint32_t umi_mask = (uint32_t)lowmask(kl.bits_umi), adj_mask = (uint32_t)lowmask(kl.bits_umi - 2u);
-    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    for (uint64_t c = blockIdx.x;; c += gridDim.x) {
+      if (ORDERED) {
+          if (threadIdx.x == 0) s_c = atomicAdd(ticket, 1u);
+          __syncthreads();
+          c = s_c;
+          __syncthreads();
+      }
+      if (c >= n_chunks) break;  // uniform
       uint64_t keys[KEY_ITEMS];
       uint32_t mask = 0;
 #pragma unroll
@@ -162,15 +196,68 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                     atomicAdd(&s_hist[p * RADIX_MAX + ((uint32_t)(keys[j] >> plan.shift[p]) & plan.mask[p])], 1u);
         }
       }
-      // one global atomic per 4096-read chunk (same-address atomics saturate near 88 per microsecond)
-      unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_out, lds);
+      if (ORDERED) {
+          // stable inside the chunk, too: output order = (item slot, wave, lane) = ascending read index
+          uint32_t below[KEY_ITEMS];
+          const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
-      for (int j = 0; j < KEY_ITEMS; j++)
-        if (mask & (1u << j)) {
-            keys_out[o] = keys[j];
-            if (vals_out) vals_out[o] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);  // read ordinal
-            o++;
-        }
+          for (int j = 0; j < KEY_ITEMS; j++) {
+              const unsigned long long m = __ballot((mask >> j) & 1u);
+              below[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+              if (lane == 0) s_ws[j * 4 + wave] = (uint32_t)__popcll(m);
+          }
+          __syncthreads();
+          if (threadIdx.x < KEY_ITEMS * 4) {  // one wave: exclusive scan of the 64 (slot, wave) counts
+              const uint32_t v = s_ws[threadIdx.x];
+              uint32_t x = v;
+#pragma unroll
+              for (int d = 1; d < KEY_ITEMS * 4; d <<= 1) {
+                  const uint32_t y = __shfl_up(x, d);
+                  if (threadIdx.x >= (uint32_t)d) x += y;
+              }
+              s_ws[threadIdx.x] = x - v;
+              if (threadIdx.x == KEY_ITEMS * 4 - 1) {
+                  const uint32_t total = x;
+                  unsigned long long excl = 0;
+                  if (c > 0) {
+                      __hip_atomic_store(&status[c], BK_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      // every lower ticket is held by a workgroup that is running or done: the chain always moves on
+                      for (uint64_t p = c - 1;; p--) {
+                          unsigned long long sv;
+                          do {
+                              sv = __hip_atomic_load(&status[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                              if ((sv >> 62) == 0ull) __builtin_amdgcn_s_sleep(1);
+                          } while ((sv >> 62) == 0ull);
+                          excl += sv & (BK_AGG - 1ull);
+                          if ((sv >> 62) == 2ull) break;
+                      }
+                  }
+                  __hip_atomic_store(&status[c], BK_INC | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (c + 1 == n_chunks) *n_out = excl + total;
+                  s_c = excl;
+              }
+          }
+          __syncthreads();
+          const unsigned long long base = s_c;
+#pragma unroll
+          for (int j = 0; j < KEY_ITEMS; j++)
+              if (mask & (1u << j)) {
+                  const unsigned long long o = base + s_ws[j * 4 + wave] + below[j];
+                  keys_out[o] = keys[j];
+                  if (vals_out) vals_out[o] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);  // read ordinal
+              }
+          __syncthreads();
+      } else {
+          // one global atomic per 4096-read chunk (same-address atomics saturate near 88 per microsecond)
+          unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_out, lds);
+#pragma unroll
+          for (int j = 0; j < KEY_ITEMS; j++)
+              if (mask & (1u << j)) {
+                  keys_out[o] = keys[j];
+                  if (vals_out) vals_out[o] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);  // read ordinal
+                  o++;
+              }
+      }
     }
     if (HIST) {
         __syncthreads();
@@ -211,13 +298,30 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
             CR_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t), ctx->stream));
         }
         const dim3 grid(cr_grid(recs->n, 256, d_hist ? 1024u : 256u * 8u));
+        // with ordinals: order-preserving compaction (tickets + look-back status, one word per 4096-read chunk)
+        DevBuf status_b;
+        unsigned long long *d_status = nullptr;
+        uint32_t *d_ticket = ctx->d_scalars + 44;
+        if (d_vals_out) {
+            const uint64_t n_chunks = (recs->n + 256ull * KEY_ITEMS - 1) / (256ull * KEY_ITEMS);
+            CR_TRY(dmalloc(ctx, status_b, n_chunks * sizeof(unsigned long long)));
+            d_status = status_b.as<unsigned long long>();
+            CR_HIP(ctx, hipMemsetAsync(d_status, 0, n_chunks * sizeof(unsigned long long), ctx->stream));
+            CR_HIP(ctx, hipMemsetAsync(d_ticket, 0, sizeof(uint32_t), ctx->stream));
+        }
 #define CR_BUILD_KEYS(LQW)                                                                                                  \
-    if (d_hist)                                                                                                             \
+    if (d_vals_out)                                                                                                         \
+        hipLaunchKernelGGL((k_build_keys<LQW, false, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, \
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
+                           d_status, d_ticket);                                                                             \
+    else if (d_hist)                                                                                                        \
         hipLaunchKernelGGL((k_build_keys<LQW, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,     \
-                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist); \
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
+                           d_status, d_ticket);                                                                             \
     else                                                                                                                    \
         hipLaunchKernelGGL((k_build_keys<LQW, false>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,    \
-                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist)
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
+                           d_status, d_ticket)
         switch (recs->umi_len) {
             case 4: CR_BUILD_KEYS(1); break;
             case 8: CR_BUILD_KEYS(2); break;
@@ -937,29 +1041,13 @@ struct EmitSummary {
     }
 };
 
-struct DevBuf {  // pooled temporary, returned to the context's pool at scope exit
-    crgpu_ctx *ctx = nullptr;
-    void *p = nullptr;
-    ~DevBuf() { cr_pool_free(ctx, p); }
-    template <typename T>
-    T *as() { return (T *)p; }
-};
-
-static int dmalloc(crgpu_ctx *ctx, DevBuf &b, uint64_t bytes) {
-    b.ctx = ctx;
-    return cr_pool_alloc(ctx, &b.p, bytes);
-}
-
-static int read_u32(crgpu_ctx *ctx, const uint32_t *d, uint32_t *h) {
-    return crgpu_memcpy_d2h(ctx, h, d, sizeof(uint32_t));
-}
-
 struct PerRead {
     bool summary = false;        // keep the per-barcode corrected-read table for crgpu_counts_barcode_summary
     uint64_t n_reads = 0;        // entries of the output arrays
     uint32_t *d_vals = nullptr;  // read ordinal of every key (sorted along with the keys)
     uint32_t *out_umi = nullptr, *out_cnt = nullptr;
     uint8_t *out_flags = nullptr;
+    struct DupRec *packed_out = nullptr;  // non-NULL: leave the packed 12-byte records here (n_reads entries), no unpacking
 };
 
 static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out, PerRead pr) {
@@ -1121,16 +1209,18 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     if (vals) {
         DevBuf rep_b, packed_b;
         CR_TRY(dmalloc(ctx, rep_b, nd * sizeof(uint32_t)));
-        CR_TRY(dmalloc(ctx, packed_b, pr.n_reads * sizeof(DupRec)));
+        if (!pr.packed_out) CR_TRY(dmalloc(ctx, packed_b, pr.n_reads * sizeof(DupRec)));
+        DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
         CrTimer t(ctx, CRGPU_T_DEDUP);
         // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): all-zero records
-        CR_HIP(ctx, hipMemsetAsync(packed_b.p, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(packed, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
         hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
                            rep_b.as<uint32_t>());
         hipLaunchKernelGGL(k_per_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys, corr,
-                           inc_all, st, minidx, rep_b.as<uint32_t>(), packed_b.as<DupRec>());
-        hipLaunchKernelGGL(k_unpack_dupinfo, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream, packed_b.as<DupRec>(),
-                           pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
+                           inc_all, st, minidx, rep_b.as<uint32_t>(), packed);
+        if (!pr.packed_out)
+            hipLaunchKernelGGL(k_unpack_dupinfo, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream, packed, pr.n_reads,
+                               pr.out_umi, pr.out_cnt, pr.out_flags);
         CR_HIP(ctx, hipGetLastError());
     }
 
@@ -1212,6 +1302,117 @@ extern "C" int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs
         if (d_dupflags_out) CR_HIP(ctx, hipMemsetAsync(d_dupflags_out, 0, n, ctx->stream));
     }
     return count_keys_impl(ctx, keys_b.as<uint64_t>(), n_keys, out, pr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one GEM well on several GPUs, with per-read DupInfo (SURVEY 8e + mark_dups.rs:61-72)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_iota_u32(uint32_t *p, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (uint32_t)i;
+}
+// the records that came back from the owners, in the order of this rank's partitioned keys -> the reads they belong to
+__global__ __launch_bounds__(256) void k_scatter_dupinfo(const DupRec *__restrict__ rec, const uint32_t *__restrict__ ordinal,
+                                                         uint64_t n_keys, uint32_t *__restrict__ out_umi,
+                                                         uint32_t *__restrict__ out_cnt, uint8_t *__restrict__ out_flags) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_keys; j += stride) {
+        const DupRec d = rec[j];
+        const uint32_t r = ordinal[j];
+        if (out_umi) out_umi[r] = d.umi;
+        if (out_cnt) out_cnt[r] = d.read_count;
+        if (out_flags) out_flags[r] = (uint8_t)d.flags;
+    }
+}
+
+// Collective.  Every rank passes its shard of the well's records (contiguous slices of the read stream in rank order:
+// the qname rank of a read is its position in that stream) and gets back (a) the counts of the barcode range it owns,
+// as crgpu_exchange_keys_dev + crgpu_count_keys_dev would give them, and (b) the DupInfo of ITS OWN reads:
+//   keys + ordinals -> stable partition by owner -> keys to the owners (C2) -> dedup there with the position in the
+//   receive buffer as ordinal (source-rank-major, stable == the well's read order) -> the packed 12-byte records travel
+//   back along the same routes -> scattered to the reads by the ordinals that stayed at home.
+extern "C" int crgpu_count_records_sharded_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
+                                               uint32_t *d_processed_umi_out, uint32_t *d_read_count_out,
+                                               uint8_t *d_dupflags_out) {
+    if (!ctx || !recs || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    *out = nullptr;
+    cr_invalidate(ctx);
+    CR_REQUIRE(ctx, recs->n <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_records_sharded: at most 2^31-1 records per call");
+    const uint64_t n = recs->n;
+    const int W = ctx->n_ranks;
+    DevBuf keys_b, vals_b, pkeys_b, pvals_b, recv_b, rrec_b, brec_b, iota_b;
+    CR_TRY(dmalloc(ctx, keys_b, (n ? n : 1) * sizeof(uint64_t)));
+    CR_TRY(dmalloc(ctx, vals_b, (n ? n : 1) * sizeof(uint32_t)));
+    uint64_t n_keys = 0;
+    CR_TRY(build_keys_impl(ctx, recs, keys_b.as<uint64_t>(), vals_b.as<uint32_t>(), &n_keys));
+    // C2 with the ordinals kept at home
+    std::vector<uint32_t> bounds(W + 1);
+    CR_TRY(crgpu_balanced_bounds(ctx, (uint32_t)W, bounds.data()));
+    CR_TRY(dmalloc(ctx, pkeys_b, (n_keys ? n_keys : 1) * sizeof(uint64_t)));
+    CR_TRY(dmalloc(ctx, pvals_b, (n_keys ? n_keys : 1) * sizeof(uint32_t)));
+    std::vector<uint64_t> send_cnt(W, 0), all((size_t)W * W, 0);
+    CR_TRY(cr_partition_by_owner_kv(ctx, keys_b.as<uint64_t>(), pkeys_b.as<uint64_t>(), vals_b.as<uint32_t>(), pvals_b.as<uint32_t>(),
+                                    n_keys, ctx->layout.sh_bc(), (uint32_t)W, bounds.data(), send_cnt.data()));
+    CR_TRY(cr_comm_allgather_u64(ctx, send_cnt.data(), (uint32_t)W, all.data()));
+    std::vector<uint64_t> soff(W), sbytes(W), roff(W), rbytes(W);
+    uint64_t n_recv = 0, so = 0;
+    for (int p = 0; p < W; p++) {
+        soff[p] = so;
+        sbytes[p] = send_cnt[p];
+        so += send_cnt[p];
+        roff[p] = n_recv;
+        rbytes[p] = all[(size_t)p * W + ctx->rank];
+        n_recv += rbytes[p];
+    }
+    CR_REQUIRE(ctx, n_recv <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_records_sharded: this rank would own %llu keys (> 2^31-1)",
+               (unsigned long long)n_recv);
+    auto scaled = [&](const std::vector<uint64_t> &v, uint64_t f) {
+        std::vector<uint64_t> o(v.size());
+        for (size_t i = 0; i < v.size(); i++) o[i] = v[i] * f;
+        return o;
+    };
+    CR_TRY(dmalloc(ctx, recv_b, (n_recv ? n_recv : 1) * sizeof(uint64_t)));
+    {
+        CrTimer t(ctx, CRGPU_T_COMM, n_keys);
+        CR_TRY(cr_comm_alltoallv(ctx, pkeys_b.p, scaled(soff, 8).data(), scaled(sbytes, 8).data(), recv_b.p, scaled(roff, 8).data(),
+                                 scaled(rbytes, 8).data()));
+        CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // dedup of the owned range; the records of the received keys come back packed, in receive order
+    CR_TRY(dmalloc(ctx, rrec_b, (n_recv ? n_recv : 1) * sizeof(DupRec)));
+    CR_TRY(dmalloc(ctx, iota_b, (n_recv ? n_recv : 1) * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_iota_u32, dim3(cr_grid(n_recv ? n_recv : 1, 256)), dim3(256), 0, ctx->stream, iota_b.as<uint32_t>(), n_recv);
+    PerRead pr;
+    pr.summary = true;
+    pr.n_reads = n_recv;
+    pr.d_vals = iota_b.as<uint32_t>();
+    pr.packed_out = rrec_b.as<DupRec>();
+    CR_TRY(count_keys_impl(ctx, recv_b.as<uint64_t>(), n_recv, out, pr));
+    // the records travel home along the reversed routes
+    CR_TRY(dmalloc(ctx, brec_b, (n_keys ? n_keys : 1) * sizeof(DupRec)));
+    {
+        CrTimer t(ctx, CRGPU_T_COMM, n_recv);
+        const uint64_t rs = sizeof(DupRec);
+        int rc = cr_comm_alltoallv(ctx, rrec_b.p, scaled(roff, rs).data(), scaled(rbytes, rs).data(), brec_b.p, scaled(soff, rs).data(),
+                                   scaled(sbytes, rs).data());
+        if (rc == CRGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "sync failed");
+        if (rc != CRGPU_OK) {
+            crgpu_counts_free(ctx, *out);
+            *out = nullptr;
+            return rc;
+        }
+    }
+    CrTimer t(ctx, CRGPU_T_DEDUP);
+    if (d_processed_umi_out) CR_HIP(ctx, hipMemsetAsync(d_processed_umi_out, 0, n * sizeof(uint32_t), ctx->stream));
+    if (d_read_count_out) CR_HIP(ctx, hipMemsetAsync(d_read_count_out, 0, n * sizeof(uint32_t), ctx->stream));
+    if (d_dupflags_out) CR_HIP(ctx, hipMemsetAsync(d_dupflags_out, 0, n, ctx->stream));
+    if (n_keys)
+        hipLaunchKernelGGL(k_scatter_dupinfo, dim3(cr_grid(n_keys, 256)), dim3(256), 0, ctx->stream, brec_b.as<DupRec>(),
+                           pvals_b.as<uint32_t>(), n_keys, d_processed_umi_out, d_read_count_out, d_dupflags_out);
+    CR_HIP(ctx, hipGetLastError());
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the temporaries above go back to the pool
+    return CRGPU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -712,8 +712,9 @@ int cr_radix_sort_u32(crgpu_ctx *ctx, uint32_t *d_keys, uint32_t *d_tmp, uint32_
 }
 
 // Stable partition of keys by the owner rank of their barcode: one counting-sort pass.
-int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
-                          uint32_t n_ranks, const uint32_t *bounds, uint64_t *counts_out) {
+// d_vin / d_vout (nullable): a 32-bit payload (the read ordinals) that travels with the keys
+int cr_partition_by_owner_kv(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, const uint32_t *d_vin, uint32_t *d_vout,
+                             uint64_t n, uint32_t sh_bc, uint32_t n_ranks, const uint32_t *bounds, uint64_t *counts_out) {
     CR_REQUIRE(ctx, n_ranks >= 1 && n_ranks <= RADIX, CRGPU_EINVAL, "partition: n_ranks must be 1..256");
     CR_REQUIRE(ctx, n <= 0x7FFFFFFFull, CRGPU_ERANGE, "partition: at most 2^31-1 keys per call");
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = 0;
@@ -727,14 +728,19 @@ int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out,
         uint32_t *d_bounds = ctx->d_scalars + 760;  // 257 u32 inside the 1024-word scalar page
         CR_HIP(ctx, hipMemcpyAsync(d_bounds, bounds, (n_ranks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's array may be a temporary
-        CR_TRY((radix_pass<uint64_t, OwnerBounds>(ctx, d_in, d_out, nullptr, nullptr, n, OwnerBounds{sh_bc, n_ranks, d_bounds})));
+        CR_TRY((radix_pass<uint64_t, OwnerBounds>(ctx, d_in, d_out, d_vin, d_vout, n, OwnerBounds{sh_bc, n_ranks, d_bounds})));
     } else {
         // rank r owns canonical barcode ranks [r*width, (r+1)*width)
         const uint32_t width = (ctx->n_canon + n_ranks - 1) / n_ranks;
-        CR_TRY((radix_pass<uint64_t, OwnerDiv>(ctx, d_in, d_out, nullptr, nullptr, n, OwnerDiv{sh_bc, width ? width : 1u})));
+        CR_TRY((radix_pass<uint64_t, OwnerDiv>(ctx, d_in, d_out, d_vin, d_vout, n, OwnerDiv{sh_bc, width ? width : 1u})));
     }
     uint32_t totals[RADIX];
     CR_TRY(crgpu_memcpy_d2h(ctx, totals, digit_totals_buf(ctx), sizeof(totals)));
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = totals[r];
     return CRGPU_OK;
+}
+
+int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
+                          uint32_t n_ranks, const uint32_t *bounds, uint64_t *counts_out) {
+    return cr_partition_by_owner_kv(ctx, d_in, d_out, nullptr, nullptr, n, sh_bc, n_ranks, bounds, counts_out);
 }

@@ -528,6 +528,13 @@ class Context:
                                                    _p(d_dupflags)))
         return Counts(self, h)
 
+    def count_records_sharded(self, recs, d_processed_umi=None, d_read_count=None, d_dupflags=None):
+        """collective: dedup of one well sharded over the ranks, DupInfo of this rank's own reads (crgpu.h)"""
+        h = C.c_void_p()
+        self._check(self.L.crgpu_count_records_sharded_dev(self.h, C.byref(recs), C.byref(h), _p(d_processed_umi), _p(d_read_count),
+                                                           _p(d_dupflags)))
+        return Counts(self, h)
+
     def enable_barcode_summary(self, on=True):
         """count_keys keeps what Counts.barcode_summary needs (count_records always does)"""
         self._check(self.L.crgpu_enable_barcode_summary(self.h, int(bool(on))))

@@ -82,6 +82,16 @@ class HipBackend:
         self._keep.append(counts)
         return counts
 
+    def count_records(self, shard, dupinfo, sharded):
+        """dedup straight from the records with per-read DupInfo (processed UMI, read count, flags) for THIS rank's reads;
+        sharded: the well is spread over the ranks (crgpu_count_records_sharded_dev), else this rank holds all of it"""
+        recs = self.ctx.records(shard["n"], shard["umi_len"], shard["idx"], shard["umi"], shard["umi_qualn"],
+                                shard["feature"], shard.get("flags"))
+        f = self.ctx.count_records_sharded if sharded else self.ctx.count_records
+        counts = f(recs, *dupinfo)
+        self._keep.append(counts)
+        return counts
+
     def triplet_arrays(self, counts):
         return counts.triplets_dev()
 
@@ -160,15 +170,19 @@ class CountPipeline:
         m = self.be.assemble(b, f, c, counts.n_triplets)
         return self.be.gather_wells(m)
 
-    def run(self, shard):
-        """Full path.  Returns the device CSC on rank 0 (None elsewhere)."""
+    def run(self, shard, dupinfo=None):
+        """Full path.  Returns the device CSC on rank 0 (None elsewhere).  dupinfo: three device arrays of shard['n']
+        entries (processed UMI u32, read count u32, flags u8) that receive the DupInfo of this rank's reads."""
         self.correct_barcodes(shard)
         if self.collective:
             self.be.allreduce_hist(self.libs, COUNTS_CORRECTED)   # matrix columns = barcodes seen on ANY rank
-        keys, n_keys = self.be.build_keys(shard)
-        if self.collective:
-            keys, n_keys = self.be.exchange_keys(keys, n_keys)
-        counts = self.be.count_keys(keys, n_keys)
+        if dupinfo is not None:
+            counts = self.be.count_records(shard, dupinfo, sharded=self.collective)
+        else:
+            keys, n_keys = self.be.build_keys(shard)
+            if self.collective:
+                keys, n_keys = self.be.exchange_keys(keys, n_keys)
+            counts = self.be.count_keys(keys, n_keys)
         if not self.collective:
             b, f, c = self.be.triplet_arrays(counts)
             return self.be.assemble(b, f, c, counts.n_triplets)

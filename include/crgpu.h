@@ -334,6 +334,15 @@ int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys
 #define CRGPU_DUP_UMI_COUNT 0x08u    /* DupInfo::is_umi_count: the representative read of its molecule */
 int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
                             uint32_t *d_processed_umi_out, uint32_t *d_read_count_out, uint8_t *d_dupflags_out);
+/* The same for ONE GEM well sharded over the ranks of the context's communicator (collective).  Every rank
+ * passes its shard -- contiguous slices of the well's read stream in rank order, so that a read's qname rank is its
+ * position in that stream -- and receives (a) *out: the counts of the barcode range it owns (as crgpu_exchange_keys_dev +
+ * crgpu_count_keys_dev give them; gather the triplets with crgpu_gather_triplets_dev) and (b) the DupInfo arrays of ITS
+ * OWN reads: the keys go to the owners of their barcodes with their order kept, the owners dedup with the position in
+ * the receive buffer as qname rank, and the packed per-read records travel back along the same routes.  The VALID and
+ * CORRECTED tables must have been all-reduced (the owner ranges are derived from them on every rank). */
+int crgpu_count_records_sharded_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
+                                    uint32_t *d_processed_umi_out, uint32_t *d_read_count_out, uint8_t *d_dupflags_out);
 int crgpu_counts_info(crgpu_ctx *ctx, const crgpu_counts *c, uint64_t *n_triplets, uint64_t *n_molecules);
 /* C3 (see "collectives"): root receives every rank's triplets concatenated in rank order; the three arrays are
  * library-owned (crgpu_free each); on the other ranks they come back NULL with *n_total_out = 0. */

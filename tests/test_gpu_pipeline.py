@@ -227,3 +227,76 @@ def test_four_host_threads_share_one_context():
     assert not errors, errors
     assert len(expect[0][0]) > 100
     c.close()
+
+
+def test_sharded_well_returns_every_reads_dupinfo_to_its_rank():
+    """crgpu_count_records_sharded_dev on three thread-ranks: the per-read DupInfo each rank gets back for ITS OWN reads
+    (processed UMI, read count, corrected / low-support / umi-count flags: what the unchanged host needs for the UB /
+    duplicate-flag / xf tags, tx_annotation/src/read.rs:536-590) equals the single-process oracle's on the whole well,
+    read by read, and the gathered triplets give the oracle's matrix."""
+    import threading
+
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import COUNTS_CORRECTED, COUNTS_VALID
+
+    world, per = 3, 100_000
+    n = world * per
+    w = S.Workload(n_total=n, seed=47, n_wl=40_000, n_cells=120, n_ambient=3000, n_genes=300, umi_len=8, umi_err=0.02)
+    r_all = w.host_reads(0, n)
+    gid = E.local_group_id(world)
+    outs, errors = [None] * world, []
+
+    def worker(rank):
+        c = None
+        try:
+            c = E.Context(0, n_ranks=world, rank=rank, unique_id=gid)
+            c.trust_unchanged_buffers(True)
+            c.set_whitelist(0, w.wl_packed, length=16)
+            c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+            r = {k: v[rank * per:(rank + 1) * per] for k, v in r_all.items()}
+            sh = _make_shard(c, w, r, per)
+            c.match_and_count(sh["cb"], sh["flags"], per, sh["idx"])
+            c.allreduce_counts(-1, COUNTS_VALID)
+            c.correct(sh["cb"], sh["cb_qualn"], sh["flags"], per, sh["idx"])
+            c.allreduce_counts(-1, COUNTS_CORRECTED)
+            recs = c.records(per, w.umi_len, sh["idx"], sh["umi"], sh["umi_qualn"], sh["feature"], sh["flags"])
+            d_pu, d_rc, d_fl = c.empty(per, np.uint32), c.empty(per, np.uint32), c.empty(per, np.uint8)
+            counts = c.count_records_sharded(recs, d_pu, d_rc, d_fl)
+            arrs, total = c.gather_triplets(counts)
+            m = None
+            if rank == 0:
+                m = c.assemble_matrix_dev(arrs[0], arrs[1], arrs[2], total).download()
+            outs[rank] = (c, d_pu.to_host(), d_rc.to_host(), d_fl.to_host(), m, c.canon_order()[1])
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            if c is not None:
+                c.close()
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not errors, errors
+    res = O.run_pipeline(G.oracle_reads_from_packed(r_all, w.cb_len, w.umi_len), [O.Whitelist(E.unpack_seqs(w.wl_packed, 16))],
+                         n_threads=4, want_dupinfo=True)
+    od = res.dupinfo
+    pu = np.concatenate([o[1] for o in outs])
+    rc = np.concatenate([o[2] for o in outs])
+    fl = np.concatenate([o[3] for o in outs])
+    has = od["has_dupinfo"] != 0
+    assert np.array_equal((fl & 1) != 0, has)
+    assert np.array_equal((fl & 2) != 0, od["is_corrected"] != 0)
+    assert np.array_equal((fl & 4) != 0, od["is_low_support"] != 0)
+    assert np.array_equal((fl & 8) != 0, od["is_umi_count"] != 0)
+    assert np.array_equal(pu[has], od["processed_umi"][has]) and np.array_equal(rc[has], od["read_count"][has])
+    assert not pu[~has].any() and not rc[~has].any()
+    assert int(((fl & 2) != 0).sum()) > 100 and int(((fl & 8) != 0).sum()) > 10_000
+    rank_, indptr, indices, data = outs[0][4]
+    assert np.array_equal(E.unpack_seqs(outs[0][5][rank_], 16), res.barcodes)
+    assert np.array_equal(indptr, res.indptr) and np.array_equal(indices, res.indices) and np.array_equal(data, res.data)
+    for o in outs:
+        o[0].close()
