@@ -195,6 +195,8 @@ SYMBOLS = {
     "crgpu_concat_matrices": (_i, [_vp, _vp, _vp, _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_write_mtx": (_i, [_vp, C.POINTER(MatrixView), C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint16]),
     "crgpu_assemble_matrix_dev": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(MatrixDevView))]),
+    "crgpu_sum_matrices_dev": (_i, [_vp, C.POINTER(MatrixDevView), C.POINTER(MatrixDevView), C.POINTER(C.POINTER(MatrixDevView))]),
+    "crgpu_select_barcodes_dev": (_i, [_vp, C.POINTER(MatrixDevView), _vp, _u64, C.POINTER(C.POINTER(MatrixDevView))]),
     "crgpu_matrix_dev_free": (None, [_vp, C.POINTER(MatrixDevView)]),
     "crgpu_matrix_dev_download": (_i, [_vp, C.POINTER(MatrixDevView), _vp, _vp, _vp, _vp]),
     "crgpu_count": (_i, [_vp, C.POINTER(Records), _u32, C.POINTER(C.POINTER(MatrixView))]),

@@ -1526,6 +1526,192 @@ extern "C" int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, c
     return CRGPU_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// aggr-style post-processing on the device
+// ------------------------------------------------------------------------------------------------
+// merge of two index-sorted columns; WRITE = false counts the merged entries
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_sum_columns(uint64_t n_cols, const long long *__restrict__ pa, const int32_t *__restrict__ ia,
+                                                     const int32_t *__restrict__ da, const long long *__restrict__ pb,
+                                                     const int32_t *__restrict__ ib, const int32_t *__restrict__ db,
+                                                     uint32_t *__restrict__ cnt, const uint32_t *__restrict__ off,
+                                                     int32_t *__restrict__ io, int32_t *__restrict__ dout) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += stride) {
+        long long i = pa[c], j = pb[c];
+        const long long ie = pa[c + 1], je = pb[c + 1];
+        uint32_t o = WRITE ? off[c] : 0u;
+        while (i < ie || j < je) {
+            const int32_t ra = i < ie ? ia[i] : 0x7FFFFFFF, rb = j < je ? ib[j] : 0x7FFFFFFF;
+            if (WRITE) {
+                io[o] = ra < rb ? ra : rb;
+                dout[o] = (ra <= rb ? da[i] : 0) + (rb <= ra ? db[j] : 0);
+            }
+            o++;
+            i += ra <= rb;
+            j += rb <= ra;
+        }
+        if (!WRITE) cnt[c] = o;
+    }
+}
+__global__ __launch_bounds__(256) void k_ranks_differ(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t n,
+                                                      uint32_t *__restrict__ flag) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (a[i] != b[i]) *flag = 1u;
+}
+__global__ __launch_bounds__(256) void k_offsets_to_indptr(const uint32_t *__restrict__ off, uint64_t n, uint32_t total,
+                                                           long long *__restrict__ indptr) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride)
+        indptr[i] = i < n ? (long long)off[i] : (long long)total;
+}
+__global__ __launch_bounds__(256) void k_selected_lengths(const long long *__restrict__ indptr, const uint64_t *__restrict__ cols,
+                                                          uint64_t n_sel, const uint32_t *__restrict__ rank_in,
+                                                          uint32_t *__restrict__ len, uint32_t *__restrict__ rank_out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_sel; k += stride) {
+        const uint64_t c = cols[k];
+        len[k] = (uint32_t)(indptr[c + 1] - indptr[c]);
+        rank_out[k] = rank_in[c];
+    }
+}
+// one wave per selected column: a contiguous copy of its entries
+__global__ __launch_bounds__(256) void k_copy_columns(const long long *__restrict__ indptr, const uint64_t *__restrict__ cols,
+                                                      uint64_t n_sel, const uint32_t *__restrict__ off,
+                                                      const int32_t *__restrict__ ia, const int32_t *__restrict__ da,
+                                                      int32_t *__restrict__ io, int32_t *__restrict__ dout) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t k = wave0; k < n_sel; k += n_waves) {
+        const uint64_t c = cols[k];
+        const long long s = indptr[c], e = indptr[c + 1];
+        const uint32_t o = off[k];
+        for (long long i = s + lane; i < e; i += 64) {
+            io[o + (i - s)] = ia[i];
+            dout[o + (i - s)] = da[i];
+        }
+    }
+}
+
+static int new_matrix_dev(crgpu_ctx *ctx, uint64_t V, uint64_t nnz, MatrixDevImpl **out) {
+    MatrixDevImpl *m = new (std::nothrow) MatrixDevImpl();
+    if (!m) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
+    int rc = cr_pool_alloc(ctx, (void **)&m->d_rank, (V ? V : 1) * sizeof(uint32_t));
+    if (rc == CRGPU_OK) rc = cr_pool_alloc(ctx, (void **)&m->d_indptr, (V + 1) * sizeof(long long));
+    if (rc == CRGPU_OK) rc = cr_pool_alloc(ctx, (void **)&m->d_indices, (nnz ? nnz : 1) * sizeof(int32_t));
+    if (rc == CRGPU_OK) rc = cr_pool_alloc(ctx, (void **)&m->d_data, (nnz ? nnz : 1) * sizeof(int32_t));
+    if (rc != CRGPU_OK) {
+        crgpu_matrix_dev_free(ctx, &m->view);
+        return rc;
+    }
+    m->view.n_barcodes = V;
+    m->view.nnz = nnz;
+    m->view.d_barcode_rank = m->d_rank;
+    m->view.d_indptr = (const int64_t *)m->d_indptr;
+    m->view.d_indices = m->d_indices;
+    m->view.d_data = m->d_data;
+    *out = m;
+    return CRGPU_OK;
+}
+
+// CountMatrix.merge / merge_matrices (lib/python/cellranger/matrix.py:479-482,1319-1329): element-wise sum of two matrices
+// of the same shape -- here two device CSCs over the same columns (same barcode ranks in the same order).
+extern "C" int crgpu_sum_matrices_dev(crgpu_ctx *ctx, const crgpu_matrix_dev *a, const crgpu_matrix_dev *b, crgpu_matrix_dev **out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    *out = nullptr;
+    CR_REQUIRE(ctx, a && b, CRGPU_EINVAL, "crgpu_sum_matrices_dev: NULL matrix");
+    CR_REQUIRE(ctx, a->n_barcodes == b->n_barcodes, CRGPU_EINVAL, "crgpu_sum_matrices_dev: %llu vs %llu columns",
+               (unsigned long long)a->n_barcodes, (unsigned long long)b->n_barcodes);
+    CR_REQUIRE(ctx, a->nnz + b->nnz < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_sum_matrices_dev: too many entries");
+    const uint64_t V = a->n_barcodes;
+    uint32_t *d_flag = ctx->d_scalars + 48, *d_total = ctx->d_scalars + 16;
+    DevBuf cnt_b;
+    CR_TRY(dmalloc(ctx, cnt_b, (V + 1) * sizeof(uint32_t)));
+    uint32_t *cnt = cnt_b.as<uint32_t>();
+    const long long *pa = (const long long *)a->d_indptr, *pb = (const long long *)b->d_indptr;
+    uint32_t differ = 0, total = 0;
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX, a->nnz + b->nnz);
+        CR_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(uint32_t), ctx->stream));
+        if (V) {
+            hipLaunchKernelGGL(k_ranks_differ, dim3(cr_grid(V, 256)), dim3(256), 0, ctx->stream, a->d_barcode_rank, b->d_barcode_rank, V, d_flag);
+            hipLaunchKernelGGL(k_sum_columns<false>, dim3(cr_grid(V, 256)), dim3(256), 0, ctx->stream, V, pa, a->d_indices, a->d_data, pb,
+                               b->d_indices, b->d_data, cnt, (const uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+        }
+        CR_HIP(ctx, hipGetLastError());
+        CR_TRY(cr_scan_small(ctx, cnt, V, d_total));
+    }
+    CR_TRY(read_u32(ctx, d_flag, &differ));
+    CR_REQUIRE(ctx, !differ, CRGPU_EINVAL, "crgpu_sum_matrices_dev: the matrices hold different barcodes");
+    CR_TRY(read_u32(ctx, d_total, &total));
+    MatrixDevImpl *m = nullptr;
+    CR_TRY(new_matrix_dev(ctx, V, total, &m));
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX);
+        if (V) {
+            CR_HIP(ctx, hipMemcpyAsync(m->d_rank, a->d_barcode_rank, V * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_sum_columns<true>, dim3(cr_grid(V, 256)), dim3(256), 0, ctx->stream, V, pa, a->d_indices, a->d_data, pb,
+                               b->d_indices, b->d_data, (uint32_t *)nullptr, cnt, m->d_indices, m->d_data);
+        }
+        hipLaunchKernelGGL(k_offsets_to_indptr, dim3(cr_grid(V + 1, 256)), dim3(256), 0, ctx->stream, cnt, V, total, m->d_indptr);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            crgpu_matrix_dev_free(ctx, &m->view);
+            return cr_fail(ctx, CRGPU_EHIP, "crgpu_sum_matrices_dev: kernel failed");
+        }
+    }
+    *out = &m->view;
+    return CRGPU_OK;
+}
+
+// CountMatrix.select_barcodes (matrix.py:860-875): the columns `cols` (host array of column positions) in the given order.
+extern "C" int crgpu_select_barcodes_dev(crgpu_ctx *ctx, const crgpu_matrix_dev *a, const uint64_t *cols, uint64_t n_cols,
+                                         crgpu_matrix_dev **out) {
+    if (!ctx || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    *out = nullptr;
+    CR_REQUIRE(ctx, a && (cols || n_cols == 0), CRGPU_EINVAL, "crgpu_select_barcodes_dev: NULL argument");
+    for (uint64_t k = 0; k < n_cols; k++)
+        CR_REQUIRE(ctx, cols[k] < a->n_barcodes, CRGPU_EINVAL, "crgpu_select_barcodes_dev: column %llu out of range",
+                   (unsigned long long)cols[k]);
+    DevBuf cols_b, len_b, rank_b;
+    CR_TRY(dmalloc(ctx, cols_b, (n_cols ? n_cols : 1) * sizeof(uint64_t)));
+    CR_TRY(dmalloc(ctx, len_b, (n_cols + 1) * sizeof(uint32_t)));
+    CR_TRY(dmalloc(ctx, rank_b, (n_cols ? n_cols : 1) * sizeof(uint32_t)));
+    uint32_t *d_total = ctx->d_scalars + 16, total = 0;
+    const long long *pa = (const long long *)a->d_indptr;
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX, n_cols);
+        if (n_cols) {
+            CR_HIP(ctx, hipMemcpyAsync(cols_b.p, cols, n_cols * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_selected_lengths, dim3(cr_grid(n_cols, 256)), dim3(256), 0, ctx->stream, pa, cols_b.as<uint64_t>(), n_cols,
+                               a->d_barcode_rank, len_b.as<uint32_t>(), rank_b.as<uint32_t>());
+        }
+        CR_HIP(ctx, hipGetLastError());
+        CR_TRY(cr_scan_small(ctx, len_b.as<uint32_t>(), n_cols, d_total));
+    }
+    CR_TRY(read_u32(ctx, d_total, &total));
+    MatrixDevImpl *m = nullptr;
+    CR_TRY(new_matrix_dev(ctx, n_cols, total, &m));
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX);
+        if (n_cols) {
+            CR_HIP(ctx, hipMemcpyAsync(m->d_rank, rank_b.p, n_cols * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_copy_columns, dim3(cr_grid(n_cols * 64, 256)), dim3(256), 0, ctx->stream, pa, cols_b.as<uint64_t>(), n_cols,
+                               len_b.as<uint32_t>(), a->d_indices, a->d_data, m->d_indices, m->d_data);
+        }
+        hipLaunchKernelGGL(k_offsets_to_indptr, dim3(cr_grid(n_cols + 1, 256)), dim3(256), 0, ctx->stream, len_b.as<uint32_t>(), n_cols,
+                           total, m->d_indptr);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            crgpu_matrix_dev_free(ctx, &m->view);
+            return cr_fail(ctx, CRGPU_EHIP, "crgpu_select_barcodes_dev: kernel failed");
+        }
+    }
+    *out = &m->view;
+    return CRGPU_OK;
+}
+
 extern "C" void crgpu_matrix_dev_free(crgpu_ctx *ctx, crgpu_matrix_dev *mv) {
     if (!mv || !ctx) return;
     CR_ENTER(ctx);

@@ -569,6 +569,19 @@ class Context:
         self._check(self.L.crgpu_select_barcodes(self.h, m._mv, ptr(cols), len(cols), C.byref(mv)))
         return Matrix(self, mv)
 
+    def sum_matrices_dev(self, a, b):
+        """element-wise sum of two device CSCs over the same columns"""
+        mv = C.POINTER(_lib.MatrixDevView)()
+        self._check(self.L.crgpu_sum_matrices_dev(self.h, a._mv, b._mv, C.byref(mv)))
+        return MatrixDev(self, mv)
+
+    def select_barcodes_dev(self, m, cols):
+        """the given columns of a device CSC in the given order"""
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        mv = C.POINTER(_lib.MatrixDevView)()
+        self._check(self.L.crgpu_select_barcodes_dev(self.h, m._mv, ptr(cols), len(cols), C.byref(mv)))
+        return MatrixDev(self, mv)
+
     def concat_matrices(self, mats, gem_groups):
         """merged matrix of several GEM wells: column concatenation in (gem_group, barcode) order"""
         arr = (C.c_void_p * len(mats))(*[C.cast(m._mv, C.c_void_p) for m in mats])

@@ -448,6 +448,14 @@ typedef struct {
 int crgpu_assemble_matrix_dev(crgpu_ctx *ctx, const uint32_t *d_bc, const uint32_t *d_feature, const uint32_t *d_count,
                               uint64_t n_triplets, crgpu_matrix_dev **out);
 void crgpu_matrix_dev_free(crgpu_ctx *ctx, crgpu_matrix_dev *m);
+/* aggr-style post-processing of DEVICE matrices (the host versions are crgpu_sum_matrices / crgpu_select_barcodes):
+ * crgpu_sum_matrices_dev     element-wise sum of two CSCs over the same columns (same barcode ranks in the same order;
+ *                            CountMatrix.merge, lib/python/cellranger/matrix.py:479-482,1319-1329): per column a merge of the
+ *                            two index-sorted entry lists, counted, scanned and written;
+ * crgpu_select_barcodes_dev  the columns at the positions `cols` (host array) in the given order (matrix.py:860-875). */
+int crgpu_sum_matrices_dev(crgpu_ctx *ctx, const crgpu_matrix_dev *a, const crgpu_matrix_dev *b, crgpu_matrix_dev **out);
+int crgpu_select_barcodes_dev(crgpu_ctx *ctx, const crgpu_matrix_dev *a, const uint64_t *cols, uint64_t n_cols,
+                              crgpu_matrix_dev **out);
 /* copy to caller-allocated host arrays (any may be NULL) */
 int crgpu_matrix_dev_download(crgpu_ctx *ctx, const crgpu_matrix_dev *m, uint32_t *rank_out, int64_t *indptr_out,
                               int32_t *indices_out, int32_t *data_out);

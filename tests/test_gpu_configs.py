@@ -186,4 +186,25 @@ def test_aggr_merge_and_barcode_selection_match_scipy():
     assert np.array_equal(sel.data, exp_sel.data) and np.array_equal(sel.barcode_rank, a.barcode_rank[cols])
     with pytest.raises(CrgpuError):
         c.sum_matrices(tot, sel)  # shapes differ
+    # the same two operations on DEVICE matrices (crgpu_sum_matrices_dev / crgpu_select_barcodes_dev)
+    dmats = []
+    for h in range(2):
+        recs = c.records(n, w.umi_len, dev["idx"].ptr + 4 * h * n, d_umi.ptr + 4 * h * n, d_uq.ptr + 12 * h * n,
+                         d_ft.ptr + 4 * h * n, dev["flags"].ptr + h * n)
+        keys = c.empty(n, np.uint64)
+        cnt = c.count_keys(keys, c.build_keys(recs, keys))
+        tb, tf, tc = cnt.triplets_dev()
+        dmats.append((c.assemble_matrix_dev(tb, tf, tc, cnt.n_triplets), cnt))
+    dtot = c.sum_matrices_dev(dmats[0][0], dmats[1][0])
+    rank, indptr, indices, data = dtot.download()
+    assert np.array_equal(rank, a.barcode_rank) and np.array_equal(indptr, exp.indptr)
+    assert np.array_equal(indices, exp.indices) and np.array_equal(data, exp.data)
+    dsel = c.select_barcodes_dev(dtot, cols)
+    rank, indptr, indices, data = dsel.download()
+    assert np.array_equal(rank, a.barcode_rank[cols]) and np.array_equal(indptr, exp_sel.indptr)
+    assert np.array_equal(indices, exp_sel.indices) and np.array_equal(data, exp_sel.data)
+    empty = c.select_barcodes_dev(dtot, np.zeros(0, np.uint64))
+    assert empty.n_barcodes == 0 and empty.nnz == 0
+    with pytest.raises(CrgpuError):
+        c.sum_matrices_dev(dtot, dsel)
     c.close()
