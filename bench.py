@@ -42,7 +42,7 @@ KERNEL_BYTES = {
     "correct": ("k_correct_records", 4, "read: the index every read gets (the misses' 29 B are inside it)"),
     "keys": ("k_build_keys", 33, "record: idx 4 + umi 4 + umi qual 12 + feature 4 + flags 1 in, key 8 out"),
     "sort_scatter": ("k_radix_scatter", 16, "key per pass: 8 B in + 8 B out"),
-    "sort_hist": ("k_radix_hist", 8, "key per pass: 8 B in"),
+    "sort_hist": ("k_finish_runs (+ k_global_hist / k_radix_hist when they run)", 8, "key: 8 B in (the keys that move are written back)"),
     "dedup": ("dedup family (run lengths, UMI correction, low support, molecules, triplets)", 8,
               "sorted key: 8 B in, once (outputs, a few per cent of it, not counted)"),
 }
@@ -367,6 +367,7 @@ def main():
                               "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in ledger.items() if v[1]},
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in ledger.items() if v[1]},
+            "kernel_units_per_step": {k: v[2] / args.steps for k, v in ledger.items() if v[1] and v[2]},
             "output": out_info,
             "host_step_marks_ms": [round((m - t0) * 1e3, 2) for m in step_marks],
         }

@@ -130,6 +130,7 @@ struct crgpu_ctx {
     KeyHistograms ghist;
     std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
+    uint64_t sort_refinished = 0;          // sorts whose finishing pass met a run too long for it and that were redone on all bits
     uint64_t sort_fallbacks = 0;           // sorts whose look-back watchdog fired and that were finished by the classic passes
 
     double max_expected_errors = 1.7976931348623157e308;  // corrector.rs:104 (f64::MAX)
@@ -218,6 +219,8 @@ int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out);
 void cr_drop_miss_records(crgpu_ctx *ctx);
 // sort.hip: the plan radix_sort would use for 64-bit keys on bits [lo_bit, hi_bit); false = onesweep does not apply
 bool cr_sweep_plan(uint32_t lo_bit, uint32_t hi_bit, SweepPlan *plan, uint32_t *widths);
+// low bits of a molecule key of total_bits that the radix passes leave to the finishing pass (0: none)
+uint32_t cr_sort_low_bits(uint32_t total_bits);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel): the attribute is per device
 static inline void cr_allow_lds(crgpu_ctx *ctx, const void *kernel, size_t bytes) {
     if (ctx->lds_attr_done.insert(kernel).second)

@@ -117,6 +117,9 @@ extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
         case CRGPU_STAT_SORT_FALLBACKS:
             *value_out = ctx->sort_fallbacks;
             return CRGPU_OK;
+        case CRGPU_STAT_SORT_REFINISHED:
+            *value_out = ctx->sort_refinished;
+            return CRGPU_OK;
         default:
             return cr_fail(ctx, CRGPU_EINVAL, "crgpu_get_stat: unknown counter %d", which);
     }

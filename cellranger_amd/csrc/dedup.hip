@@ -292,7 +292,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         uint32_t widths[OS_MAX_PASSES];
         memset(&plan, 0, sizeof(plan));
         uint32_t *d_hist = nullptr;
-        if (!d_vals_out && ctx->trust_buffers && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(0, ctx->layout.total_bits(), &plan, widths)) {
+        if (!d_vals_out && ctx->trust_buffers && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(cr_sort_low_bits(ctx->layout.total_bits()), ctx->layout.total_bits(), &plan, widths)) {
             if (!gh.d_hist) CR_TRY(cr_pool_alloc(ctx, (void **)&gh.d_hist, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t)));
             d_hist = gh.d_hist;
             CR_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t), ctx->stream));

@@ -624,6 +624,26 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     return CRGPU_OK;
 }
 
+// Bits of the molecule keys that the radix passes leave to k_finish_runs: with L low bits left out, the passes sort on
+// the top bits only (all 9 bits wide) and the finishing pass orders the short runs of equal top bits in LDS.  L is the
+// largest value <= 16 that makes ceil((total - L) / 9) passes cover the rest: 61 bits -> 5 passes + 16 bits (instead
+// of 7 passes), 64 -> 6 + 10, 50 -> 4 + 14.  0: keys too short to gain a pass, or not switched on.
+// OFF by default (CRGPU_SORT_FINISH=1 turns it on): at 1 B records the five passes take 18.8 ms instead of 25.7, but the
+// finishing pass as a kernel of its own costs 20 ms (3.8 ms for staging the tiles, 5 ms for the run bounds, 11 ms for the
+// ranks inside the long runs of the big (barcode, gene) segments) -- profiles/r02_finish_pass_ab.txt.  It can pay only
+// once it is fused into the run-length pass that reads the sorted keys anyway.
+uint32_t cr_sort_low_bits(uint32_t total_bits) {
+    const char *e = getenv("CRGPU_SORT_FINISH");
+    const bool on = e && atoi(e) == 1;
+    if (!on || !onesweep_enabled() || total_bits <= 27) return 0;
+    const uint32_t p = (total_bits - 16 + 8) / 9;      // passes of 9 bits for the top part
+    if (9 * p >= total_bits) return 0;
+    const uint32_t low = total_bits - 9 * p;          // <= 16 by construction
+    // the classic plan for comparison: only worth it when it saves at least one pass
+    const uint32_t p8 = (total_bits + 7) / 8, p9 = (total_bits + 8) / 9;
+    return p < (p9 < p8 ? p9 : p8) ? low : 0;
+}
+
 bool cr_sweep_plan(uint32_t lo_bit, uint32_t hi_bit, SweepPlan *plan, uint32_t *widths) {
     if (hi_bit <= lo_bit || !onesweep_enabled()) return false;
     const uint32_t total = hi_bit - lo_bit;
@@ -646,6 +666,135 @@ bool cr_sweep_plan(uint32_t lo_bit, uint32_t hi_bit, SweepPlan *plan, uint32_t *
     return true;
 }
 
+// ---- finishing pass: order the runs of equal top bits by their low bits ---------------------------------------------
+// After the radix passes on bits [low, total) the keys are sorted by their top bits and stable otherwise.  Runs of equal
+// top bits are short (keys of one (barcode, feature, library) whose UMIs share their leading bases, mostly copies of one
+// key), so every key finds its place by counting the keys of its run that precede it (by low bits, ties by position:
+// exactly the order the full stable sort produces).  A workgroup takes the whole runs whose head lies in its tile of
+// FIN_TILE keys, stages tile + halo in LDS with one coalesced load (no dependent global loads) and writes back only the
+// keys that move.  A run longer than FIN_HALO raises *fallback and its tile writes nothing: the host then sorts the
+// buffer, still a permutation of the keys, again on all bits.
+#define FIN_TILE 4096u
+#define FIN_HALO 1024u     // keys staged behind the tile: the runs that begin in the tile end in there, or the sort is redone
+#define FIN_CAP (1u + FIN_TILE + FIN_HALO)
+template <bool HAS_VALS>
+__global__ __launch_bounds__(256) void k_finish_runs(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n,
+                                                     uint32_t low_bits, uint32_t *__restrict__ fallback) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *sk = reinterpret_cast<uint64_t *>(smem);                                       // FIN_CAP keys
+    uint16_t *spos = reinterpret_cast<uint16_t *>(smem + (size_t)FIN_CAP * 8);              // where each key belongs
+    uint32_t *sv = reinterpret_cast<uint32_t *>(smem + (size_t)FIN_CAP * 8 + ((FIN_CAP * 2 + 15) & ~15u));  // payloads
+    __shared__ uint32_t s_a, s_b, s_bad;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_tiles = (n + FIN_TILE - 1) / FIN_TILE;
+    const uint64_t lowmask = (1ull << low_bits) - 1ull;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * FIN_TILE, t1 = t0 + FIN_TILE < n ? t0 + FIN_TILE : n;
+        // one coalesced load of the window: the key before the tile, the tile, the halo
+        const uint64_t w0 = t0 ? t0 - 1 : 0, w1 = t1 + FIN_HALO < n ? t1 + FIN_HALO : n;
+        const uint32_t cnt = (uint32_t)(w1 - w0), off0 = (uint32_t)(t0 - w0), off1 = (uint32_t)(t1 - w0);
+        if (tid == 0) {
+            s_a = t0 == 0 ? 0u : 0xFFFFFFFFu;
+            s_b = 0xFFFFFFFFu;
+            s_bad = 0u;
+        }
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            sk[i] = keys[w0 + i];
+            if (HAS_VALS) sv[i] = vals[w0 + i];
+        }
+        __syncthreads();
+        // [a, b): the whole runs whose head lies in the tile = first run head at or after t0 .. first one at or after t1
+        // (every thread keeps its first hit, a wave reduces, four LDS atomics per tile: one atomic per head cost 25 ms)
+        {
+            uint32_t fa = 0xFFFFFFFFu, fb = 0xFFFFFFFFu;
+            for (uint32_t i = tid + 1; i < cnt && fb == 0xFFFFFFFFu; i += 256) {
+                if ((sk[i] >> low_bits) == (sk[i - 1] >> low_bits)) continue;
+                if (i >= off0 && fa == 0xFFFFFFFFu) fa = i;
+                if (i >= off1) fb = i;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t xa = __shfl_xor(fa, d), xb = __shfl_xor(fb, d);
+                fa = xa < fa ? xa : fa;
+                fb = xb < fb ? xb : fb;
+            }
+            if ((tid & 63u) == 0u) {
+                if (fa != 0xFFFFFFFFu) atomicMin(&s_a, fa);
+                if (fb != 0xFFFFFFFFu) atomicMin(&s_b, fb);
+            }
+        }
+        __syncthreads();
+        const uint32_t ra = s_a;
+        uint32_t rb = s_b;
+        if (rb == 0xFFFFFFFFu && w1 == n) rb = cnt;  // the last run ends with the array
+        __syncthreads();
+        if (ra == 0xFFFFFFFFu || ra >= off1) {
+            // no run begins in this tile: it lies inside a run whose owner deals with it (or raises the fallback)
+            continue;
+        }
+        if (rb == 0xFFFFFFFFu) {  // the last run of the tile goes on beyond the halo
+            if (tid == 0) atomicOr(fallback, 1u);
+            continue;
+        }
+        for (uint32_t i = ra + tid; i < rb; i += 256) {
+            const uint64_t k = sk[i];
+            const uint64_t top = k >> low_bits, low = k & lowmask;
+            uint32_t s = i, e = i + 1, rank = 0;
+#ifndef FIN_EXP_NO_SCAN
+            while (s > ra && (sk[s - 1] >> low_bits) == top) s--;
+            while (e < rb && (sk[e] >> low_bits) == top) e++;
+#endif
+#ifdef FIN_EXP_NO_RANK
+            if (true) {}
+#else
+            if (e - s > FIN_HALO) s_bad = 1u;  // quadratic work beyond this: leave it to the full sort
+#endif
+            else {
+                for (uint32_t j = s; j < i; j++) rank += (sk[j] & lowmask) <= low;   // earlier position: ties stay in front
+                for (uint32_t j = i + 1; j < e; j++) rank += (sk[j] & lowmask) < low;
+            }
+            spos[i] = (uint16_t)(s + rank);
+        }
+        __syncthreads();
+        const bool bad = s_bad != 0u;
+        if (bad) {
+            if (tid == 0) atomicOr(fallback, 1u);  // nothing of this tile is written: the buffer stays a permutation
+        } else {
+            for (uint32_t i = ra + tid; i < rb; i += 256) {
+                const uint32_t p = spos[i];
+                if (p != i) {
+                    keys[w0 + p] = sk[i];
+                    if (HAS_VALS) vals[w0 + p] = sv[i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int finish_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
+    *fell_back = false;
+    uint32_t *d_flag = ctx->d_scalars + 52;
+    const size_t lds = (size_t)FIN_CAP * 8 + ((FIN_CAP * 2 + 15) & ~15u) + (d_vals ? (size_t)FIN_CAP * 4 : 0);
+    {
+        CrTimer t(ctx, CRGPU_T_SORT_HIST, n);  // booked beside the histogram slot: "sort, not a scatter pass"
+        CR_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(uint32_t), ctx->stream));
+        const dim3 grid(cr_grid((n + FIN_TILE - 1) / FIN_TILE, 1, 256u * 8u));
+        if (d_vals) {
+            cr_allow_lds(ctx, (const void *)k_finish_runs<true>, lds);
+            hipLaunchKernelGGL(k_finish_runs<true>, grid, dim3(256), lds, ctx->stream, d_keys, d_vals, n, low_bits, d_flag);
+        } else {
+            cr_allow_lds(ctx, (const void *)k_finish_runs<false>, lds);
+            hipLaunchKernelGGL(k_finish_runs<false>, grid, dim3(256), lds, ctx->stream, d_keys, d_vals, n, low_bits, d_flag);
+        }
+        CR_HIP(ctx, hipGetLastError());
+    }
+    uint32_t flag = 0;
+    CR_TRY(crgpu_memcpy_d2h(ctx, &flag, d_flag, sizeof(flag)));
+    *fell_back = flag != 0;
+    return CRGPU_OK;
+}
+
 template <typename K>
 static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp, uint64_t n,
                       uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
@@ -665,17 +814,41 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
     if (sizeof(K) == 8) {
         SweepPlan plan;
         uint32_t widths[OS_MAX_PASSES];
-        const bool sweep = cr_sweep_plan(lo_bit, hi_bit, &plan, widths);
+        // the passes sort on the top bits only when that saves one; k_finish_runs orders the `low` bits afterwards
+        const uint32_t low = lo_bit == 0 ? cr_sort_low_bits(hi_bit) : 0u;
+        const bool sweep = cr_sweep_plan(lo_bit + low, hi_bit, &plan, widths);
         KeyHistograms &gh = ctx->ghist;
         const bool have_hist = sweep && gh.valid && gh.d_keys == (const uint64_t *)d_keys && gh.n == n &&
                                memcmp(&gh.plan, &plan, sizeof(plan)) == 0;
         gh.valid = false;  // consumed (or stale) either way
-        if (sweep && d_vals)
-            return onesweep_sort_u64<true>(ctx, (uint64_t *)d_keys, (uint64_t *)d_tmp, d_vals, d_vals_tmp, n, plan, widths,
-                                           result_in_tmp, nullptr);
-        if (sweep)
-            return onesweep_sort_u64<false>(ctx, (uint64_t *)d_keys, (uint64_t *)d_tmp, nullptr, nullptr, n, plan, widths,
-                                            result_in_tmp, have_hist ? gh.d_hist : nullptr);
+        if (sweep) {
+            uint64_t *k0 = (uint64_t *)d_keys, *k1 = (uint64_t *)d_tmp;
+            if (d_vals)
+                CR_TRY(onesweep_sort_u64<true>(ctx, k0, k1, d_vals, d_vals_tmp, n, plan, widths, result_in_tmp, nullptr));
+            else
+                CR_TRY(onesweep_sort_u64<false>(ctx, k0, k1, nullptr, nullptr, n, plan, widths, result_in_tmp,
+                                                have_hist ? gh.d_hist : nullptr));
+            if (!low) return CRGPU_OK;
+            bool fell_back = false;
+            CR_TRY(finish_runs(ctx, *result_in_tmp ? k1 : k0, d_vals ? (*result_in_tmp ? d_vals_tmp : d_vals) : nullptr, n, low,
+                               &fell_back));
+            if (!fell_back) return CRGPU_OK;
+            // a run of equal top bits too long for the finishing pass (it may have moved keys inside other runs: the
+            // buffer still holds every key): sort it again on all bits
+            ctx->sort_refinished++;
+            SweepPlan full;
+            uint32_t fw[OS_MAX_PASSES];
+            CR_REQUIRE(ctx, cr_sweep_plan(lo_bit, hi_bit, &full, fw), CRGPU_EHIP, "sort: no plan for the full key");
+            bool flip = false;
+            uint64_t *a = *result_in_tmp ? k1 : k0, *b = *result_in_tmp ? k0 : k1;
+            uint32_t *va = *result_in_tmp ? d_vals_tmp : d_vals, *vb = *result_in_tmp ? d_vals : d_vals_tmp;
+            if (d_vals)
+                CR_TRY(onesweep_sort_u64<true>(ctx, a, b, va, vb, n, full, fw, &flip, nullptr));
+            else
+                CR_TRY(onesweep_sort_u64<false>(ctx, a, b, nullptr, nullptr, n, full, fw, &flip, nullptr));
+            if (flip) *result_in_tmp = !*result_in_tmp;
+            return CRGPU_OK;
+        }
     }
     uint32_t shift = lo_bit;
     for (uint32_t pass = 0; pass < passes && shift < hi_bit; pass++) {

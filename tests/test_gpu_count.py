@@ -379,7 +379,7 @@ def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, monkeypatc
     w = S.Workload(n_total=n, seed=58, n_wl=60_000, n_cells=150, n_ambient=5000, n_genes=500)
     c = G.fresh_ctx()
     c.set_whitelist(0, w.wl_packed, length=16)
-    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)   # 16 + 9 + 24 + 1 = 50 bits: six passes
+    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)   # 16 + 9 + 24 + 1 = 50 bits: six passes (8+8+8+8+9+9)
     r = w.host_reads(0, n)
     _, _, _, dev = G.gpu_barcode_stage(c, r, n)
     d_umi, d_uq, d_ft = c.upload(r["umi"]), c.upload(r["umi_qualn"]), c.upload(r["feature"])
@@ -423,4 +423,43 @@ def test_3m_whitelist_64_bit_keys_bit_exact():
     r = w.host_reads(0, n)
     res, m = _compare_with_oracle(c, w, r, n, w.n_genes)
     assert m.nnz > 50_000
+    c.close()
+
+
+def test_finishing_pass_hands_long_runs_back_to_the_full_sort(monkeypatch):
+    """(experimental path, CRGPU_SORT_FINISH=1) The radix passes sort the molecule keys on their top bits and k_finish_runs orders the runs of equal top bits.
+    One (barcode, feature) whose UMIs all share their leading bases makes a run far longer than the finishing pass
+    stages (FIN_RUN_MAX): the sort must notice, redo the buffer on all key bits, and give the same molecules as the
+    plain seven / eight-pass sort (CRGPU_SORT_FINISH=0) -- checked through the oracle."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+
+    monkeypatch.setenv("CRGPU_SORT_FINISH", "1")
+    rng = np.random.default_rng(5)
+    n = 60_000
+    wl = ["ACGTACGTACGTACGT", "TTTTACGTACGTACGA", "GGGGACGTACGTACCC"]
+    c = G.fresh_ctx()
+    c.set_whitelist_ascii(0, wl)
+    c.set_key_layout(40_000, 12, 1, 0)   # 2 + 16 + 24 + 1 = 43 bits: three passes + 16 low bits
+    # every UMI = 4 fixed leading bases + 8 random ones: 65 536 possible keys share the top bits of one run
+    umi = (np.uint32(0b00011011) << np.uint32(16)) | rng.integers(0, 1 << 16, n, dtype=np.uint32)
+    idx = np.zeros(n, np.uint32)
+    feature = np.full(n, 7, np.uint32)
+    uq = np.full((n, 12), 70, np.uint8)
+    d_idx, d_umi, d_uq, d_ft = c.upload(idx), c.upload(umi), c.upload(uq), c.upload(feature)
+    recs = c.records(n, 12, d_idx, d_umi, d_uq, d_ft, None)
+    keys = c.empty(n, np.uint64)
+    nk = c.build_keys(recs, keys)
+    assert nk == n
+    cnt = c.count_keys(keys, nk)
+    assert c.stat(1) == 1, "the long run did not reach the full-sort fallback"
+    mol = cnt.molecules()
+    # oracle: one barcode, one feature
+    umi_ascii = E.unpack_seqs(umi, 12)
+    _, uc = O.mark_dups_group(umi_ascii, np.ones(n, np.uint8), feature, utype=np.zeros(n, np.uint8),
+                              qname=np.arange(n, dtype=np.uint64), umi_correction=True)
+    order = np.argsort(uc["umi"], kind="stable")
+    assert np.array_equal(mol["umi"], uc["umi"][order]) and np.array_equal(mol["read_count"], uc["read_count"][order])
+    assert len(mol["umi"]) > 5_000
     c.close()
