@@ -191,6 +191,8 @@ int cr_comm_init(crgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id);
 int cr_comm_allgather_u64(crgpu_ctx *ctx, const uint64_t *mine, uint32_t k, uint64_t *all_out);
 int cr_comm_alltoallv(crgpu_ctx *ctx, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
                       const uint64_t *recv_off, const uint64_t *recv_bytes);
+int cr_partition_by_payload(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, const uint32_t *d_vin, uint32_t *d_vout,
+                            uint64_t n, uint32_t shift);
 int cr_partition_by_owner_kv(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, const uint32_t *d_vin, uint32_t *d_vout,
                              uint64_t n, uint32_t sh_bc, uint32_t n_ranks, const uint32_t *bounds, uint64_t *counts_out);
 void cr_set_thread_error(const char *msg);

@@ -956,6 +956,60 @@ __global__ __launch_bounds__(256) void k_unpack_dupinfo(const DupRec *__restrict
     }
 }
 
+// ---- the same through windows of read ordinals ---------------------------------------------------------------------------
+// (experiment, off by default -- see the driver) A read's position in sorted-key order has nothing to do with its ordinal:
+// k_per_read's 12-byte stores go all over the output (35 ms per 1 B records, 23 G stores/s).  Instead: one 8-byte record per SORTED position (coalesced), a stable
+// counting pass that groups (record, ordinal) by the top 9 bits of the ordinal (cr_partition_by_payload), and a scatter
+// whose stores then stay inside one window of n / 512 reads at a time -- small enough for the memory-side cache to merge
+// them into whole lines.  Packed record: [processed UMI 32][read_count 28][flags 4]; a read count that does not fit
+// raises *overflow and the host takes the direct path above.
+#define PR_COUNT_BITS 28u
+__device__ __forceinline__ uint64_t pack_duprec(uint32_t umi, uint32_t read_count, uint32_t flags) {
+    return ((uint64_t)umi << 32) | ((uint64_t)read_count << 4) | (flags & 0xFu);
+}
+__global__ __launch_bounds__(256) void k_per_read_sorted(const KL kl, const uint64_t *__restrict__ ukey,
+                                                         const uint32_t *__restrict__ vals, const uint32_t *__restrict__ upos,
+                                                         uint64_t nd, uint64_t n_keys, const uint32_t *__restrict__ corr,
+                                                         const uint32_t *__restrict__ inc_all, const uint16_t *__restrict__ st,
+                                                         const uint32_t *__restrict__ minidx, const uint32_t *__restrict__ rep_read,
+                                                         uint64_t *__restrict__ prec, uint32_t *__restrict__ overflow) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
+        const uint32_t b = upos[k], e = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
+        const bool corrected = (st[k] & ST_CORRECTED) != 0u;
+        const uint32_t K = corrected ? corr[k] : (uint32_t)k;
+        const uint32_t sK = st[K];
+        const uint32_t endK = (uint64_t)K + 1 < nd ? upos[K + 1] : (uint32_t)n_keys;
+        const uint32_t cntK = endK - upos[K];
+        const bool is_target = st_inc1(sK) != 0u;
+        const uint32_t read_count = ((sK & ST_CORRECTED) ? 0u : cntK) + (is_target ? inc_all[K] : 0u);
+        if (read_count >> PR_COUNT_BITS) *overflow = 1u;
+        const uint32_t umi = (uint32_t)((ukey[K] >> kl.sh_umi) & lowmask(kl.bits_umi));
+        const uint32_t mi = is_target ? minidx[K] : NONE32;
+        const uint32_t rep = rep_read[mi != NONE32 ? mi : K];
+        const bool lowK = (sK & ST_LOW) != 0u;
+        const uint32_t base = CRGPU_DUP_HAS | (corrected ? CRGPU_DUP_CORRECTED : 0u) | (lowK ? CRGPU_DUP_LOW_SUPPORT : 0u);
+        for (uint32_t i = b; i < e; i++)
+            prec[i] = pack_duprec(umi, read_count, base | ((!lowK && vals[i] == rep) ? CRGPU_DUP_UMI_COUNT : 0u));
+    }
+}
+// (record, ordinal) pairs grouped by ordinal window -> the output arrays (any may be NULL) or the packed 12-byte records
+__global__ __launch_bounds__(256) void k_scatter_records(const uint64_t *__restrict__ prec, const uint32_t *__restrict__ ordinal,
+                                                         uint64_t n_keys, uint32_t *__restrict__ out_umi,
+                                                         uint32_t *__restrict__ out_cnt, uint8_t *__restrict__ out_flags,
+                                                         DupRec *__restrict__ packed_out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_keys; j += stride) {
+        const uint64_t d = prec[j];
+        const uint32_t r = ordinal[j];
+        const uint32_t umi = (uint32_t)(d >> 32), cnt = (uint32_t)((d >> 4) & ((1u << PR_COUNT_BITS) - 1u)), fl = (uint32_t)(d & 0xFu);
+        if (packed_out) packed_out[r] = DupRec{umi, cnt, fl};
+        if (out_umi) out_umi[r] = umi;
+        if (out_cnt) out_cnt[r] = cnt;
+        if (out_flags) out_flags[r] = (uint8_t)fl;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------------
@@ -1207,21 +1261,60 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
 
     // 5b. optional per-read DupInfo
     if (vals) {
-        DevBuf rep_b, packed_b;
+        DevBuf rep_b;
         CR_TRY(dmalloc(ctx, rep_b, nd * sizeof(uint32_t)));
-        if (!pr.packed_out) CR_TRY(dmalloc(ctx, packed_b, pr.n_reads * sizeof(DupRec)));
-        DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): all-zero records
-        CR_HIP(ctx, hipMemsetAsync(packed, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
         hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
                            rep_b.as<uint32_t>());
-        hipLaunchKernelGGL(k_per_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys, corr,
-                           inc_all, st, minidx, rep_b.as<uint32_t>(), packed);
-        if (!pr.packed_out)
-            hipLaunchKernelGGL(k_unpack_dupinfo, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream, packed, pr.n_reads,
-                               pr.out_umi, pr.out_cnt, pr.out_flags);
-        CR_HIP(ctx, hipGetLastError());
+        // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): zeros
+        if (pr.packed_out) {
+            CR_HIP(ctx, hipMemsetAsync(pr.packed_out, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
+        } else {
+            if (pr.out_umi) CR_HIP(ctx, hipMemsetAsync(pr.out_umi, 0, pr.n_reads * sizeof(uint32_t), ctx->stream));
+            if (pr.out_cnt) CR_HIP(ctx, hipMemsetAsync(pr.out_cnt, 0, pr.n_reads * sizeof(uint32_t), ctx->stream));
+            if (pr.out_flags) CR_HIP(ctx, hipMemsetAsync(pr.out_flags, 0, pr.n_reads, ctx->stream));
+        }
+        // The direct scatter is the default.  CRGPU_DUPINFO_WINDOWED=1 takes the windowed one (k_per_read_sorted): measured at
+        // 1 B records it is SLOWER (dedup family 119-138 ms against 77 ms, profiles/r02_dupinfo_windowed_ab.txt): 512 windows of
+        // 2 M reads are 24 MB of output each, far beyond the 4 MB L2 of an XCD, and the three output arrays take three
+        // scattered stores per read instead of one.  Kept as a tested experiment for windows that fit the L2 (two levels).
+        bool direct = getenv("CRGPU_DUPINFO_WINDOWED") == nullptr;
+        if (!direct) {
+            DevBuf prec_b, prec2_b, ord2_b;
+            CR_TRY(dmalloc(ctx, prec_b, n_keys * sizeof(uint64_t)));
+            CR_TRY(dmalloc(ctx, prec2_b, n_keys * sizeof(uint64_t)));
+            CR_TRY(dmalloc(ctx, ord2_b, n_keys * sizeof(uint32_t)));
+            uint32_t *d_over = ctx->d_scalars + 56, over = 0;
+            CR_HIP(ctx, hipMemsetAsync(d_over, 0, sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(k_per_read_sorted, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
+                               corr, inc_all, st, minidx, rep_b.as<uint32_t>(), prec_b.as<uint64_t>(), d_over);
+            CR_HIP(ctx, hipGetLastError());
+            CR_TRY(read_u32(ctx, d_over, &over));
+            if (over) {
+                direct = true;
+            } else {
+                const uint32_t bits = cr_ceil_log2(pr.n_reads ? pr.n_reads : 1);
+                CR_TRY(cr_partition_by_payload(ctx, prec_b.as<uint64_t>(), prec2_b.as<uint64_t>(), vals, ord2_b.as<uint32_t>(), n_keys,
+                                               bits > 9 ? bits - 9 : 0));
+                hipLaunchKernelGGL(k_scatter_records, dim3(cr_grid(n_keys, 256)), dim3(256), 0, ctx->stream, prec2_b.as<uint64_t>(),
+                                   ord2_b.as<uint32_t>(), n_keys, pr.out_umi, pr.out_cnt, pr.out_flags, pr.packed_out);
+                CR_HIP(ctx, hipGetLastError());
+            }
+        }
+        if (direct) {
+            DevBuf packed_b;
+            if (!pr.packed_out) {
+                CR_TRY(dmalloc(ctx, packed_b, pr.n_reads * sizeof(DupRec)));
+                CR_HIP(ctx, hipMemsetAsync(packed_b.p, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
+            }
+            DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
+            hipLaunchKernelGGL(k_per_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys, corr,
+                               inc_all, st, minidx, rep_b.as<uint32_t>(), packed);
+            if (!pr.packed_out)
+                hipLaunchKernelGGL(k_unpack_dupinfo, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream, packed, pr.n_reads,
+                                   pr.out_umi, pr.out_cnt, pr.out_flags);
+            CR_HIP(ctx, hipGetLastError());
+        }
     }
 
     // 5c. optional: reads with a corrected UMI per (library, barcode) -- the one BarcodeSummary column that cannot be

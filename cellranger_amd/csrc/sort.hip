@@ -43,7 +43,9 @@
 #ifndef SORT_ITEMS
 #define SORT_ITEMS 16      // keys per thread per chunk
 #endif
-#define SORT_ITEMS_KV64 8  // 64-bit keys with a payload: 12 bytes per element in LDS
+#ifndef SORT_ITEMS_KV64
+#define SORT_ITEMS_KV64 10  // 64-bit keys with a payload: 12 bytes per element, 10 K elements = 120 KB of LDS (8 K: 7 x 6.1 ms at 1 B records)
+#endif
 #define SORT_WAVES (SORT_BLOCK / 64)
 #define RADIX_BITS 8
 #define RADIX 256
@@ -99,17 +101,26 @@ int cr_scan_small(crgpu_ctx *ctx, uint32_t *d_data, uint64_t n, uint32_t *d_tota
 //                                                  contiguous barcode-rank ranges, like shardio's make_chunks)
 // OwnerBounds  index of the range [bounds[r], bounds[r+1]) that holds (key >> shift); `bounds` has
 //              width+1 ascending entries in device memory (histogram-balanced ranges)
+// PayloadDigit (payload >> shift) & mask         (partition by the top bits of the read ordinal that travels as payload)
+// Every functor is called as dig(key, payload); only PayloadDigit looks at the payload.
 struct RadixDigit {
     uint32_t shift, mask;
     template <typename K>
-    __device__ __forceinline__ uint32_t operator()(K key) const {
+    __device__ __forceinline__ uint32_t operator()(K key, uint32_t = 0u) const {
         return (uint32_t)(key >> shift) & mask;
+    }
+};
+struct PayloadDigit {
+    uint32_t shift, mask;
+    template <typename K>
+    __device__ __forceinline__ uint32_t operator()(K, uint32_t val) const {
+        return (val >> shift) & mask;
     }
 };
 struct OwnerDiv {
     uint32_t shift, width;
     template <typename K>
-    __device__ __forceinline__ uint32_t operator()(K key) const {
+    __device__ __forceinline__ uint32_t operator()(K key, uint32_t = 0u) const {
         return (uint32_t)((uint64_t)key >> shift) / width;
     }
 };
@@ -117,7 +128,7 @@ struct OwnerBounds {
     uint32_t shift, width;
     const uint32_t *bounds;
     template <typename K>
-    __device__ __forceinline__ uint32_t operator()(K key) const {
+    __device__ __forceinline__ uint32_t operator()(K key, uint32_t = 0u) const {
         const uint32_t v = (uint32_t)((uint64_t)key >> shift);
         uint32_t lo = 0, hi = width;  // first r with bounds[r+1] > v
         while (lo + 1 < hi) {
@@ -142,16 +153,16 @@ struct SortCfg {
 
 // ---- pass 1: per-block digit histogram ------------------------------------------------------------
 template <typename K, typename DIG, int BITS>
-__global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(const K *__restrict__ keys, uint64_t n, uint64_t tile,
-                                                           DIG dig, uint32_t *__restrict__ block_hist,
-                                                           uint32_t n_blocks) {
+__global__ __launch_bounds__(SORT_BLOCK) void k_radix_hist(const K *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                           uint64_t n, uint64_t tile, DIG dig,
+                                                           uint32_t *__restrict__ block_hist, uint32_t n_blocks) {
     constexpr uint32_t RADIX_T = 1u << BITS;
     __shared__ uint32_t h[RADIX_T];
     if (threadIdx.x < RADIX_T) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * tile;
     const uint64_t hi = lo + tile < n ? lo + tile : n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) atomicAdd(&h[dig(keys[i])], 1u);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) atomicAdd(&h[dig(keys[i], vals ? vals[i] : 0u)], 1u);
     __syncthreads();
     if (threadIdx.x < RADIX_T) block_hist[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             }
 #pragma unroll
             for (int it = 0; it < ITEMS; it++) {
-                const uint32_t d = dig(key[it]);
+                const uint32_t d = dig(key[it], HAS_VALS ? val[it] : 0u);
                 dr[it] = (d << 16) | wave_multisplit_rank<BITS, true>(d, true, wcount[wave]);
             }
         } else {
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
 #pragma unroll
             for (int it = 0; it < ITEMS; it++) {
                 const bool ok = wave_off + it * 64 < chunk_n;
-                const uint32_t d = ok ? dig(key[it]) : 0u;
+                const uint32_t d = ok ? dig(key[it], HAS_VALS ? val[it] : 0u) : 0u;
                 dr[it] = (d << 16) | wave_multisplit_rank<BITS, false>(d, ok, wcount[wave]);
             }
         }
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         if (ONESWEEP && *s_abort) break;  // uniform: nothing of this chunk is written, the pass is redone
         for (uint32_t p = tid; p < chunk_n; p += SORT_BLOCK) {
             const K k = skeys[p];
-            const uint32_t pos = p + gdelta[dig(k)];
+            const uint32_t pos = p + gdelta[dig(k, HAS_VALS ? svals[p] : 0u)];
             SORT_STORE_OUT(k, &keys_out[pos]);
             if (HAS_VALS) vals_out[pos] = svals[p];
         }
@@ -419,9 +430,10 @@ static uint32_t sort_blocks(uint64_t n, uint64_t chunk, uint64_t *tile_out) {
 static uint32_t *digit_totals_buf(crgpu_ctx *ctx) { return ctx->d_sort_hist + 256 * 2048; }  // RADIX_MAX u32 behind the block histograms
 
 // one counting-sort pass keyed by `dig` (stable).
+// slot >= 0: the timing slot all three kernels are booked under (without units)
 template <typename K, typename DIG, int BITS = RADIX_BITS>
 static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d_vin, uint32_t *d_vout, uint64_t n,
-                      DIG dig) {
+                      DIG dig, int slot = -1) {
     uint64_t tile;
     const uint32_t nb = sort_blocks(n, d_vin ? SortCfg<K, true>::CHUNK : SortCfg<K, false>::CHUNK, &tile);
     uint32_t *d_hist = ctx->d_sort_hist;
@@ -429,14 +441,14 @@ static int radix_pass(crgpu_ctx *ctx, const K *d_in, K *d_out, const uint32_t *d
     {
         // the auxiliary 32-bit sort of the low-support stage is booked under that stage: the SORT slots are
         // the 64-bit molecule-key sort alone (bench.py prices them at 8 / 16 bytes per key)
-        CrTimer t(ctx, sizeof(K) == 8 ? CRGPU_T_SORT_HIST : CRGPU_T_DEDUP, sizeof(K) == 8 ? n : 0);
-        hipLaunchKernelGGL((k_radix_hist<K, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, n, tile, dig, d_hist, nb);
+        CrTimer t(ctx, slot >= 0 ? slot : (sizeof(K) == 8 ? CRGPU_T_SORT_HIST : CRGPU_T_DEDUP), (slot < 0 && sizeof(K) == 8) ? n : 0);
+        hipLaunchKernelGGL((k_radix_hist<K, DIG, BITS>), dim3(nb), dim3(SORT_BLOCK), 0, ctx->stream, d_in, d_vin, n, tile, dig, d_hist, nb);
     }
     {
-        CrTimer t(ctx, CRGPU_T_SCAN);
+        CrTimer t(ctx, slot >= 0 ? slot : CRGPU_T_SCAN);
         hipLaunchKernelGGL(k_scan_digits, dim3(1u << BITS), dim3(256), 0, ctx->stream, d_hist, nb, d_tot);
     }
-    CrTimer t(ctx, sizeof(K) == 8 ? CRGPU_T_SORT : CRGPU_T_DEDUP, sizeof(K) == 8 ? n : 0);  // DEDUP counts its keys once
+    CrTimer t(ctx, slot >= 0 ? slot : (sizeof(K) == 8 ? CRGPU_T_SORT : CRGPU_T_DEDUP), (slot < 0 && sizeof(K) == 8) ? n : 0);  // DEDUP counts its keys once
     // more than 64 KB of LDS per workgroup has to be requested per kernel, once
     const size_t lds_kv = SortCfg<K, true>::lds_bytes(BITS), lds_k = SortCfg<K, false>::lds_bytes(BITS);
     if (d_vin) {
@@ -916,4 +928,12 @@ int cr_partition_by_owner_kv(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_o
 int cr_partition_by_owner(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, uint32_t sh_bc,
                           uint32_t n_ranks, const uint32_t *bounds, uint64_t *counts_out) {
     return cr_partition_by_owner_kv(ctx, d_in, d_out, nullptr, nullptr, n, sh_bc, n_ranks, bounds, counts_out);
+}
+
+// One stable counting pass of (64-bit value, 32-bit payload) pairs keyed by the top bits of the PAYLOAD: groups the
+// per-read records of the DupInfo path by windows of read ordinals before they are scattered to the reads.
+int cr_partition_by_payload(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, const uint32_t *d_vin, uint32_t *d_vout,
+                            uint64_t n, uint32_t shift) {
+    if (n == 0) return CRGPU_OK;
+    return radix_pass<uint64_t, PayloadDigit, 9>(ctx, d_in, d_out, d_vin, d_vout, n, PayloadDigit{shift, 511u}, CRGPU_T_DEDUP);
 }

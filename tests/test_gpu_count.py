@@ -463,3 +463,21 @@ def test_finishing_pass_hands_long_runs_back_to_the_full_sort(monkeypatch):
     assert np.array_equal(mol["umi"], uc["umi"][order]) and np.array_equal(mol["read_count"], uc["read_count"][order])
     assert len(mol["umi"]) > 5_000
     c.close()
+
+
+@pytest.mark.parametrize("n", [300_000, 2_000_000])
+def test_windowed_dupinfo_scatter_matches_the_oracle(n, monkeypatch):
+    """The experimental windowed scatter of the per-read records (CRGPU_DUPINFO_WINDOWED=1: k_per_read_sorted ->
+    cr_partition_by_payload -> k_scatter_records): every read's DupInfo equals the oracle's, as the direct path's does in
+    the other tests."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+
+    monkeypatch.setenv("CRGPU_DUPINFO_WINDOWED", "1")
+    w = S.Workload(n_total=n, seed=S.SEED0 + 9, n_wl=100_000, n_cells=300, n_ambient=20000, n_genes=2000)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    res, m = _compare_with_oracle(c, w, r, n, w.n_genes)
+    assert m.nnz > 50_000
+    c.close()
