@@ -138,6 +138,10 @@ struct crgpu_ctx {
     double *d_ptab = nullptr;  // 128 entries: probability(q) for q = 0..127 (corrector.rs:167-171)
 
     KeyLayout layout;
+    // targeted-panel UMI filter (mark_dups.rs:311-320): on-target flag per feature + minimum read count (0 = None)
+    uint8_t *d_on_target = nullptr;
+    uint32_t n_target_features = 0;
+    uint64_t target_min_reads = 0;
 
     // scratch
     uint32_t *d_scalars = nullptr;  // small device counters

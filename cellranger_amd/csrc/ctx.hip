@@ -165,6 +165,7 @@ extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
         hipFree(p.d_index);
         hipFree(p.d_dist);
     }
+    hipFree(ctx->d_on_target);
     hipFree(ctx->d_canon_keys);
     hipFree(ctx->d_hot_image);
     hipFree(ctx->d_ptab);

@@ -33,6 +33,7 @@ struct crgpu_counts {
     uint64_t *d_mkeys = nullptr;    // molecule keys (primary layout), n_molecules
     uint32_t *d_mreads = nullptr;   // read_count of each molecule
     uint32_t *d_corr_reads = nullptr;  // [library][barcode rank] reads whose UMI was corrected (BarcodeSummary), or NULL
+    uint32_t *d_filt_reads = nullptr;  // [library][barcode rank] reads of molecules the targeted-panel filter removed, or NULL
     uint32_t n_canon = 0;
     KeyLayout layout;
 };
@@ -62,6 +63,25 @@ extern "C" int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_
                L.bits_bc, L.bits_feat, L.bits_lib, L.bits_umi);
     L.set = true;
     ctx->layout = L;
+    return CRGPU_OK;
+}
+
+// targeted gene expression: DupBuilder::build(.., targeted_umi_min_read_count) + FeatureReference::target_set
+// (mark_dups.rs:156-169,311-320; the threshold comes from _slfe_matrix_computer.mro:122-140).  on_target: n_features bytes
+// (host), non-zero = the feature is in the target set; NULL or min_read_count == 0 switches the filter off.
+extern "C" int crgpu_set_target_filter(crgpu_ctx *ctx, const uint8_t *on_target, uint32_t n_features, uint64_t min_read_count) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_on_target) CR_HIP(ctx, hipFree(ctx->d_on_target));
+    ctx->d_on_target = nullptr;
+    ctx->n_target_features = 0;
+    ctx->target_min_reads = 0;
+    if (!on_target || !min_read_count || !n_features) return CRGPU_OK;
+    CR_HIP(ctx, hipMalloc((void **)&ctx->d_on_target, n_features));
+    CR_HIP(ctx, hipMemcpy(ctx->d_on_target, on_target, n_features, hipMemcpyHostToDevice));
+    ctx->n_target_features = n_features;
+    ctx->target_min_reads = min_read_count;
     return CRGPU_OK;
 }
 
@@ -551,12 +571,39 @@ struct EmitRun {  // distinct key + start position of its run
         upos[o] = (uint32_t)i;
     }
 };
-struct MolFlag {  // distinct key that yields a UmiCount (mark_dups.rs:322-325 with rate 1.0, no target filter)
-    const uint16_t *st;  // state word of umi_correct.h
+// targeted-panel filter (mark_dups.rs:311-320): a corrected key of an on-target feature whose read count stays below
+// the threshold yields no UmiCount (and its reads carry is_filtered_target_umi); min_reads == 0: None
+struct TargetFilter {
+    const uint8_t *on_target;
+    uint32_t n_features, sh_feat, bits_feat;
+    uint64_t min_reads;
+    __device__ __forceinline__ bool filtered(uint64_t key, uint32_t read_count, bool low) const {
+        if (!min_reads) return false;
+        const uint32_t f = (uint32_t)((key >> sh_feat) & lowmask(bits_feat));
+        return f < n_features && on_target[f] != 0 && (uint64_t)read_count < min_reads && !low;
+    }
+};
+struct MolFlag {  // distinct key that yields a UmiCount (mark_dups.rs:322-325 with rate 1.0)
+    const uint16_t *st;  // per-key state word
     __device__ __forceinline__ bool operator()(uint64_t k) const {
         const uint32_t s = st[k];
         const bool landed = !(s & ST_CORRECTED) | (st_inc1(s) > 0u);  // some read's corrected key is k
         return landed & !(s & ST_LOW);
+    }
+};
+struct MolFlagTargeted {  // the same with the targeted-panel filter: needs the key's final read count
+    const uint16_t *st;
+    const uint64_t *ukey;
+    const uint32_t *upos, *inc_all;
+    uint64_t n_keys, n_dist;
+    TargetFilter tf;
+    __device__ __forceinline__ bool operator()(uint64_t k) const {
+        const uint32_t s = st[k];
+        const bool landed = !(s & ST_CORRECTED) | (st_inc1(s) > 0u);
+        if (!landed || (s & ST_LOW)) return false;
+        const uint32_t end = k + 1 < n_dist ? upos[k + 1] : (uint32_t)n_keys;
+        const uint32_t rc = ((s & ST_CORRECTED) ? 0u : end - upos[k]) + (st_inc1(s) ? inc_all[k] : 0u);
+        return !tf.filtered(ukey[k], rc, false);
     }
 };
 struct EmitMol {
@@ -917,7 +964,8 @@ __global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *_
                                                   const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
                                                   const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc_all,
                                                   const uint16_t *__restrict__ st, const uint32_t *__restrict__ minidx,
-                                                  const uint32_t *__restrict__ rep_read, DupRec *__restrict__ packed) {
+                                                  const uint32_t *__restrict__ rep_read, DupRec *__restrict__ packed,
+                                                  const TargetFilter tf) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
         const uint32_t b = upos[k], e = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
@@ -933,13 +981,14 @@ __global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *_
         const uint32_t rep_key = mi != NONE32 ? mi : K;  // umigene_min_key[corrected_key]
         const uint32_t rep = rep_read[rep_key];
         const bool lowK = (sK & ST_LOW) != 0u;
+        const bool filt = tf.filtered(ukey[K], read_count, lowK);
         const uint8_t base = (uint8_t)(CRGPU_DUP_HAS | (corrected ? CRGPU_DUP_CORRECTED : 0) |
-                                       (lowK ? CRGPU_DUP_LOW_SUPPORT : 0));
+                                       (lowK ? CRGPU_DUP_LOW_SUPPORT : 0) | (filt ? CRGPU_DUP_FILTERED_TARGET : 0));
         for (uint32_t i = b; i < e; i++) {
             const uint32_t r = vals[i];
             // one 12-byte store per read: the position of a read in sorted order has nothing to do with its ordinal,
             // and three separate scattered stores cost three partial-line writes per read (38 GB per 200 M reads)
-            packed[r] = DupRec{umi, read_count, (uint32_t)(base | ((!lowK && r == rep) ? CRGPU_DUP_UMI_COUNT : 0))};
+            packed[r] = DupRec{umi, read_count, (uint32_t)(base | ((!lowK && !filt && r == rep) ? CRGPU_DUP_UMI_COUNT : 0))};
         }
     }
 }
@@ -961,18 +1010,19 @@ __global__ __launch_bounds__(256) void k_unpack_dupinfo(const DupRec *__restrict
 // k_per_read's 12-byte stores go all over the output (35 ms per 1 B records, 23 G stores/s).  Instead: one 8-byte record per SORTED position (coalesced), a stable
 // counting pass that groups (record, ordinal) by the top 9 bits of the ordinal (cr_partition_by_payload), and a scatter
 // whose stores then stay inside one window of n / 512 reads at a time -- small enough for the memory-side cache to merge
-// them into whole lines.  Packed record: [processed UMI 32][read_count 28][flags 4]; a read count that does not fit
+// them into whole lines.  Packed record: [processed UMI 32][read_count 27][flags 5]; a read count that does not fit
 // raises *overflow and the host takes the direct path above.
-#define PR_COUNT_BITS 28u
+#define PR_COUNT_BITS 27u
 __device__ __forceinline__ uint64_t pack_duprec(uint32_t umi, uint32_t read_count, uint32_t flags) {
-    return ((uint64_t)umi << 32) | ((uint64_t)read_count << 4) | (flags & 0xFu);
+    return ((uint64_t)umi << 32) | ((uint64_t)read_count << 5) | (flags & 0x1Fu);
 }
 __global__ __launch_bounds__(256) void k_per_read_sorted(const KL kl, const uint64_t *__restrict__ ukey,
                                                          const uint32_t *__restrict__ vals, const uint32_t *__restrict__ upos,
                                                          uint64_t nd, uint64_t n_keys, const uint32_t *__restrict__ corr,
                                                          const uint32_t *__restrict__ inc_all, const uint16_t *__restrict__ st,
                                                          const uint32_t *__restrict__ minidx, const uint32_t *__restrict__ rep_read,
-                                                         uint64_t *__restrict__ prec, uint32_t *__restrict__ overflow) {
+                                                         uint64_t *__restrict__ prec, uint32_t *__restrict__ overflow,
+                                                         const TargetFilter tf) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
         const uint32_t b = upos[k], e = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
@@ -988,9 +1038,11 @@ __global__ __launch_bounds__(256) void k_per_read_sorted(const KL kl, const uint
         const uint32_t mi = is_target ? minidx[K] : NONE32;
         const uint32_t rep = rep_read[mi != NONE32 ? mi : K];
         const bool lowK = (sK & ST_LOW) != 0u;
-        const uint32_t base = CRGPU_DUP_HAS | (corrected ? CRGPU_DUP_CORRECTED : 0u) | (lowK ? CRGPU_DUP_LOW_SUPPORT : 0u);
+        const bool filt = tf.filtered(ukey[K], read_count, lowK);
+        const uint32_t base = CRGPU_DUP_HAS | (corrected ? CRGPU_DUP_CORRECTED : 0u) | (lowK ? CRGPU_DUP_LOW_SUPPORT : 0u) |
+                              (filt ? CRGPU_DUP_FILTERED_TARGET : 0u);
         for (uint32_t i = b; i < e; i++)
-            prec[i] = pack_duprec(umi, read_count, base | ((!lowK && vals[i] == rep) ? CRGPU_DUP_UMI_COUNT : 0u));
+            prec[i] = pack_duprec(umi, read_count, base | ((!lowK && !filt && vals[i] == rep) ? CRGPU_DUP_UMI_COUNT : 0u));
     }
 }
 // (record, ordinal) pairs grouped by ordinal window -> the output arrays (any may be NULL) or the packed 12-byte records
@@ -1002,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_scatter_records(const uint64_t *__restr
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_keys; j += stride) {
         const uint64_t d = prec[j];
         const uint32_t r = ordinal[j];
-        const uint32_t umi = (uint32_t)(d >> 32), cnt = (uint32_t)((d >> 4) & ((1u << PR_COUNT_BITS) - 1u)), fl = (uint32_t)(d & 0xFu);
+        const uint32_t umi = (uint32_t)(d >> 32), cnt = (uint32_t)((d >> 5) & ((1u << PR_COUNT_BITS) - 1u)), fl = (uint32_t)(d & 0x1Fu);
         if (packed_out) packed_out[r] = DupRec{umi, cnt, fl};
         if (out_umi) out_umi[r] = umi;
         if (out_cnt) out_cnt[r] = cnt;
@@ -1026,6 +1078,26 @@ __global__ __launch_bounds__(256) void k_corrected_reads(const KL kl, const uint
         const uint32_t run = (k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys) - upos[k];
         const uint32_t lib = (uint32_t)((key >> kl.sh_lib) & lowmask(kl.bits_lib));
         atomicAdd(&tab[(size_t)lib * W + (uint32_t)(key >> kl.sh_bc)], run);
+    }
+}
+
+// reads of the keys that the targeted-panel filter took out of the molecule table: they still count as
+// candidate_dup_reads in the BarcodeSummary (aligner.rs:54-67 looks at is_low_support_umi only)
+__global__ __launch_bounds__(256) void k_filtered_reads(const KL kl, const uint64_t *__restrict__ ukey,
+                                                        const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
+                                                        const uint16_t *__restrict__ st, const uint32_t *__restrict__ inc_all,
+                                                        const TargetFilter tf, uint32_t W, uint32_t *__restrict__ tab) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
+        const uint32_t s = st[k];
+        const bool landed = !(s & ST_CORRECTED) | (st_inc1(s) > 0u);
+        if (!landed || (s & ST_LOW)) continue;
+        const uint32_t end = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
+        const uint32_t rc = ((s & ST_CORRECTED) ? 0u : end - upos[k]) + (st_inc1(s) ? inc_all[k] : 0u);
+        const uint64_t key = ukey[k];
+        if (!tf.filtered(key, rc, false)) continue;
+        const uint32_t lib = (uint32_t)((key >> kl.sh_lib) & lowmask(kl.bits_lib));
+        atomicAdd(&tab[(size_t)lib * W + (uint32_t)(key >> kl.sh_bc)], rc);
     }
 }
 
@@ -1077,7 +1149,7 @@ struct SummaryFlag {  // barcode rank with at least one read of this library (a 
     __device__ __forceinline__ bool operator()(uint64_t i) const { return (valid[lo + i] + corrected[lo + i]) != 0u; }
 };
 struct EmitSummary {
-    const uint32_t *valid, *corrected, *umis, *cand, *corr_reads;  // the last three may be NULL (no molecules)
+    const uint32_t *valid, *corrected, *umis, *cand, *corr_reads, *filt_reads;  // the last four may be NULL
     uint32_t lo, lib;
     crgpu_barcode_summary_row *rows;
     struct Pre {};
@@ -1089,7 +1161,7 @@ struct EmitSummary {
         w.library = lib;
         w.reads = (uint64_t)valid[r] + corrected[r];
         w.umis = umis ? umis[r] : 0u;
-        w.candidate_dup_reads = cand ? cand[r] : 0u;
+        w.candidate_dup_reads = (uint64_t)(cand ? cand[r] : 0u) + (filt_reads ? filt_reads[r] : 0u);
         w.umi_corrected_reads = corr_reads ? corr_reads[r] : 0u;
         rows[o] = w;
     }
@@ -1250,11 +1322,14 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     CR_TRY(dmalloc(ctx, mkeys_b, nd * sizeof(uint64_t)));
     CR_TRY(dmalloc(ctx, mreads_b, nd * sizeof(uint32_t)));
     uint32_t nm32 = 0;
+    const TargetFilter tf{ctx->d_on_target, ctx->n_target_features, L.sh_feat(), L.bits_feat, ctx->d_on_target ? ctx->target_min_reads : 0};
     {
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        CR_TRY(compact(ctx, MolFlag{st},
-                       EmitMol{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()}, nd,
-                       d_block, d_total));
+        const EmitMol emit{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()};
+        if (tf.min_reads)
+            CR_TRY(compact(ctx, MolFlagTargeted{st, ukey, upos, inc_all, n_keys, nd, tf}, emit, nd, d_block, d_total));
+        else
+            CR_TRY(compact(ctx, MolFlag{st}, emit, nd, d_block, d_total));
     }
     CR_TRY(read_u32(ctx, d_total, &nm32));
     const uint64_t nm = nm32;
@@ -1287,7 +1362,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             uint32_t *d_over = ctx->d_scalars + 56, over = 0;
             CR_HIP(ctx, hipMemsetAsync(d_over, 0, sizeof(uint32_t), ctx->stream));
             hipLaunchKernelGGL(k_per_read_sorted, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
-                               corr, inc_all, st, minidx, rep_b.as<uint32_t>(), prec_b.as<uint64_t>(), d_over);
+                               corr, inc_all, st, minidx, rep_b.as<uint32_t>(), prec_b.as<uint64_t>(), d_over, tf);
             CR_HIP(ctx, hipGetLastError());
             CR_TRY(read_u32(ctx, d_over, &over));
             if (over) {
@@ -1309,7 +1384,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             }
             DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
             hipLaunchKernelGGL(k_per_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys, corr,
-                               inc_all, st, minidx, rep_b.as<uint32_t>(), packed);
+                               inc_all, st, minidx, rep_b.as<uint32_t>(), packed, tf);
             if (!pr.packed_out)
                 hipLaunchKernelGGL(k_unpack_dupinfo, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream, packed, pr.n_reads,
                                    pr.out_umi, pr.out_cnt, pr.out_flags);
@@ -1326,6 +1401,12 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CR_HIP(ctx, hipMemsetAsync(res->d_corr_reads, 0, bytes, ctx->stream));
         hipLaunchKernelGGL(k_corrected_reads, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, st,
                            ctx->n_canon, res->d_corr_reads);
+        if (tf.min_reads) {
+            CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_filt_reads, bytes));
+            CR_HIP(ctx, hipMemsetAsync(res->d_filt_reads, 0, bytes, ctx->stream));
+            hipLaunchKernelGGL(k_filtered_reads, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, st,
+                               inc_all, tf, ctx->n_canon, res->d_filt_reads);
+        }
         CR_HIP(ctx, hipGetLastError());
     }
 
@@ -1945,7 +2026,8 @@ extern "C" int crgpu_counts_barcode_summary(crgpu_ctx *ctx, const crgpu_counts *
             CR_TRY(compact(ctx, SummaryFlag{valid, corrected, rank_lo},
                            EmitSummary{valid, corrected, c->n_molecules ? umis_b.as<uint32_t>() + off : nullptr,
                                        c->n_molecules ? cand_b.as<uint32_t>() + off : nullptr,
-                                       c->d_corr_reads ? c->d_corr_reads + off : nullptr, rank_lo, lib,
+                                       c->d_corr_reads ? c->d_corr_reads + off : nullptr,
+                                       c->d_filt_reads ? c->d_filt_reads + off : nullptr, rank_lo, lib,
                                        rows_b.as<crgpu_barcode_summary_row>()},
                            span, ctx->d_sort_hist, d_total));
         }
@@ -1969,5 +2051,6 @@ extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
     cr_pool_free(ctx, c->d_mkeys);
     cr_pool_free(ctx, c->d_mreads);
     cr_pool_free(ctx, c->d_corr_reads);
+    cr_pool_free(ctx, c->d_filt_reads);
     delete c;
 }

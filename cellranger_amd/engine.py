@@ -492,6 +492,11 @@ class Context:
         self._check(self.L.crgpu_set_key_layout(self.h, n_features, umi_len, n_libs, multiplexing_lib_mask))
         self.n_features, self.umi_len = n_features, umi_len
 
+    def set_target_filter(self, on_target=None, min_read_count=0):
+        """targeted-panel UMI filter (mark_dups.rs:311-320); None switches it off"""
+        a = None if on_target is None else np.ascontiguousarray(on_target, dtype=np.uint8)
+        self._check(self.L.crgpu_set_target_filter(self.h, ptr(a), 0 if a is None else len(a), int(min_read_count)))
+
     def records(self, n, umi_len, d_bc_idx, d_umi, d_umi_qualn, d_feature, d_flags=None):
         r = Records()
         r.n, r.umi_len = n, umi_len

@@ -305,6 +305,12 @@ int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_t umi_len, 
                          uint32_t multiplexing_lib_mask);
 int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out,
                          uint64_t *n_keys_out);
+/* Targeted Gene Expression: DupBuilder::build(.., targeted_umi_min_read_count) with the target set of the feature
+ * reference (tx_annotation/src/mark_dups.rs:156-169,311-320; threshold from mro/rna/_slfe_matrix_computer.mro:122-140): a
+ * molecule of an on-target feature whose read count stays below min_read_count (and that is not low support) yields no
+ * UmiCount, and its reads carry CRGPU_DUP_FILTERED_TARGET.  on_target: n_features bytes (host, copied), non-zero = in the
+ * target set.  NULL or min_read_count == 0: no filter (the default).  Applies to every count call that follows. */
+int crgpu_set_target_filter(crgpu_ctx *ctx, const uint8_t *on_target, uint32_t n_features, uint64_t min_read_count);
 /* owner rank of a key's barcode for the all-to-all: rank r owns the contiguous canonical-rank range
  * [r*w, (r+1)*w), w = ceil(n_canon / n_ranks) -- barcode-range chunks like shardio's make_chunks
  * (align_and_count.rs:505-524) -- or, when `bounds` (host, n_ranks+1 ascending ranks, bounds[0] = 0,
@@ -333,6 +339,7 @@ int crgpu_count_keys_dev(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys
 #define CRGPU_DUP_CORRECTED 0x02u    /* DupInfo::is_corrected */
 #define CRGPU_DUP_LOW_SUPPORT 0x04u  /* DupInfo::is_low_support_umi */
 #define CRGPU_DUP_UMI_COUNT 0x08u    /* DupInfo::is_umi_count: the representative read of its molecule */
+#define CRGPU_DUP_FILTERED_TARGET 0x10u /* DupInfo::is_filtered_target_umi (crgpu_set_target_filter) */
 int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs, crgpu_counts **out,
                             uint32_t *d_processed_umi_out, uint32_t *d_read_count_out, uint8_t *d_dupflags_out);
 /* The same for ONE GEM well sharded over the ranks of the context's communicator (collective).  Every rank

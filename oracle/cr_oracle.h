@@ -105,7 +105,11 @@ typedef struct {
     uint8_t is_umi_count;
     uint32_t processed_umi; /* 2-bit of corrected umi */
     uint32_t read_count;    /* umigene_counts[corrected_key] */
+    uint8_t is_filtered_target; /* DupInfo::is_filtered_target_umi (mark_dups.rs:311-320) */
+    uint8_t pad_[3];
 } oracle_dupinfo;
+/* targeted_umi_min_read_count + the target set of the feature reference for the following runs (NULL: None) */
+void oracle_set_target_filter(const uint8_t *on_target, uint32_t n_features, uint64_t min_read_count);
 
 typedef struct {
     uint32_t feature_idx;

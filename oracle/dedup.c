@@ -185,6 +185,17 @@ static int selkey_less(uint8_t ut_a, uint64_t q_a, uint8_t ut_b, uint64_t q_b) {
     return q_a < q_b;
 }
 
+/* targeted-panel UMI filter (mark_dups.rs:311-320): state of the checker, set by the tests before a run.
+ * on_target[f] != 0 for the features of the target set; threshold 0 = None (no filter). */
+static const uint8_t *g_on_target = NULL;
+static uint32_t g_n_target_features = 0;
+static uint64_t g_target_min_reads = 0;
+void oracle_set_target_filter(const uint8_t *on_target, uint32_t n_features, uint64_t min_read_count) {
+    g_on_target = on_target;
+    g_n_target_features = n_features;
+    g_target_min_reads = on_target ? min_read_count : 0;
+}
+
 uint64_t oracle_mark_dups_group(const char *umi, uint32_t umi_len, const uint8_t *umi_valid,
                                 const uint32_t *feature, const uint8_t *utype,
                                 const uint64_t *qname, uint64_t n, int umi_correction_enabled,
@@ -272,8 +283,10 @@ uint64_t oracle_mark_dups_group(const char *umi, uint32_t umi_len, const uint8_t
             int is_min_qname = qname[i] == cr->min_qname;
             di.read_count = (uint32_t)cr->count;
             di.processed_umi = oracle_encode_2bit_u32(cr->umi, umi_len);
-            /* targeted_umi_min_read_count = None, subsample rate 1.0 (stages/stubs.rs:6-8) */
-            di.is_umi_count = !di.is_low_support && is_min_qname;
+            /* mark_dups.rs:311-320 (None unless oracle_set_target_filter was called); subsample rate 1.0 (stages/stubs.rs:6-8) */
+            di.is_filtered_target = g_target_min_reads && cr->gene < g_n_target_features && g_on_target[cr->gene] &&
+                                    (uint64_t)cr->count < g_target_min_reads && !di.is_low_support;
+            di.is_umi_count = !di.is_low_support && is_min_qname && !di.is_filtered_target;
             if (di.is_umi_count && umi_counts_out) {
                 oracle_umicount *u = &umi_counts_out[n_out];
                 memset(u, 0, sizeof(*u));

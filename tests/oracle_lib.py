@@ -40,7 +40,7 @@ class DupInfo(C.Structure):
 
 DUPINFO_DTYPE = np.dtype(
     [("has_dupinfo", "u1"), ("is_corrected", "u1"), ("is_low_support", "u1"), ("is_umi_count", "u1"),
-     ("processed_umi", "<u4"), ("read_count", "<u4")]
+     ("processed_umi", "<u4"), ("read_count", "<u4"), ("is_filtered_target", "u1"), ("_pad", "V3")]
 )
 UMICOUNT_DTYPE = np.dtype(
     [("feature_idx", "<u4"), ("umi", "<u4"), ("read_count", "<u4"), ("utype", "u1"), ("_pad", "V3")]
@@ -259,6 +259,22 @@ def mark_dups_group(umis, umi_valid, feature, utype=None, qname=None, umi_correc
     m = lib().oracle_mark_dups_group(_ptr(u), ul, _ptr(v), _ptr(f), _ptr(t), _ptr(q), n, int(umi_correction),
                                      int(filter_umis), _ptr(dup), _ptr(uc))
     return dup, uc[:m]
+
+
+_target_keep = None
+
+
+def set_target_filter(on_target=None, min_read_count=0):
+    """targeted_umi_min_read_count + target set for the following oracle runs (None: no filter)"""
+    global _target_keep
+    f = lib().oracle_set_target_filter
+    f.restype, f.argtypes = None, [C.c_void_p, C.c_uint32, C.c_uint64]
+    if on_target is None:
+        _target_keep = None
+        f(None, 0, 0)
+    else:
+        _target_keep = np.ascontiguousarray(on_target, dtype=np.uint8)
+        f(_ptr(_target_keep), len(_target_keep), int(min_read_count))
 
 
 class PipelineResult:

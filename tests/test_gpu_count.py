@@ -69,6 +69,7 @@ def _compare_with_oracle(c, w, r, n, n_features, n_libs=1, mux_mask=0, whitelist
     assert np.array_equal((dup["flags"] & 2) != 0, od["is_corrected"] != 0)
     assert np.array_equal((dup["flags"] & 4) != 0, od["is_low_support"] != 0)
     assert np.array_equal((dup["flags"] & 8) != 0, od["is_umi_count"] != 0)
+    assert np.array_equal((dup["flags"] & 16) != 0, od["is_filtered_target"] != 0)
     assert np.array_equal(dup["processed_umi"][has], od["processed_umi"][has])
     assert np.array_equal(dup["read_count"][has], od["read_count"][has])
     assert not dup["read_count"][~has].any() and not dup["processed_umi"][~has].any()
@@ -480,4 +481,35 @@ def test_windowed_dupinfo_scatter_matches_the_oracle(n, monkeypatch):
     r = w.host_reads(0, n)
     res, m = _compare_with_oracle(c, w, r, n, w.n_genes)
     assert m.nnz > 50_000
+    c.close()
+
+
+def test_targeted_panel_umi_filter_matches_the_oracle():
+    """Targeted Gene Expression (mark_dups.rs:311-320): molecules of on-target features with fewer reads than
+    targeted_umi_min_read_count yield no UmiCount and their reads carry is_filtered_target_umi.  Half of the features
+    on target, threshold 3: DupInfo flags, matrix, molecule table and BarcodeSummary equal the oracle's; then the filter is
+    switched off again and the plain results come back."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import synth as S
+
+    n = 400_000
+    w = S.Workload(n_total=n, seed=S.SEED0 + 11, n_wl=50_000, n_cells=200, n_ambient=5000, n_genes=600, reads_per_umi=3)
+    on_target = (np.arange(w.n_genes) % 2 == 0).astype(np.uint8)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    try:
+        c.set_target_filter(on_target, 3)
+        O.set_target_filter(on_target, 3)
+        res, m = _compare_with_oracle(c, w, r, n, w.n_genes)
+        n_filtered = int((res.dupinfo["is_filtered_target"] != 0).sum())
+        assert n_filtered > 10_000
+        nnz_filtered = m.nnz
+    finally:
+        O.set_target_filter(None)
+    c.set_target_filter(None)
+    c.reset_counts()
+    res2, m2 = _compare_with_oracle(c, w, r, n, w.n_genes)
+    assert int((res2.dupinfo["is_filtered_target"] != 0).sum()) == 0 and m2.data.sum() > m.data.sum() and m2.nnz >= nnz_filtered
     c.close()
