@@ -59,7 +59,7 @@ def parse_args():
                     help="whitelist entries: 737280 (737K-august-2016) or 6794880 (3M-february-2018, the SC3Pv3 list)")
     ap.add_argument("--dupinfo", action="store_true",
                     help="cfg3: time crgpu_count_records_dev (per-read DupInfo for the BAM tags) instead of the keys-only count")
-    ap.add_argument("--cpu-sample", type=int, default=24_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=64_000_000,
                     help="reads of the CPU-baseline sample (about 10-30 s of oracle work on the box's cores)")
     ap.add_argument("--cpu-1thread-sample", type=int, default=1_000_000)
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed full-size property checks (cfg3, N=1)")
@@ -116,7 +116,20 @@ def cpu_baseline(w, workload, sample, sample_1t):
     from cellranger_amd import engine as E
     from cellranger_amd import synth as S
 
-    cores = len(os.sched_getaffinity(0))
+    # host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one (the
+    # GPU boxes expose 256 hardware threads but give a one-GPU job the share of 16; 256 OpenMP threads on 16 cores' worth of
+    # time only fight each other)
+    affinity = len(os.sched_getaffinity(0))
+    cores = affinity
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(affinity, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("CRGPU_CPU_THREADS"):
+        cores = int(os.environ["CRGPU_CPU_THREADS"])
 
     def run(n_reads, threads):
         r = w.host_reads(0, n_reads)
@@ -140,6 +153,7 @@ def cpu_baseline(w, workload, sample, sample_1t):
         "unit": "M reads/s",
         "cores": cores,
         "threads_used": cores,
+        "hardware_threads_visible": affinity,
         "kind": "port",
         "correct_M_reads_per_s": sample / correct / 1e6,
         "dedup_M_reads_per_s": (sample / dedup / 1e6) if dedup else None,
