@@ -71,11 +71,15 @@ class MatrixDevView(C.Structure):
 
 SHARD_METRIC_FIELDS = ["sequenced_reads", "bc_n_bases", "bc_bases", "umi_n_bases", "umi_bases", "bc_q30_bases", "bc_q30_den",
                        "umi_q30_bases", "umi_q30_den", "good_umi", "has_n_barcode", "has_n_umi", "homopolymer_barcode",
-                       "homopolymer_umi", "low_min_qual_barcode", "low_min_qual_umi", "miss_whitelist_barcode"]
+                       "homopolymer_umi", "low_min_qual_barcode", "low_min_qual_umi", "miss_whitelist_barcode", "polyt_suffix_umi"]
 
 
 class ShardMetrics(C.Structure):
     _fields_ = [(f, C.c_uint64) for f in SHARD_METRIC_FIELDS]
+
+
+class RowsMetrics(C.Structure):
+    _fields_ = [(f, C.c_uint64) for f in ("n_bases", "bases", "q30_bases", "q30_den")]
 
 
 # crgpu_barcode_summary_row as a numpy record
@@ -161,6 +165,9 @@ SYMBOLS = {
     "crgpu_pack_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp]),
     "crgpu_pack_rows_dev": (_i, [_vp, _vp, _vp, _u64, _u32, _u32, _u32, _vp, _vp, _vp]),
     "crgpu_shard_metrics_dev": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, C.POINTER(ShardMetrics)]),
+    "crgpu_rows_metrics_dev": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, C.POINTER(RowsMetrics)]),
+    "crgpu_homopolymer_metrics_dev": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _u32, _vp]),
+    "crgpu_fastq_to_rows_dev": (_i, [_vp, _vp, _u64, _u32, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
     "crgpu_match_and_count_dev": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "crgpu_set_posterior": (_i, [_vp, _dbl, _dbl]),
     "crgpu_correct_dev": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _vp]),
@@ -193,6 +200,7 @@ SYMBOLS = {
     "crgpu_matrix_free": (None, [_vp, C.POINTER(MatrixView)]),
     "crgpu_sum_matrices": (_i, [_vp, C.POINTER(MatrixView), C.POINTER(MatrixView), C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_select_barcodes": (_i, [_vp, C.POINTER(MatrixView), _vp, _u64, C.POINTER(C.POINTER(MatrixView))]),
+    "crgpu_trim_molecule_barcodes_dev": (_i, [_vp, _vp, _u64, _u64, _vp, _u64, _i, _u64, _vp, C.POINTER(_u64)]),
     "crgpu_concat_matrices": (_i, [_vp, _vp, _vp, _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_write_mtx": (_i, [_vp, C.POINTER(MatrixView), C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint16]),
     "crgpu_assemble_matrix_dev": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(MatrixDevView))]),

@@ -2054,3 +2054,109 @@ extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
     cr_pool_free(ctx, c->d_filt_reads);
     delete c;
 }
+
+// ------------------------------------------------------------------------------------------------
+// aggr: MERGE_MOLECULES on the barcode_idx column
+// ------------------------------------------------------------------------------------------------
+// MoleculeInfoWriter::trim_barcodes (cr_h5/src/molecule_info.rs:890-960) keeps the barcodes of pass_filter and, unless
+// pass_only, every barcode that a molecule refers to, in ascending order, and rewrites barcode_idx to positions in the
+// trimmed list; MERGE_MOLECULES' join (cr_aggr/src/merge_molecules.rs:131-330) then concatenates the samples with
+// barcode_idx shifted by the number of barcodes retained before (bc_idx_offsets).  The H5 container, the gem-group /
+// library look-up tables (two tiny maps applied per row) and the metrics JSON stay with the host.
+__global__ __launch_bounds__(256) void k_mark_u64(const uint64_t *__restrict__ idx, uint64_t n, uint64_t limit, uint8_t *__restrict__ flag,
+                                                  uint32_t *__restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t v = idx[i];
+        if (v < limit) flag[v] = 1; else *bad = 1u;
+    }
+}
+struct EmitRetained {
+    uint32_t *retained, *newpos;
+    struct Pre {};
+    __device__ __forceinline__ Pre pre(uint64_t) const { return Pre(); }
+    __device__ __forceinline__ void operator()(uint64_t k, uint32_t o, Pre) const {
+        retained[o] = (uint32_t)k;
+        newpos[k] = o;
+    }
+};
+__global__ __launch_bounds__(256) void k_remap_u64(uint64_t *__restrict__ idx, uint64_t n, const uint32_t *__restrict__ newpos,
+                                                   uint64_t offset) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) idx[i] = offset + newpos[idx[i]];
+}
+
+extern "C" int crgpu_trim_molecule_barcodes_dev(crgpu_ctx *ctx, uint64_t *d_barcode_idx_inout, uint64_t n_molecules,
+                                                uint64_t n_barcodes, uint64_t *pass_filter_idx_inout, uint64_t n_pass,
+                                                int pass_only, uint64_t barcode_idx_offset, uint64_t *retained_out,
+                                                uint64_t *n_retained_out) {
+    if (!ctx || !n_retained_out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    *n_retained_out = 0;
+    CR_REQUIRE(ctx, n_barcodes < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_trim_molecule_barcodes: at most 2^32-2 barcodes");
+    CR_REQUIRE(ctx, n_molecules == 0 || d_barcode_idx_inout, CRGPU_EINVAL, "crgpu_trim_molecule_barcodes: NULL barcode_idx");
+    CR_REQUIRE(ctx, n_pass == 0 || pass_filter_idx_inout, CRGPU_EINVAL, "crgpu_trim_molecule_barcodes: NULL pass_filter");
+    cr_invalidate(ctx);
+    DevBuf flag_b, ret_b, pos_b, pf_b;
+    CR_TRY(dmalloc(ctx, flag_b, n_barcodes + 1));
+    CR_TRY(dmalloc(ctx, ret_b, (n_barcodes + 1) * sizeof(uint32_t)));
+    CR_TRY(dmalloc(ctx, pos_b, (n_barcodes + 1) * sizeof(uint32_t)));
+    uint8_t *flag = flag_b.as<uint8_t>();
+    uint32_t *d_bad = ctx->d_scalars + 60, *d_total = ctx->d_scalars + 16, bad = 0, kept = 0;
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX, n_molecules);
+        CR_HIP(ctx, hipMemsetAsync(flag, 0, n_barcodes + 1, ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
+        if (n_pass) {
+            CR_TRY(dmalloc(ctx, pf_b, n_pass * sizeof(uint64_t)));
+            CR_HIP(ctx, hipMemcpyAsync(pf_b.p, pass_filter_idx_inout, n_pass * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_mark_u64, dim3(cr_grid(n_pass, 256)), dim3(256), 0, ctx->stream, pf_b.as<uint64_t>(), n_pass, n_barcodes, flag, d_bad);
+        }
+        if (!pass_only && n_molecules)
+            hipLaunchKernelGGL(k_mark_u64, dim3(cr_grid(n_molecules, 256)), dim3(256), 0, ctx->stream, d_barcode_idx_inout, n_molecules,
+                               n_barcodes, flag, d_bad);
+        CR_HIP(ctx, hipGetLastError());
+        if (n_barcodes)
+            CR_TRY(compact(ctx, CandFlag{flag}, EmitRetained{ret_b.as<uint32_t>(), pos_b.as<uint32_t>()}, n_barcodes, ctx->d_sort_hist, d_total));
+    }
+    CR_TRY(read_u32(ctx, d_bad, &bad));
+    CR_REQUIRE(ctx, !bad, CRGPU_EINVAL, "crgpu_trim_molecule_barcodes: a barcode index lies beyond the %llu barcodes",
+               (unsigned long long)n_barcodes);
+    if (n_barcodes) CR_TRY(read_u32(ctx, d_total, &kept));
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX);
+        // with pass_only a molecule may refer to a barcode that is not retained: the reference panics there
+        // ("Error accessing invalid barcode index"); here such rows would read an undefined position, so check first
+        if (pass_only && n_molecules) {
+            DevBuf chk_b;
+            CR_TRY(dmalloc(ctx, chk_b, n_barcodes + 1));
+            CR_HIP(ctx, hipMemsetAsync(chk_b.p, 0, n_barcodes + 1, ctx->stream));
+            hipLaunchKernelGGL(k_mark_u64, dim3(cr_grid(n_molecules, 256)), dim3(256), 0, ctx->stream, d_barcode_idx_inout, n_molecules,
+                               n_barcodes, chk_b.as<uint8_t>(), d_bad);
+            std::vector<uint8_t> used(n_barcodes), keep(n_barcodes);
+            CR_TRY(crgpu_memcpy_d2h(ctx, used.data(), chk_b.p, n_barcodes));
+            CR_TRY(crgpu_memcpy_d2h(ctx, keep.data(), flag, n_barcodes));
+            for (uint64_t b = 0; b < n_barcodes; b++)
+                CR_REQUIRE(ctx, !used[b] || keep[b], CRGPU_EINVAL,
+                           "crgpu_trim_molecule_barcodes: molecules refer to barcode %llu, which pass_filter does not retain",
+                           (unsigned long long)b);
+        }
+        if (n_molecules)
+            hipLaunchKernelGGL(k_remap_u64, dim3(cr_grid(n_molecules, 256)), dim3(256), 0, ctx->stream, d_barcode_idx_inout, n_molecules,
+                               pos_b.as<uint32_t>(), barcode_idx_offset);
+        if (n_pass) {
+            hipLaunchKernelGGL(k_remap_u64, dim3(cr_grid(n_pass, 256)), dim3(256), 0, ctx->stream, pf_b.as<uint64_t>(), n_pass,
+                               pos_b.as<uint32_t>(), barcode_idx_offset);
+            CR_TRY(crgpu_memcpy_d2h(ctx, pass_filter_idx_inout, pf_b.p, n_pass * sizeof(uint64_t)));
+        }
+        CR_HIP(ctx, hipGetLastError());
+    }
+    if (retained_out && kept) {
+        std::vector<uint32_t> r(kept);
+        CR_TRY(crgpu_memcpy_d2h(ctx, r.data(), ret_b.p, (size_t)kept * sizeof(uint32_t)));
+        for (uint32_t i = 0; i < kept; i++) retained_out[i] = r[i];
+    }
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_retained_out = kept;
+    return CRGPU_OK;
+}

@@ -561,6 +561,26 @@ class Context:
                                                    _p(d_idx), n, C.byref(m)))
         return {f: int(getattr(m, f)) for f in _lib.SHARD_METRIC_FIELDS}
 
+    def rows_metrics(self, d_seq_rows, d_qual_rows, n, row_stride, d_len=None):
+        """frac_n_bases / frac_q30_bases of one read of the pair over FASTQ rows, as a dict of counts"""
+        m = _lib.RowsMetrics()
+        self._check(self.L.crgpu_rows_metrics_dev(self.h, _p(d_seq_rows), _p(d_qual_rows), _p(d_len), n, row_stride, C.byref(m)))
+        return {f: int(getattr(m, f)) for f, _ in _lib.RowsMetrics._fields_}
+
+    def homopolymer_metrics(self, d_r1_rows, r1_stride, n, d_r2_rows=None, r2_stride=0, d_r1_len=None, d_r2_len=None, run_len=15):
+        """{A,C,G,T}_perfect_homopolymer: reads whose R1 or R2 holds run_len equal bases in a row"""
+        out = np.zeros(4, np.uint64)
+        self._check(self.L.crgpu_homopolymer_metrics_dev(self.h, _p(d_r1_rows), r1_stride, _p(d_r1_len), _p(d_r2_rows), r2_stride,
+                                                         _p(d_r2_len), n, run_len, ptr(out)))
+        return dict(zip("ACGT", (int(x) for x in out)))
+
+    def fastq_to_rows(self, d_text, n_bytes, row_stride, max_records, d_seq_rows, d_qual_rows, d_len=None):
+        """FASTQ text (device) -> rows; returns the number of records"""
+        n = C.c_uint64()
+        self._check(self.L.crgpu_fastq_to_rows_dev(self.h, _p(d_text), n_bytes, row_stride, max_records, _p(d_seq_rows), _p(d_qual_rows),
+                                                   _p(d_len), C.byref(n)))
+        return n.value
+
     def sum_matrices(self, a, b):
         """CountMatrix.merge: element-wise sum of two matrices of the same shape"""
         mv = C.POINTER(MatrixView)()
@@ -586,6 +606,16 @@ class Context:
         mv = C.POINTER(_lib.MatrixDevView)()
         self._check(self.L.crgpu_select_barcodes_dev(self.h, m._mv, ptr(cols), len(cols), C.byref(mv)))
         return MatrixDev(self, mv)
+
+    def trim_molecule_barcodes(self, d_barcode_idx, n_molecules, n_barcodes, pass_filter_idx=None, pass_only=False, offset=0):
+        """MERGE_MOLECULES on barcode_idx (crgpu.h): rewrites the device column in place; returns (retained old indices,
+        rewritten pass_filter indices)"""
+        pf = np.zeros(0, np.uint64) if pass_filter_idx is None else np.ascontiguousarray(pass_filter_idx, dtype=np.uint64).copy()
+        retained = np.zeros(n_barcodes, np.uint64)
+        n = C.c_uint64()
+        self._check(self.L.crgpu_trim_molecule_barcodes_dev(self.h, _p(d_barcode_idx), n_molecules, n_barcodes, ptr(pf) if len(pf) else None,
+                                                            len(pf), int(pass_only), offset, ptr(retained), C.byref(n)))
+        return retained[: n.value], pf
 
     def concat_matrices(self, mats, gem_groups):
         """merged matrix of several GEM wells: column concatenation in (gem_group, barcode) order"""

@@ -169,7 +169,7 @@ int crgpu_pack_rows_dev(crgpu_ctx *ctx, const uint8_t *d_seq_rows, const uint8_t
  * read (cr_lib/src/make_shard_metrics.rs:263-332; frac_n_bases / frac_q30_bases :355-392; thresholds :20-23), as one
  * fused scan over the packed arrays (crgpu_pack_dev layout).  PercentMetrics come back as numerator / denominator
  * counts; they add up over batches in the caller.  d_idx (nullable): pass A's output, for miss_whitelist_barcode.
- * Not covered: R1/R2/I1/I2 metrics (those sequences are not inputs of this path), polyt_suffix_umi. */
+ * The whole-read metrics (R1 / R2 / I1 / I2 N and Q30 fractions, the perfect-homopolymer flags) are below. */
 typedef struct {
     uint64_t sequenced_reads;
     uint64_t bc_n_bases, bc_bases;          /* bc_N_bases */
@@ -181,10 +181,36 @@ typedef struct {
     uint64_t homopolymer_barcode, homopolymer_umi;
     uint64_t low_min_qual_barcode, low_min_qual_umi; /* min quality - 33 < 10 */
     uint64_t miss_whitelist_barcode;
+    uint64_t polyt_suffix_umi;              /* the last 5 bases of the UMI are T (UMI_POLYT_SUFFIX_LENGTH, :23,317-321) */
 } crgpu_shard_metrics;
 int crgpu_shard_metrics_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_cb_qualn, uint32_t cb_len,
                             const uint32_t *d_umi, const uint8_t *d_umi_qualn, uint32_t umi_len, const uint32_t *d_idx,
                             uint64_t n, crgpu_shard_metrics *out);
+
+/* Whole-read metrics of MakeShardVisitor::visit_processed_read over read rows as the FASTQ holds them (n rows of
+ * row_stride bytes, sequence and quality; d_len (nullable) = bases of every row, else row_stride):
+ *   crgpu_rows_metrics_dev        frac_n_bases / frac_q30_bases of one read of the pair (read_N_bases, read_bases_with_q30,
+ *                                 read2_*, i1_*, i2_*: make_shard_metrics.rs:266-279,355-392), as counts;
+ *   crgpu_homopolymer_metrics_dev {A,C,G,T}_perfect_homopolymer (:281-300): reads whose R1 OR R2 (d_r2_rows nullable) holds
+ *                                 run_len (HOMOPOLYMER_LENGTH = 15) equal bases in a row; out4 = counts for A, C, G, T.
+ * PatternCheck lives in an un-vendored crate: "the pattern occurs in the read" is the reading taken; parity unpinned. */
+typedef struct {
+    uint64_t n_bases, bases;      /* frac_n_bases */
+    uint64_t q30_bases, q30_den;  /* frac_q30_bases: q >= 30+33 over q > 2+33 */
+} crgpu_rows_metrics;
+int crgpu_rows_metrics_dev(crgpu_ctx *ctx, const uint8_t *d_seq_rows, const uint8_t *d_qual_rows, const uint32_t *d_len,
+                           uint64_t n, uint32_t row_stride, crgpu_rows_metrics *out);
+int crgpu_homopolymer_metrics_dev(crgpu_ctx *ctx, const uint8_t *d_r1_rows, uint32_t r1_stride, const uint32_t *d_r1_len,
+                                  const uint8_t *d_r2_rows, uint32_t r2_stride, const uint32_t *d_r2_len, uint64_t n,
+                                  uint32_t run_len, uint64_t *out4);
+/* FASTQ text -> read rows (the device side of the ingest; decompression stays with the host): d_text holds
+ * whole 4-line records (LF or CRLF; the last line may lack its line end).  Record r's sequence and quality go to row r
+ * of d_seq_rows / d_qual_rows (row_stride bytes each, zero-padded; longer reads are cut and reported through d_len),
+ * d_len_out[r] (nullable) = its length in the file.  A record whose header does not start with '@', whose third line does
+ * not start with '+' or whose sequence and quality differ in length makes the call fail (CRGPU_EINVAL), as does a line
+ * count that is not a multiple of four.  max_records: room in the row buffers (CRGPU_ERANGE beyond). */
+int crgpu_fastq_to_rows_dev(crgpu_ctx *ctx, const uint8_t *d_text, uint64_t n_bytes, uint32_t row_stride, uint64_t max_records,
+                            uint8_t *d_seq_rows, uint8_t *d_qual_rows, uint32_t *d_len_out, uint64_t *n_records_out);
 
 /* ---- pass A: exact match + valid-barcode histogram (K1) -----------------------------------------
  * Replaces Whitelist::check_and_update per read (whitelist.rs:494-517, called from
@@ -432,6 +458,16 @@ void crgpu_matrix_free(crgpu_ctx *ctx, crgpu_matrix *m);
  * crgpu_select_barcodes CountMatrix.select_barcodes (matrix.py:860-875): the given columns in the given order. */
 int crgpu_sum_matrices(crgpu_ctx *ctx, const crgpu_matrix *a, const crgpu_matrix *b, crgpu_matrix **out);
 int crgpu_select_barcodes(crgpu_ctx *ctx, const crgpu_matrix *a, const uint64_t *cols, uint64_t n_cols, crgpu_matrix **out);
+/* aggr's MERGE_MOLECULES on the barcode_idx column of a sample's molecule table:
+ * MoleculeInfoWriter::trim_barcodes (cr_h5/src/molecule_info.rs:890-960) + the offset of the join
+ * (cr_aggr/src/merge_molecules.rs:131-330).  Retained = the barcodes of pass_filter and, unless pass_only, every barcode a
+ * molecule refers to, ascending; d_barcode_idx_inout (device, n_molecules) and pass_filter_idx_inout (host, n_pass; column 0
+ * of barcode_info/pass_filter) are rewritten to barcode_idx_offset + position in the retained list; retained_out (host,
+ * room for n_barcodes entries, nullable) receives the old indices kept, *n_retained_out their number (the next sample's
+ * offset is barcode_idx_offset + that).  The H5 container, the gem-group / library maps and the metrics stay with the host. */
+int crgpu_trim_molecule_barcodes_dev(crgpu_ctx *ctx, uint64_t *d_barcode_idx_inout, uint64_t n_molecules, uint64_t n_barcodes,
+                                     uint64_t *pass_filter_idx_inout, uint64_t n_pass, int pass_only,
+                                     uint64_t barcode_idx_offset, uint64_t *retained_out, uint64_t *n_retained_out);
 /* Several GEM wells of one sample (BASELINE configs[4]: one well per GPU): the merged matrix is the column
  * concatenation in (gem_group, barcode) order -- Barcode orders by gem group first (barcode/src/lib.rs:119-124).
  * gem_groups[i] is the group of mats[i], strictly ascending; all matrices share n_features and cb_len. */

@@ -283,6 +283,11 @@ void oracle_shard_metrics_scan(const char *cb, const uint8_t *cb_qual, uint32_t 
         m.low_min_qual_barcode += (uint8_t)(min_qual(bq, cb_len) - 33) < 10; /* BARCODE_MIN_QUAL_THRESHOLD, :21,313-315 */
         m.low_min_qual_umi += (uint8_t)(min_qual(uq, umi_len) - 33) < 10;    /* UMI_MIN_QUAL_THRESHOLD, :22,316 */
         if (exact_hit) m.miss_whitelist_barcode += !exact_hit[r];
+        if (umi_len >= 5) { /* UMI_POLYT_SUFFIX_LENGTH, :23,317-321 */
+            int all_t = 1;
+            for (uint32_t i = umi_len - 5; i < umi_len; i++) all_t &= u[i] == 'T';
+            m.polyt_suffix_umi += (uint64_t)all_t;
+        }
     }
     *out = m;
 }

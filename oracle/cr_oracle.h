@@ -218,8 +218,8 @@ void oracle_compute_feature_dist(const int64_t *counts, const uint32_t *feature_
  * :355-392; constants :20-23; RnaRead::barcode_min_qual / umi_min_qual cr_types/src/rna_read.rs:738-749).
  * PercentMetric numerators / denominators as plain counts.  bc_state: the oracle_barcode_stage result
  * (0 = not on the whitelist after pass A ... see BcResult); miss_whitelist counts reads whose barcode is invalid
- * after the exact match, i.e. bc_state != 1.  Not restated: the R1/R2/I1/I2 metrics (those sequences are not inputs of
- * this path) and polyt_suffix_umi (SSeq::has_polyt_suffix lives in the un-vendored fastq_set crate). */
+ * after the exact match, i.e. bc_state != 1.  The whole-read metrics (R1/R2/I1/I2 N and Q30 fractions, perfect
+ * homopolymers) are restated in numpy next to their GPU test (tests/test_gpu_configs.py). */
 typedef struct {
     uint64_t sequenced_reads;
     uint64_t bc_n_bases, bc_bases;          /* bc_N_bases */
@@ -231,6 +231,8 @@ typedef struct {
     uint64_t homopolymer_barcode, homopolymer_umi;
     uint64_t low_min_qual_barcode, low_min_qual_umi; /* min quality - 33 < 10 */
     uint64_t miss_whitelist_barcode;
+    uint64_t polyt_suffix_umi; /* last UMI_POLYT_SUFFIX_LENGTH = 5 bases are 'T' (make_shard_metrics.rs:23,317-321; SSeq::has_polyt_suffix
+                                  is in the un-vendored fastq_set crate: the reading taken, parity unpinned) */
 } oracle_shard_metrics;
 void oracle_shard_metrics_scan(const char *cb, const uint8_t *cb_qual, uint32_t cb_len, const char *umi,
                                const uint8_t *umi_qual, uint32_t umi_len, const uint8_t *exact_hit /* nullable */,

@@ -416,7 +416,7 @@ def compute_feature_dist(counts, feature_types):
 
 SHARD_METRIC_FIELDS = ["sequenced_reads", "bc_n_bases", "bc_bases", "umi_n_bases", "umi_bases", "bc_q30_bases", "bc_q30_den",
                        "umi_q30_bases", "umi_q30_den", "good_umi", "has_n_barcode", "has_n_umi", "homopolymer_barcode",
-                       "homopolymer_umi", "low_min_qual_barcode", "low_min_qual_umi", "miss_whitelist_barcode"]
+                       "homopolymer_umi", "low_min_qual_barcode", "low_min_qual_umi", "miss_whitelist_barcode", "polyt_suffix_umi"]
 
 
 class _ShardMetrics(C.Structure):

@@ -208,3 +208,120 @@ def test_aggr_merge_and_barcode_selection_match_scipy():
     with pytest.raises(CrgpuError):
         c.sum_matrices_dev(dtot, dsel)
     c.close()
+
+
+def test_merge_molecules_barcode_trimming_matches_the_reference_rule():
+    """aggr's MERGE_MOLECULES on the barcode_idx column: trim_barcodes (cr_h5/src/molecule_info.rs:890-960: retain the
+    pass_filter barcodes and every barcode with a molecule, ascending, re-index) + the per-sample offset of the join
+    (cr_aggr/src/merge_molecules.rs:131-330), restated in numpy for two samples."""
+    import gpu_helpers as G
+    from cellranger_amd._lib import CrgpuError
+
+    rng = np.random.default_rng(3)
+    c = G.fresh_ctx()
+    offset = 0
+    for n_bc, n_mol, n_pass in ((5000, 40_000, 300), (737_280, 2_000_000, 9000)):
+        used_pool = rng.choice(n_bc, size=n_bc // 4, replace=False)
+        idx = np.sort(rng.choice(used_pool, size=n_mol)).astype(np.uint64)      # molecule rows are sorted by barcode
+        pf = np.sort(rng.choice(n_bc, size=n_pass, replace=False)).astype(np.uint64)
+        for pass_only in (False,):
+            keep = np.union1d(pf, idx) if not pass_only else pf
+            newpos = np.full(n_bc, -1, np.int64)
+            newpos[keep] = np.arange(len(keep))
+            d_idx = c.upload(idx)
+            retained, pf_new = c.trim_molecule_barcodes(d_idx, n_mol, n_bc, pf, pass_only=pass_only, offset=offset)
+            assert np.array_equal(retained, keep.astype(np.uint64))
+            assert np.array_equal(d_idx.to_host(), (offset + newpos[idx]).astype(np.uint64))
+            assert np.array_equal(pf_new, (offset + newpos[pf]).astype(np.uint64))
+        offset += len(keep)
+    # pass_only with a molecule outside pass_filter is an error (the reference panics on it), never a silent remap
+    d_idx = c.upload(np.array([1, 2, 7], np.uint64))
+    with pytest.raises(CrgpuError):
+        c.trim_molecule_barcodes(d_idx, 3, 10, np.array([1, 2], np.uint64), pass_only=True)
+    r, pf = c.trim_molecule_barcodes(d_idx, 3, 10, np.array([1, 2, 7, 9], np.uint64), pass_only=True)
+    assert list(r) == [1, 2, 7, 9] and list(d_idx.to_host()) == [0, 1, 2] and list(pf) == [0, 1, 2, 3]
+    with pytest.raises(CrgpuError):
+        c.trim_molecule_barcodes(c.upload(np.array([11], np.uint64)), 1, 10)
+    c.close()
+
+
+def _fastq_text(seqs, quals, crlf=False, final_newline=True):
+    nl = b"\r\n" if crlf else b"\n"
+    recs = [b"@read%d some text" % i + nl + s + nl + b"+" + nl + q for i, (s, q) in enumerate(zip(seqs, quals))]
+    return nl.join(recs) + (nl if final_newline else b"")
+
+
+def test_fastq_ingest_rows_and_whole_read_metrics():
+    """The MAKE_SHARD side of the ingest on the device: FASTQ text -> read rows (crgpu_fastq_to_rows_dev), the
+    whole-read N / Q30 fractions and the perfect-homopolymer flags of MakeShardVisitor::visit_processed_read
+    (cr_lib/src/make_shard_metrics.rs:266-300,355-392), then the barcode / UMI slices packed from the rows and their shard
+    metrics incl. polyt_suffix_umi -- each against a plain numpy / Python restatement of the cited lines.  (The reference's
+    FASTQ reader, PatternCheck and has_polyt_suffix live in the un-vendored fastq_set crate: parity unpinned.)"""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd._lib import CrgpuError
+
+    rng = np.random.default_rng(17)
+    n = 30_000
+    seqs, quals = [], []
+    for i in range(n):
+        L = int(rng.integers(28, 120))
+        s = bytearray(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L, p=[0.24, 0.24, 0.24, 0.24, 0.04]).tobytes())
+        if i % 7 == 0:   # plant homopolymers of 14..17 bases
+            k, b = int(rng.integers(14, 18)), b"ACGT"[i % 4]
+            at = int(rng.integers(0, max(1, L - k)))
+            s[at:at + k] = bytes([b]) * min(k, L - at)
+        if i % 11 == 0:  # UMIs (bases 16..28) ending in T's
+            s[23:28] = b"TTTTT"
+        seqs.append(bytes(s))
+        quals.append(rng.choice(np.array([33, 35, 36, 44, 58, 63, 70], np.uint8), size=L).tobytes())
+    stride = 128
+    c = G.fresh_ctx()
+    for crlf, final_nl in ((False, True), (True, False)):
+        text = np.frombuffer(_fastq_text(seqs, quals, crlf, final_nl), np.uint8)
+        d_text = c.upload(text)
+        d_seq, d_qual, d_len = c.empty((n, stride), np.uint8), c.empty((n, stride), np.uint8), c.empty(n, np.uint32)
+        assert c.fastq_to_rows(d_text, len(text), stride, n, d_seq, d_qual, d_len) == n
+        rows, qrows, lens = d_seq.to_host(), d_qual.to_host(), d_len.to_host()
+        for i in (0, 1, 2, n // 2, n - 2, n - 1):
+            L = len(seqs[i])
+            assert lens[i] == L and rows[i, :L].tobytes() == seqs[i] and qrows[i, :L].tobytes() == quals[i]
+            assert not rows[i, L:].any() and not qrows[i, L:].any()
+        assert np.array_equal(lens, np.array([len(s) for s in seqs], np.uint32))
+    # whole-read metrics (frac_n_bases, frac_q30_bases)
+    m = c.rows_metrics(d_seq, d_qual, n, stride, d_len)
+    allq = np.frombuffer(b"".join(quals), np.uint8)
+    alls = np.frombuffer(b"".join(seqs), np.uint8)
+    assert m == dict(n_bases=int((alls == ord("N")).sum()), bases=len(alls), q30_bases=int((allq >= 63).sum()),
+                     q30_den=int((allq > 35).sum()))
+    # perfect homopolymers: 15 equal bases in a row, in R1 or (second call) in R1 or R2
+    def has(s, b):
+        return (bytes([b]) * 15) in s
+    exp1 = {ch: sum(has(s, ord(ch)) for s in seqs) for ch in "ACGT"}
+    assert c.homopolymer_metrics(d_seq, stride, n, d_r1_len=d_len) == exp1 and min(exp1.values()) > 100
+    r2 = [seqs[(i * 7 + 3) % n] for i in range(n)]
+    d_r2 = c.upload(np.stack([np.frombuffer(s.ljust(stride, b"\0"), np.uint8) for s in r2]))
+    d_r2len = c.upload(np.array([len(s) for s in r2], np.uint32))
+    exp2 = {ch: sum(has(a, ord(ch)) or has(b, ord(ch)) for a, b in zip(seqs, r2)) for ch in "ACGT"}
+    assert c.homopolymer_metrics(d_seq, stride, n, d_r2_rows=d_r2, r2_stride=stride, d_r1_len=d_len, d_r2_len=d_r2len) == exp2
+    # the barcode / UMI slices from the rows, their metrics with the 5-T suffix flag
+    d_cb, d_cbq, d_fl = c.empty(n, np.uint32), c.empty((n, 16), np.uint8), c.zeros(n, np.uint8)
+    d_umi, d_uq = c.empty(n, np.uint32), c.empty((n, 10), np.uint8)
+    c.pack_rows(d_seq, d_qual, n, stride, 0, 16, d_cb, d_cbq, d_fl)
+    c.pack_rows(d_seq, d_qual, n, stride, 16, 10, d_umi, d_uq, None)
+    got = c.shard_metrics(d_cb, d_cbq, 16, d_umi, d_uq, 10, None, n)
+    cb = np.stack([np.frombuffer(s[:16], np.uint8) for s in seqs])
+    cbq = np.stack([np.frombuffer(q[:16], np.uint8) for q in quals])
+    um = np.stack([np.frombuffer(s[16:26], np.uint8) for s in seqs])
+    uq = np.stack([np.frombuffer(q[16:26], np.uint8) for q in quals])
+    exp = O.shard_metrics(cb, cbq, um, uq)
+    exp["miss_whitelist_barcode"] = 0
+    assert got == exp
+    # malformed input is refused
+    bad = np.frombuffer(b"@r\nACGT\n+\nIII\n", np.uint8)
+    with pytest.raises(CrgpuError):
+        c.fastq_to_rows(c.upload(bad), len(bad), stride, 4, d_seq, d_qual, d_len)
+    bad = np.frombuffer(b"@r\nACGT\n+\nIIII\n@x\nAC\n", np.uint8)
+    with pytest.raises(CrgpuError):
+        c.fastq_to_rows(c.upload(bad), len(bad), stride, 4, d_seq, d_qual, d_len)
+    c.close()

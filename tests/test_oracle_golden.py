@@ -185,6 +185,10 @@ def test_shard_metrics_hand_computed():
     assert m["low_min_qual_barcode"] == 2         # min q-33: 40, 2, 9
     assert m["low_min_qual_umi"] == 0             # min q-33: 40, 40, 10 (10 is not below 10)
     assert m["miss_whitelist_barcode"] == 1
+    assert m["polyt_suffix_umi"] == 0             # UMIs of 3 bases are shorter than the 5-base suffix
+    umi5 = np.stack([np.frombuffer(b"ACTTTTT", np.uint8), np.frombuffer(b"TTTTTAC", np.uint8), np.frombuffer(b"ATTTTNT", np.uint8)])
+    m5 = O.shard_metrics(np.tile(cb[:1], (3, 1)), np.tile(cbq[:1], (3, 1)), umi5, np.full((3, 7), 73, np.uint8))
+    assert m5["polyt_suffix_umi"] == 1            # only the first ends in TTTTT
 
 
 def test_barcode_summary_hand_computed():
