@@ -97,3 +97,33 @@ __device__ __forceinline__ uint32_t wave_multisplit_rank(uint32_t d, bool ok, C 
     }
     return prev + below;
 }
+
+// Decoupled look-back by one full wave (all 64 lanes must call it): `status` holds one word per tile, flag in the top two
+// bits (0 = nothing yet, 1 = the tile's own count, 2 = inclusive prefix up to and including the tile), value in the low 62.
+// Returns the sum of the counts of all tiles before `tile`.  64 predecessors are read per round trip -- a single lane
+// walking back one word at a time falls behind as soon as a walk takes longer than the stagger between tiles, and then
+// every walk gets long (measured: 60 us per 2048-key tile).
+__device__ __forceinline__ unsigned long long wave_lookback(const unsigned long long *status, uint64_t tile) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long excl = 0;
+    uint64_t end = tile;  // predecessors [.., end) are still to be added
+    for (;;) {
+        const bool valid = end > lane;
+        unsigned long long sv = 2ull << 62;  // before tile 0: an inclusive prefix of 0
+        if (valid) sv = __hip_atomic_load(&status[end - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t flag = (uint32_t)(sv >> 62);
+        const unsigned long long inc = __ballot(flag == 2u), pending = __ballot(flag == 0u);
+        const uint32_t first = inc ? (uint32_t)(__ffsll((long long)inc) - 1) : 64u;
+        const unsigned long long need = first >= 63u ? ~0ull : ((2ull << first) - 1ull);  // lanes 0 .. first
+        if (pending & need) {
+            __builtin_amdgcn_s_sleep(1);
+            continue;  // somebody in front of the first inclusive prefix has not published yet: same window again
+        }
+        unsigned long long v = lane <= first ? (sv & ((1ull << 62) - 1ull)) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        excl += v;
+        if (first < 64u) return excl;
+        end -= 64;
+    }
+}

@@ -266,5 +266,12 @@ static inline uint32_t cr_grid(uint64_t n, uint32_t block, uint32_t max_blocks =
 // internal entry points shared between translation units
 int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
                       uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp);
+// sort on the top key bits only when that saves passes: *low_left low bits are left to cr_finish_emit (0: fully sorted)
+int cr_radix_sort_u64_top(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
+                          uint64_t n, uint32_t hi_bit, bool *result_in_tmp, uint32_t *low_left);
+int cr_radix_sort_u64_full(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp, uint64_t n,
+                           uint32_t hi_bit, bool *result_in_tmp);
+int cr_finish_emit(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, uint64_t *d_ukey,
+                   uint32_t *d_upos, uint64_t *nd_out, bool *fell_back);
 int cr_radix_sort_u32(crgpu_ctx *ctx, uint32_t *d_keys, uint32_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
                       uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
               if (lane == 0) s_ws[j * 4 + wave] = (uint32_t)__popcll(m);
           }
           __syncthreads();
-          if (threadIdx.x < KEY_ITEMS * 4) {  // one wave: exclusive scan of the 64 (slot, wave) counts
+          if (threadIdx.x < KEY_ITEMS * 4) {  // one wave: exclusive scan of the 64 (slot, wave) counts + the look-back
               const uint32_t v = s_ws[threadIdx.x];
               uint32_t x = v;
 #pragma unroll
@@ -236,22 +236,12 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                   if (threadIdx.x >= (uint32_t)d) x += y;
               }
               s_ws[threadIdx.x] = x - v;
-              if (threadIdx.x == KEY_ITEMS * 4 - 1) {
-                  const uint32_t total = x;
-                  unsigned long long excl = 0;
-                  if (c > 0) {
-                      __hip_atomic_store(&status[c], BK_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                      // every lower ticket is held by a workgroup that is running or done: the chain always moves on
-                      for (uint64_t p = c - 1;; p--) {
-                          unsigned long long sv;
-                          do {
-                              sv = __hip_atomic_load(&status[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                              if ((sv >> 62) == 0ull) __builtin_amdgcn_s_sleep(1);
-                          } while ((sv >> 62) == 0ull);
-                          excl += sv & (BK_AGG - 1ull);
-                          if ((sv >> 62) == 2ull) break;
-                      }
-                  }
+              const uint32_t total = __shfl(x, 63);
+              if (threadIdx.x == 0 && c > 0)
+                  __hip_atomic_store(&status[c], BK_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              // every lower ticket is held by a workgroup that is running or done: the chain always moves on
+              const unsigned long long excl = wave_lookback(status, c);
+              if (threadIdx.x == 0) {
                   __hip_atomic_store(&status[c], BK_INC | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   if (c + 1 == n_chunks) *n_out = excl + total;
                   s_c = excl;
@@ -1204,15 +1194,16 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     uint32_t *d_block = ctx->d_sort_hist;      // 4096 u32 block counters of the compactions
     uint32_t *d_total = ctx->d_scalars + 16;   // device-side totals
 
-    // 1. sort the keys
+    // 1. sort the keys: fully, or on their top bits with the finishing left to the run-length pass (CRGPU_SORT_FINISH)
     DevBuf tmp, vtmp;
     CR_TRY(dmalloc(ctx, tmp, n_keys * sizeof(uint64_t)));
     if (pr.d_vals) CR_TRY(dmalloc(ctx, vtmp, n_keys * sizeof(uint32_t)));
     bool in_tmp = false;
-    CR_TRY(cr_radix_sort_u64(ctx, d_keys_inout, tmp.as<uint64_t>(), pr.d_vals, pr.d_vals ? vtmp.as<uint32_t>() : nullptr, n_keys,
-                             0, L.total_bits(), &in_tmp));
-    const uint64_t *keys = in_tmp ? tmp.as<uint64_t>() : d_keys_inout;
-    const uint32_t *vals = pr.d_vals ? (in_tmp ? vtmp.as<uint32_t>() : pr.d_vals) : nullptr;
+    uint32_t low_left = 0;
+    CR_TRY(cr_radix_sort_u64_top(ctx, d_keys_inout, tmp.as<uint64_t>(), pr.d_vals, pr.d_vals ? vtmp.as<uint32_t>() : nullptr, n_keys,
+                                 L.total_bits(), &in_tmp, &low_left));
+    uint64_t *keys_rw = in_tmp ? tmp.as<uint64_t>() : d_keys_inout;
+    uint32_t *vals_rw = pr.d_vals ? (in_tmp ? vtmp.as<uint32_t>() : pr.d_vals) : nullptr;
 
     // 2. distinct (barcode, feature, library, UMI) keys and their run starts (DupBuilder::observe)
     DevBuf ukey_b, upos_b;
@@ -1220,13 +1211,36 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     CR_TRY(dmalloc(ctx, upos_b, (n_keys + 1) * sizeof(uint32_t)));
     uint64_t *ukey = ukey_b.as<uint64_t>();
     uint32_t *upos = upos_b.as<uint32_t>();
-    uint32_t nd32 = 0;
-    {
-        CrTimer t(ctx, CRGPU_T_DEDUP, n_keys);  // the family's unit: one sorted key (counted here, once per call)
-        CR_TRY(compact(ctx, HeadFlag{keys, 1u}, EmitRun{keys, ukey, upos}, n_keys, d_block, d_total));
+    uint64_t nd = 0;
+    bool emitted = false;
+    if (low_left) {
+        bool fell_back = false;
+        CR_TRY(cr_finish_emit(ctx, keys_rw, vals_rw, n_keys, low_left, ukey, upos, &nd, &fell_back));
+        emitted = !fell_back;
+        if (fell_back) {
+            // a run of equal top bits too long for the fused pass: sort the buffer (the same multiset) on all bits
+            ctx->sort_refinished++;
+            uint64_t *other = in_tmp ? d_keys_inout : tmp.as<uint64_t>();
+            uint32_t *vother = pr.d_vals ? (in_tmp ? pr.d_vals : vtmp.as<uint32_t>()) : nullptr;
+            bool flip = false;
+            CR_TRY(cr_radix_sort_u64_full(ctx, keys_rw, other, vals_rw, vother, n_keys, L.total_bits(), &flip));
+            if (flip) {
+                keys_rw = other;
+                vals_rw = vother;
+            }
+        }
     }
-    CR_TRY(read_u32(ctx, d_total, &nd32));
-    const uint64_t nd = nd32;
+    const uint64_t *keys = keys_rw;
+    const uint32_t *vals = vals_rw;
+    if (!emitted) {
+        uint32_t nd32 = 0;
+        {
+            CrTimer t(ctx, CRGPU_T_DEDUP, n_keys);  // the family's unit: one sorted key (counted here, once per call)
+            CR_TRY(compact(ctx, HeadFlag{keys, 1u}, EmitRun{keys, ukey, upos}, n_keys, d_block, d_total));
+        }
+        CR_TRY(read_u32(ctx, d_total, &nd32));
+        nd = nd32;
+    }
 
     // 3. UMI correction + the read moves (state layout: umi_correct.h)
     DevBuf corr_b, incall_b, st_b, minidx_b;

@@ -640,10 +640,14 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
 // the top bits only (all 9 bits wide) and the finishing pass orders the short runs of equal top bits in LDS.  L is the
 // largest value <= 16 that makes ceil((total - L) / 9) passes cover the rest: 61 bits -> 5 passes + 16 bits (instead
 // of 7 passes), 64 -> 6 + 10, 50 -> 4 + 14.  0: keys too short to gain a pass, or not switched on.
-// OFF by default (CRGPU_SORT_FINISH=1 turns it on): at 1 B records the five passes take 18.8 ms instead of 25.7, but the
-// finishing pass as a kernel of its own costs 20 ms (3.8 ms for staging the tiles, 5 ms for the run bounds, 11 ms for the
-// ranks inside the long runs of the big (barcode, gene) segments) -- profiles/r02_finish_pass_ab.txt.  It can pay only
-// once it is fused into the run-length pass that reads the sorted keys anyway.
+// OFF by default (CRGPU_SORT_FINISH=1 turns it on; the whole GPU suite passes with it).  At 1 B records the five passes
+// take 18.7 ms instead of 25.7, but the finishing costs more than the 7 ms it saves, as a kernel of its own (20 ms) and
+// fused with the run-length pass (k_finish_emit, 23 ms against the 3.6 ms of the two compaction launches it replaces:
+// 7.5 ms without any ordering work -- 389 K tiles of 2048 keys with a ticket, ten barriers and a look-back each -- 1.2 ms
+// for the run bounds and 14.4 ms for the ranks).  The ranks are only 4.8 G compare steps, but 13 % of the keys sit in
+// runs of 8 to 64 (the top genes of every cell: Zipf x log-normal cell sizes), their tiles take ten times as long as the
+// others, and under ticket order every later tile waits in its look-back for the slow tile's count with all workgroup
+// slots taken.  profiles/r02_finish_pass_ab.txt.
 uint32_t cr_sort_low_bits(uint32_t total_bits) {
     const char *e = getenv("CRGPU_SORT_FINISH");
     const bool on = e && atoi(e) == 1;
@@ -752,15 +756,9 @@ __global__ __launch_bounds__(256) void k_finish_runs(uint64_t *__restrict__ keys
             const uint64_t k = sk[i];
             const uint64_t top = k >> low_bits, low = k & lowmask;
             uint32_t s = i, e = i + 1, rank = 0;
-#ifndef FIN_EXP_NO_SCAN
             while (s > ra && (sk[s - 1] >> low_bits) == top) s--;
             while (e < rb && (sk[e] >> low_bits) == top) e++;
-#endif
-#ifdef FIN_EXP_NO_RANK
-            if (true) {}
-#else
             if (e - s > FIN_HALO) s_bad = 1u;  // quadratic work beyond this: leave it to the full sort
-#endif
             else {
                 for (uint32_t j = s; j < i; j++) rank += (sk[j] & lowmask) <= low;   // earlier position: ties stay in front
                 for (uint32_t j = i + 1; j < e; j++) rank += (sk[j] & lowmask) < low;
@@ -807,10 +805,13 @@ static int finish_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint6
     return CRGPU_OK;
 }
 
+// low_left (nullable): the caller finishes the sort itself (cr_finish_emit: finishing pass fused with the run-length
+// pass); *low_left = number of low bits the passes did not sort on (0: fully sorted)
 template <typename K>
 static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp, uint64_t n,
-                      uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
+                      uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp, uint32_t *low_left = nullptr) {
     *result_in_tmp = false;
+    if (low_left) *low_left = 0;
     if (n <= 1 || hi_bit <= lo_bit) return CRGPU_OK;
     CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "sort: at most 2^32-2 keys per call");
     K *in = d_keys, *out = d_tmp;
@@ -841,6 +842,10 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
                 CR_TRY(onesweep_sort_u64<false>(ctx, k0, k1, nullptr, nullptr, n, plan, widths, result_in_tmp,
                                                 have_hist ? gh.d_hist : nullptr));
             if (!low) return CRGPU_OK;
+            if (low_left) {
+                *low_left = low;
+                return CRGPU_OK;
+            }
             bool fell_back = false;
             CR_TRY(finish_runs(ctx, *result_in_tmp ? k1 : k0, d_vals ? (*result_in_tmp ? d_vals_tmp : d_vals) : nullptr, n, low,
                                &fell_back));
@@ -889,6 +894,260 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
 int cr_radix_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
                       uint64_t n, uint32_t lo_bit, uint32_t hi_bit, bool *result_in_tmp) {
     return radix_sort<uint64_t>(ctx, d_keys, d_tmp, d_vals, d_vals_tmp, n, lo_bit, hi_bit, result_in_tmp);
+}
+// all key bits by radix passes, whatever CRGPU_SORT_FINISH says (the fallback of the fused finishing pass)
+int cr_radix_sort_u64_full(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp, uint64_t n,
+                           uint32_t hi_bit, bool *result_in_tmp) {
+    *result_in_tmp = false;
+    if (n <= 1) return CRGPU_OK;
+    SweepPlan full;
+    uint32_t fw[OS_MAX_PASSES];
+    ctx->ghist.valid = false;
+    if (!cr_sweep_plan(0, hi_bit, &full, fw))  // CRGPU_SORT=classic: the generic path sorts all bits anyway
+        return radix_sort<uint64_t>(ctx, d_keys, d_tmp, d_vals, d_vals_tmp, n, 0, hi_bit, result_in_tmp);
+    if (d_vals) return onesweep_sort_u64<true>(ctx, d_keys, d_tmp, d_vals, d_vals_tmp, n, full, fw, result_in_tmp, nullptr);
+    return onesweep_sort_u64<false>(ctx, d_keys, d_tmp, nullptr, nullptr, n, full, fw, result_in_tmp, nullptr);
+}
+int cr_radix_sort_u64_top(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
+                          uint64_t n, uint32_t hi_bit, bool *result_in_tmp, uint32_t *low_left) {
+    return radix_sort<uint64_t>(ctx, d_keys, d_tmp, d_vals, d_vals_tmp, n, 0, hi_bit, result_in_tmp, low_left);
+}
+
+// ---- finishing pass fused with the run-length pass -----------------------------------------------------------------------
+// The keys are sorted by their top bits (stable otherwise).  One pass over them orders every run of equal top bits by its
+// low bits in LDS (as k_finish_runs does) AND emits the distinct keys (ignoring the utype bit 0) with the position of their
+// first read -- what the two HeadFlag compaction launches did on fully sorted keys -- so the finishing costs no pass of
+// its own.  Tiles are handed out by tickets and get the number of distinct keys before them from a decoupled look-back
+// (one status word per tile), which keeps the output in key order.  WRITE_BACK (the per-read DupInfo path): the ordered
+// keys and payloads also go back to the buffer.  A run that outgrows the staged window raises *fallback (nothing of that
+// tile is emitted or written; the chain still moves on) and the host redoes everything the slow way.
+#define FE_TILE 2048u
+#define FE_HALO 512u
+#define FE_CAP (1u + FE_TILE + FE_HALO)
+#define FE_ROUNDS ((FE_CAP + 255u) / 256u)   // 11
+#define FE_WORDS ((FE_CAP + 63u) / 64u)      // 41
+template <bool WRITE_BACK>
+__global__ __launch_bounds__(256) void k_finish_emit(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n,
+                                                     uint32_t low_bits, uint64_t *__restrict__ ukey, uint32_t *__restrict__ upos,
+                                                     unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
+                                                     unsigned long long *__restrict__ n_out, uint32_t *__restrict__ fallback) {
+    __shared__ __attribute__((aligned(16))) uint64_t sk[FE_CAP];
+    __shared__ uint16_t slo[FE_CAP], spos[FE_CAP];
+    __shared__ uint32_t sv[WRITE_BACK ? FE_CAP : 1];
+    __shared__ unsigned long long s_head[FE_WORDS + 1];
+    __shared__ uint32_t s_cnt[FE_ROUNDS * 4 + 4];
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_tile, s_a, s_b, s_bad;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t n_tiles = (n + FE_TILE - 1) / FE_TILE;
+    const uint32_t lowmask = (1u << low_bits) - 1u;
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint64_t tile = s_tile;
+        if (tile >= n_tiles) break;  // uniform
+        const uint64_t t0 = tile * FE_TILE, t1 = t0 + FE_TILE < n ? t0 + FE_TILE : n;
+        const uint64_t w0 = t0 ? t0 - 1 : 0, w1 = t1 + FE_HALO < n ? t1 + FE_HALO : n;
+        const uint32_t cnt = (uint32_t)(w1 - w0), off0 = (uint32_t)(t0 - w0), off1 = (uint32_t)(t1 - w0);
+        if (tid == 0) s_bad = 0u;
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const uint64_t k = keys[w0 + i];
+            sk[i] = k;
+            slo[i] = (uint16_t)((uint32_t)k & lowmask);
+            if (WRITE_BACK) sv[i] = vals[w0 + i];
+        }
+        __syncthreads();
+        // run heads (equal top bits) as a bit mask: one ballot per 64 positions
+#pragma unroll 1
+        for (uint32_t j = 0; j < FE_ROUNDS; j++) {
+            const uint32_t i = j * 256u + tid;
+            bool h = false;
+            if (i < cnt) h = i == 0 ? (w0 == 0) : (sk[i] >> low_bits) != (sk[i - 1] >> low_bits);
+            const unsigned long long m = __ballot(h);
+            if (lane == 0 && j * 4u + wave < FE_WORDS + 1) s_head[j * 4u + wave] = m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // [ra, rb): the whole runs whose head lies in the tile
+            uint32_t ra = 0xFFFFFFFFu, rb = 0xFFFFFFFFu;
+            for (uint32_t w = off0 >> 6; w < FE_WORDS && ra == 0xFFFFFFFFu; w++) {
+                unsigned long long m = s_head[w];
+                if (w == (off0 >> 6)) m &= ~0ull << (off0 & 63u);
+                if (m) ra = w * 64u + (uint32_t)(__ffsll((long long)m) - 1);
+            }
+            for (uint32_t w = off1 >> 6; w < FE_WORDS && rb == 0xFFFFFFFFu; w++) {
+                unsigned long long m = s_head[w];
+                if (w == (off1 >> 6)) m &= ~0ull << (off1 & 63u);
+                if (m) rb = w * 64u + (uint32_t)(__ffsll((long long)m) - 1);
+            }
+            if (rb == 0xFFFFFFFFu && w1 == n) rb = cnt;  // the last run ends with the array
+            if (ra != 0xFFFFFFFFu && ra >= off1) ra = 0xFFFFFFFFu;  // no run begins in this tile
+            if (ra != 0xFFFFFFFFu && rb == 0xFFFFFFFFu) s_bad = 1u;  // the tile's last run goes on beyond the halo
+            s_a = ra;
+            s_b = rb;
+        }
+        __syncthreads();
+        const uint32_t ra = s_a, rb = s_b;
+        const bool active = ra != 0xFFFFFFFFu && !s_bad;
+        // place of every key inside its run: bounds from the bit mask, rank by the 16-bit low parts
+        uint64_t mykey[FE_ROUNDS];
+        uint32_t myval[FE_ROUNDS];
+        if (active) {
+#pragma unroll 1
+            for (uint32_t j = 0; j < FE_ROUNDS; j++) {
+                const uint32_t i = j * 256u + tid;
+                if (i < ra || i >= rb) continue;
+                // s = last head at or before i
+                uint32_t w = i >> 6;
+                unsigned long long m = s_head[w] & (~0ull >> (63u - (i & 63u)));
+                while (!m) m = s_head[--w];  // position ra is a head: the walk ends there at the latest
+                const uint32_t s0 = w * 64u + 63u - (uint32_t)__clzll((long long)m);
+                // e = first head after i, or rb
+                uint32_t e0 = rb;
+                w = i >> 6;
+                m = (i & 63u) == 63u ? 0ull : (s_head[w] & (~0ull << ((i & 63u) + 1u)));
+                for (;;) {
+                    if (m) {
+                        const uint32_t c = w * 64u + (uint32_t)(__ffsll((long long)m) - 1);
+                        e0 = c < rb ? c : rb;
+                        break;
+                    }
+                    if (++w >= FE_WORDS || w * 64u >= rb) break;
+                    m = s_head[w];
+                }
+                uint32_t rank = i - s0;
+                if (e0 - s0 > 1u) {
+                    if (e0 - s0 > FE_HALO) {
+                        s_bad = 1u;  // quadratic work beyond this: the slow way
+                    } else {
+                        const uint32_t low = slo[i];
+                        rank = 0;
+                        for (uint32_t q = s0; q < i; q++) rank += slo[q] <= low;   // earlier position: ties stay in front
+                        for (uint32_t q = i + 1; q < e0; q++) rank += slo[q] < low;
+                    }
+                }
+                spos[i] = (uint16_t)(s0 + rank);
+            }
+        }
+        __syncthreads();
+        const bool ok = active && !s_bad;
+        if (ok) {
+            // permute in place through registers
+#pragma unroll
+            for (uint32_t j = 0; j < FE_ROUNDS; j++) {
+                const uint32_t i = j * 256u + tid;
+                if (i >= ra && i < rb) {
+                    mykey[j] = sk[i];
+                    if (WRITE_BACK) myval[j] = sv[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (ok) {
+#pragma unroll
+            for (uint32_t j = 0; j < FE_ROUNDS; j++) {
+                const uint32_t i = j * 256u + tid;
+                if (i >= ra && i < rb) {
+                    const uint32_t p = spos[i];
+                    sk[p] = mykey[j];
+                    if (WRITE_BACK) sv[p] = myval[j];
+                }
+            }
+        }
+        __syncthreads();
+        // distinct keys (ignoring the utype bit) among [ra, rb): ra starts a run of equal top bits, so it is one
+        uint32_t below[FE_ROUNDS];
+#pragma unroll
+        for (uint32_t j = 0; j < FE_ROUNDS; j++) {
+            const uint32_t i = j * 256u + tid;
+            const bool d = ok && i >= ra && i < rb && (i == ra || (sk[i] >> 1) != (sk[i - 1] >> 1));
+            const unsigned long long m = __ballot(d);
+            below[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[j * 4u + wave] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan of the FE_ROUNDS * 4 = 44 (round, wave) counts + the look-back, by wave 0
+            const uint32_t v = tid < FE_ROUNDS * 4u ? s_cnt[tid] : 0u;
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (tid >= (uint32_t)d) x += y;
+            }
+            if (tid < FE_ROUNDS * 4u) s_cnt[tid] = x - v;
+            const uint32_t total = __shfl(x, 63);
+            if (tid == 0 && tile > 0)
+                __hip_atomic_store(&status[tile], OS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long excl = wave_lookback(status, tile);  // every lower ticket is running or done
+            if (tid == 0) {
+                __hip_atomic_store(&status[tile], OS_INC | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tile + 1 == n_tiles) *n_out = excl + total;
+                s_base = excl;
+            }
+        }
+        __syncthreads();
+        if (ok) {
+            const unsigned long long base = s_base;
+#pragma unroll
+            for (uint32_t j = 0; j < FE_ROUNDS; j++) {
+                const uint32_t i = j * 256u + tid;
+                if (i < ra || i >= rb) continue;
+                const uint64_t k = sk[i];
+                if (i == ra || (k >> 1) != (sk[i - 1] >> 1)) {
+                    const unsigned long long o = base + s_cnt[j * 4u + wave] + below[j];
+                    ukey[o] = k;
+                    upos[o] = (uint32_t)(w0 + i);
+                }
+                if (WRITE_BACK) {
+                    keys[w0 + i] = k;
+                    vals[w0 + i] = sv[i];
+                }
+            }
+        } else if (s_bad && tid == 0) {
+            atomicOr(fallback, 1u);
+        }
+        __syncthreads();
+    }
+}
+
+// Finishes a sort that cr_radix_sort_u64_top left with `low_bits` unsorted low bits and emits the distinct keys:
+// ukey / upos (room for n entries), *nd_out = their number.  *fell_back: a run was too long; ukey / upos are garbage, the
+// keys (and payloads) are untouched or partly ordered inside their runs -- still the same multiset.
+int cr_finish_emit(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, uint64_t *d_ukey,
+                   uint32_t *d_upos, uint64_t *nd_out, bool *fell_back) {
+    *fell_back = false;
+    *nd_out = 0;
+    if (n == 0) return CRGPU_OK;
+    const uint64_t n_tiles = (n + FE_TILE - 1) / FE_TILE;
+    void *d_status = nullptr;
+    CR_TRY(cr_pool_alloc(ctx, &d_status, n_tiles * sizeof(unsigned long long) + 64));
+    uint32_t *d_ticket = ctx->d_scalars + 44, *d_flag = ctx->d_scalars + 52;
+    unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
+    hipError_t e;
+    {
+        CrTimer t(ctx, CRGPU_T_DEDUP, n);  // it is the run-length pass of the dedup family (which counts its keys here)
+        e = hipMemsetAsync(d_status, 0, n_tiles * sizeof(unsigned long long), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_ticket, 0, sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), ctx->stream);
+        const dim3 grid((unsigned)(n_tiles < 2048 ? n_tiles : 2048));
+        if (d_vals)
+            hipLaunchKernelGGL(k_finish_emit<true>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits, d_ukey, d_upos,
+                               (unsigned long long *)d_status, d_ticket, d_n, d_flag);
+        else
+            hipLaunchKernelGGL(k_finish_emit<false>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits, d_ukey, d_upos,
+                               (unsigned long long *)d_status, d_ticket, d_n, d_flag);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    cr_pool_free(ctx, d_status);
+    if (e != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "finish + emit: %s", hipGetErrorString(e));
+    uint32_t flag = 0;
+    unsigned long long nd = 0;
+    CR_TRY(crgpu_memcpy_d2h(ctx, &flag, d_flag, sizeof(flag)));
+    CR_TRY(crgpu_memcpy_d2h(ctx, &nd, d_n, sizeof(nd)));
+    *fell_back = flag != 0;
+    *nd_out = nd;
+    return CRGPU_OK;
 }
 
 int cr_radix_sort_u32(crgpu_ctx *ctx, uint32_t *d_keys, uint32_t *d_tmp, uint32_t *d_vals, uint32_t *d_vals_tmp,
