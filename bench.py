@@ -225,6 +225,9 @@ def main():
     import numpy as np
     import torch
 
+    if os.environ.get("CRGPU_BENCH_SHARE_DEVICE"):
+        # rehearsal on a box with fewer GPUs than ranks: the ranks share the devices there are (RCCL must agree to it)
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     from cellranger_amd import engine as E
     from cellranger_amd import synth as S

@@ -280,3 +280,23 @@ def test_barcode_stage_on_more_than_2_31_reads():
     a = selfcheck.barcode_stage_properties(c, d)
     assert 0.90 * n < a["valid_reads"] < 0.94 * n and 0.05 * n < a["corrected_reads"] < 0.09 * n
     c.close()
+
+
+def test_bench_code_path_at_20m_reads_read_by_read():
+    """The code path the bench times -- K1's LDS table chosen by itself (>= 16 Mi reads per call), K1's miss records feeding
+    K2, the staged CORRECTED histogram, the key histograms counted by k_build_keys, the onesweep sort over thousands of
+    chunk tickets -- checked against the oracle READ BY READ at 20 M reads of the cfg3 model (not only through properties):
+    every read's barcode index and DupInfo, both histograms, the matrix, the molecule table, the BarcodeSummary rows.
+    (scripts/parity_large.py does the same at 100 M reads outside the suite.)"""
+    import gpu_helpers as G
+    import test_gpu_count as T
+    from cellranger_amd import synth as S
+
+    n = 20_000_000
+    w = S.Workload(n_total=n, seed=S.SEED0 + 3)
+    c = G.fresh_ctx()        # by-products trusted, as in bench.py
+    c.set_whitelist(0, w.wl_packed, length=16)
+    r = w.host_reads(0, n)
+    res, m = T._compare_with_oracle(c, w, r, n, w.n_genes)
+    assert m.nnz > 5_000_000 and len(res.mol) > 8_000_000
+    c.close()
