@@ -40,6 +40,7 @@ class Records(C.Structure):
         ("d_umi_qualn", C.c_void_p),
         ("d_feature", C.c_void_p),
         ("d_flags", C.c_void_p),
+        ("d_umi_len", C.c_void_p),
     ]
 
 
@@ -180,6 +181,8 @@ SYMBOLS = {
     "crgpu_match_and_count": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
     "crgpu_correct": (_i, [_vp, _i, _vp, _vp, _u64, _vp, _vp]),
     "crgpu_set_key_layout": (_i, [_vp, _u32, _u32, _u32, _u32]),
+    "crgpu_set_umi_min_len": (_i, [_vp, _u32]),
+    "crgpu_pack_rows_var_dev": (_i, [_vp, _vp, _vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "crgpu_set_target_filter": (_i, [_vp, _vp, _u32, _u64]),
     "crgpu_build_keys_dev": (_i, [_vp, C.POINTER(Records), _vp, C.POINTER(_u64)]),
     "crgpu_partition_keys_dev": (_i, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),

@@ -156,6 +156,58 @@ extern "C" int crgpu_pack_rows_dev(crgpu_ctx *ctx, const uint8_t *d_seq_rows, co
     return CRGPU_OK;
 }
 
+// UmiExtractor::extract_umi (cr_types/src/rna_read.rs:103-138): the UMI of a read that ends early keeps
+// max(min(read_len - offset, length), min_length) bases; a range beyond the end of the read fails check_range.
+__global__ __launch_bounds__(256) void k_pack_rows_var(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
+                                                       const uint32_t *__restrict__ read_len, uint64_t n, uint32_t row_stride,
+                                                       uint32_t offset, uint32_t length, uint32_t min_length,
+                                                       uint32_t *__restrict__ packed, uint8_t *__restrict__ qualn,
+                                                       uint8_t *__restrict__ len_out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t rl = read_len[i] < row_stride ? read_len[i] : row_stride;
+        const uint32_t avail = rl > offset ? rl - offset : 0u;            // saturating_sub
+        uint32_t L = avail < length ? avail : length;
+        L = L > min_length ? L : min_length;
+        if (offset + L > rl) L = 0;                                        // check_range(&range, "UMI") fails
+        const uint8_t *s = seq + i * row_stride + offset, *q = qual + i * row_stride + offset;
+        uint32_t key = 0;
+        for (uint32_t j = 0; j < length; j++) {
+            uint8_t out = 0;
+            if (j < L) {
+                bool is_n;
+                const uint32_t code = base_code(s[j], is_n);
+                key = (key << 2) | code;
+                const uint32_t qq = q[j] > 127u ? 127u : q[j];
+                out = (uint8_t)(qq | (is_n ? 0x80u : 0u));
+            }
+            qualn[i * length + j] = out;
+        }
+        packed[i] = key;
+        len_out[i] = (uint8_t)L;
+    }
+}
+
+extern "C" int crgpu_pack_rows_var_dev(crgpu_ctx *ctx, const uint8_t *d_seq_rows, const uint8_t *d_qual_rows,
+                                       const uint32_t *d_read_len, uint64_t n, uint32_t row_stride, uint32_t offset, uint32_t length,
+                                       uint32_t min_length, uint32_t *d_packed_out, uint8_t *d_qualn_out, uint8_t *d_len_out) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, length >= 1 && length <= 16 && min_length >= 1 && min_length <= length, CRGPU_ERANGE,
+               "crgpu_pack_rows_var_dev: lengths %u..%u unsupported (1 <= min <= length <= 16)", min_length, length);
+    CR_REQUIRE(ctx, (uint64_t)offset + length <= row_stride, CRGPU_EINVAL, "crgpu_pack_rows_var_dev: bases [%u, %u) lie outside a row of %u bytes",
+               offset, offset + length, row_stride);
+    if (n == 0) return CRGPU_OK;
+    CR_REQUIRE(ctx, d_seq_rows && d_qual_rows && d_read_len && d_packed_out && d_qualn_out && d_len_out, CRGPU_EINVAL,
+               "crgpu_pack_rows_var_dev: NULL buffer");
+    CrTimer t(ctx, CRGPU_T_PACK, n);
+    cr_invalidate(ctx);
+    hipLaunchKernelGGL(k_pack_rows_var, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_seq_rows, d_qual_rows, d_read_len, n,
+                       row_stride, offset, length, min_length, d_packed_out, d_qualn_out, d_len_out);
+    CR_HIP(ctx, hipGetLastError());
+    return CRGPU_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: exact match + valid-barcode histogram
 // ------------------------------------------------------------------------------------------------

@@ -65,13 +65,17 @@ struct TimedSpan {
 struct KeyLayout {
     bool set = false;
     uint32_t bits_bc = 0, bits_feat = 0, bits_lib = 0, bits_umi = 0;  // + 1 utype bit (LSB)
+    uint32_t bits_ulen = 0;    // per-read UMI length: tag = umi_len - length, 0 bits when every UMI has umi_len bases
+    uint32_t umi_min_len = 0;  // shortest UMI a read may carry (== umi_len unless crgpu_set_umi_min_len was called)
     uint32_t n_features = 0, umi_len = 0, n_libs = 0, mux_mask = 0;
-    // shifts inside the primary key  [bc][feature][lib][umi][nontx]
+    // shifts inside the primary key  [bc][feature][lib][umi length tag][umi][nontx]: the tag sits right above the UMI, so
+    // that (key >> sh_lib()) separates UMIs of different lengths like different libraries (they are different UmiSeqs)
     uint32_t sh_umi() const { return 1; }
-    uint32_t sh_lib() const { return 1 + bits_umi; }
-    uint32_t sh_feat() const { return 1 + bits_umi + bits_lib; }
-    uint32_t sh_bc() const { return 1 + bits_umi + bits_lib + bits_feat; }
-    uint32_t total_bits() const { return 1 + bits_umi + bits_lib + bits_feat + bits_bc; }
+    uint32_t sh_lib() const { return 1 + bits_umi; }                 // (library, length tag) as one field
+    uint32_t sh_libid() const { return 1 + bits_umi + bits_ulen; }   // the library id proper
+    uint32_t sh_feat() const { return 1 + bits_umi + bits_ulen + bits_lib; }
+    uint32_t sh_bc() const { return 1 + bits_umi + bits_ulen + bits_lib + bits_feat; }
+    uint32_t total_bits() const { return 1 + bits_umi + bits_ulen + bits_lib + bits_feat + bits_bc; }
 };
 
 // Compact (index, barcode, flags) records of the reads K1's table lookup kernel found no whitelist entry for:

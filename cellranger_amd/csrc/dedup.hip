@@ -56,6 +56,7 @@ extern "C" int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_
     L.bits_umi = 2 * umi_len;
     L.n_features = n_features;
     L.umi_len = umi_len;
+    L.umi_min_len = umi_len;
     L.n_libs = n_libs;
     L.mux_mask = multiplexing_lib_mask;
     CR_REQUIRE(ctx, L.total_bits() <= 64, CRGPU_ERANGE,
@@ -85,12 +86,31 @@ extern "C" int crgpu_set_target_filter(crgpu_ctx *ctx, const uint8_t *on_target,
     return CRGPU_OK;
 }
 
+// Per-read UMI lengths (UmiExtractor::extract_umi, cr_types/src/rna_read.rs:103-138: a read that ends early keeps
+// max(min(read_len - offset, length), min_length) bases): UMIs of different lengths are different UmiSeqs, so the length
+// becomes part of the key -- a tag (umi_len - length) right above the UMI bits.  Call after crgpu_set_key_layout.
+extern "C" int crgpu_set_umi_min_len(crgpu_ctx *ctx, uint32_t umi_min_len) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_set_umi_min_len: call crgpu_set_key_layout first");
+    KeyLayout L = ctx->layout;
+    CR_REQUIRE(ctx, umi_min_len >= 1 && umi_min_len <= L.umi_len, CRGPU_EINVAL, "umi_min_len must be 1..umi_len (%u)", L.umi_len);
+    L.umi_min_len = umi_min_len;
+    L.bits_ulen = cr_ceil_log2(L.umi_len - umi_min_len + 1);
+    CR_REQUIRE(ctx, L.total_bits() <= 64, CRGPU_ERANGE, "molecule key needs %u bits with %u bits of UMI length > 64", L.total_bits(),
+               L.bits_ulen);
+    ctx->layout = L;
+    cr_invalidate(ctx);
+    return CRGPU_OK;
+}
+
 struct KL {  // device copy of the layout
     uint32_t sh_umi, sh_lib, sh_feat, sh_bc, bits_umi, bits_lib, bits_feat, bits_bc, umi_len, n_features, n_libs, mux_mask;
+    uint32_t bits_ulen, sh_libid, umi_min_len;
 };
 static KL make_kl(const KeyLayout &L) {
     return KL{L.sh_umi(), L.sh_lib(), L.sh_feat(), L.sh_bc(), L.bits_umi, L.bits_lib, L.bits_feat, L.bits_bc,
-              L.umi_len, L.n_features, L.n_libs, L.mux_mask};
+              L.umi_len, L.n_features, L.n_libs, L.mux_mask, L.bits_ulen, L.sh_libid(), L.umi_min_len};
 }
 __device__ __forceinline__ uint64_t lowmask(uint32_t bits) { return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull); }
 
@@ -136,7 +156,8 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                                                     uint32_t *__restrict__ vals_out,
                                                     unsigned long long *__restrict__ n_out, const SweepPlan plan,
                                                     uint32_t *__restrict__ ghist, unsigned long long *__restrict__ status,
-                                                    uint32_t *__restrict__ ticket) {
+                                                    uint32_t *__restrict__ ticket, const uint8_t *__restrict__ ulen) {
+    // ulen (nullable, byte path LQW == 0 only): the UMI length of every read, umi_min_len .. umi_len
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
     __shared__ unsigned long long s_c;  // ORDERED: the chunk of this round, then its output offset
     __shared__ uint32_t s_ws[KEY_ITEMS * 4];  // ORDERED: kept keys of (item slot, wave), then their exclusive prefix
@@ -164,7 +185,7 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
 #pragma unroll
       for (int j0 = 0; j0 < KEY_ITEMS; j0 += KEY_BATCH) {
         // every field of KEY_BATCH reads is requested before any is looked at (no load sits behind a branch)
-        uint32_t vb[KEY_BATCH], vf[KEY_BATCH], vfl[KEY_BATCH], vu[KEY_BATCH];
+        uint32_t vb[KEY_BATCH], vf[KEY_BATCH], vfl[KEY_BATCH], vu[KEY_BATCH], vl[KEY_BATCH];
         QRow<LQW> vq[KEY_BATCH];
 #pragma unroll
         for (int jj = 0; jj < KEY_BATCH; jj++) {
@@ -174,6 +195,7 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
             vf[jj] = ok ? feature[i] : CRGPU_NO_FEATURE;
             vfl[jj] = (ok && flags) ? flags[i] : 0u;
             vu[jj] = ok ? umi[i] : 0u;
+            vl[jj] = (LQW == 0 && ok && ulen) ? ulen[i] : L;
             if (LQW) {
                 if (ok) vq[jj] = *reinterpret_cast<const QRow<LQW> *>(umi_q + i * (uint64_t)(4 * LQW));
                 else
@@ -187,7 +209,11 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
             const uint32_t b = vb[jj], f = vf[jj], fl = vfl[jj];
             const uint32_t lib = fl & CRGPU_FLAG_LIB_MASK;
             bool keep = b != CRGPU_MISS && f != CRGPU_NO_FEATURE && f < kl.n_features && lib < kl.n_libs;
-            const uint32_t u = vu[jj] & umi_mask;
+            // this read's UMI length (a length outside umi_min_len .. umi_len: the reference's check_range fails, no UMI)
+            const uint32_t Li = LQW == 0 ? vl[jj] : L;
+            if (LQW == 0 && (Li < kl.umi_min_len || Li > L)) keep = false;
+            const uint32_t Lc = (LQW == 0 && Li >= 1u && Li <= L) ? Li : L;
+            const uint32_t u = vu[jj] & (LQW == 0 ? (uint32_t)lowmask(2u * Lc) : umi_mask);
             // UmiInfo::new (umi/src/info.rs:20-37)
             bool has_n = false, low_q = false;
             if (LQW) {
@@ -199,17 +225,17 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                     for (int bb = 0; bb < 4; bb++) low_q |= (uint8_t)(((w >> (8 * bb)) & 0x7Fu) - 33u) < 10u;
                 }
             } else if (keep) {
-                for (uint32_t k = 0; k < L; k++) {
+                for (uint32_t k = 0; k < Lc; k++) {
                     const uint32_t q = umi_q[i * L + k];
                     has_n |= (q & 0x80u) != 0u;
                     low_q |= (uint8_t)((q & 0x7Fu) - 33u) < 10u;  // u8 wrapping subtraction, UMI_MIN_QV = 10
                 }
             }
             // is_homopolymer: every adjacent pair equal (true for a 1-base UMI)
-            const bool homopolymer = ((u ^ (u >> 2)) & adj_mask) == 0u;
+            const bool homopolymer = ((u ^ (u >> 2)) & (LQW == 0 ? (uint32_t)lowmask(2u * Lc - 2u) : adj_mask)) == 0u;
             keep = keep && !(has_n || homopolymer || low_q);
-            keys[j] = ((uint64_t)b << kl.sh_bc) | ((uint64_t)f << kl.sh_feat) | ((uint64_t)lib << kl.sh_lib) |
-                      ((uint64_t)u << kl.sh_umi) | ((fl & CRGPU_FLAG_NONTXOMIC) ? 1ull : 0ull);
+            keys[j] = ((uint64_t)b << kl.sh_bc) | ((uint64_t)f << kl.sh_feat) | ((uint64_t)lib << kl.sh_libid) |
+                      ((uint64_t)(L - Lc) << kl.sh_lib) | ((uint64_t)u << kl.sh_umi) | ((fl & CRGPU_FLAG_NONTXOMIC) ? 1ull : 0ull);
             if (keep) mask |= 1u << j;
             if (HIST && keep)
                 for (uint32_t p = 0; p < plan.n_passes; p++)
@@ -287,6 +313,8 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     CR_REQUIRE(ctx, recs->n <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_build_keys: at most 2^31-1 records per call");
     CR_REQUIRE(ctx, recs->d_bc_idx && recs->d_umi && recs->d_umi_qualn && recs->d_feature && d_keys_out, CRGPU_EINVAL,
                "crgpu_build_keys: NULL buffer");
+    CR_REQUIRE(ctx, !recs->d_umi_len || ctx->layout.bits_ulen || ctx->layout.umi_min_len == ctx->layout.umi_len, CRGPU_ESTATE,
+               "crgpu_build_keys: per-read UMI lengths need crgpu_set_umi_min_len");
     CR_REQUIRE(ctx, (recs->umi_len & 3u) != 0u || (uintptr_t)recs->d_umi_qualn % 4 == 0, CRGPU_EINVAL,
                "crgpu_build_keys: the UMI quality buffer must be 4-byte aligned");
     unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
@@ -323,16 +351,16 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     if (d_vals_out)                                                                                                         \
         hipLaunchKernelGGL((k_build_keys<LQW, false, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket);                                                                             \
+                           d_status, d_ticket, recs->d_umi_len);                                                            \
     else if (d_hist)                                                                                                        \
         hipLaunchKernelGGL((k_build_keys<LQW, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,     \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket);                                                                             \
+                           d_status, d_ticket, recs->d_umi_len);                                                            \
     else                                                                                                                    \
         hipLaunchKernelGGL((k_build_keys<LQW, false>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,    \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket)
-        switch (recs->umi_len) {
+                           d_status, d_ticket, recs->d_umi_len)
+        switch (recs->d_umi_len ? 0u : recs->umi_len) {  // per-read lengths: the byte path
             case 4: CR_BUILD_KEYS(1); break;
             case 8: CR_BUILD_KEYS(2); break;
             case 12: CR_BUILD_KEYS(3); break;
@@ -720,9 +748,9 @@ __global__ __launch_bounds__(256) void k_rep_utype(const uint64_t *__restrict__ 
 // comparison below re-checks the exact (barcode, library, UMI) so hash collisions cannot merge groups.
 __device__ __forceinline__ uint64_t group_id(const KL &kl, uint64_t key) {  // (barcode, library, UMI), exact
     const uint64_t umi = (key >> kl.sh_umi) & lowmask(kl.bits_umi);
-    const uint64_t lib = (key >> kl.sh_lib) & lowmask(kl.bits_lib);
+    const uint64_t lib = (key >> kl.sh_lib) & lowmask(kl.bits_lib + kl.bits_ulen);  // library and UMI length: both tell UmiSeqs apart
     const uint64_t bc = key >> kl.sh_bc;
-    return ((bc << kl.bits_lib) | lib) << kl.bits_umi | umi;
+    return ((bc << (kl.bits_lib + kl.bits_ulen)) | lib) << kl.bits_umi | umi;
 }
 __device__ __forceinline__ uint32_t group_hash(uint64_t g) {
     g ^= g >> 33;
@@ -1066,7 +1094,7 @@ __global__ __launch_bounds__(256) void k_corrected_reads(const KL kl, const uint
         if (!(st[k] & ST_CORRECTED)) continue;
         const uint64_t key = ukey[k];
         const uint32_t run = (k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys) - upos[k];
-        const uint32_t lib = (uint32_t)((key >> kl.sh_lib) & lowmask(kl.bits_lib));
+        const uint32_t lib = (uint32_t)((key >> kl.sh_libid) & lowmask(kl.bits_lib));
         atomicAdd(&tab[(size_t)lib * W + (uint32_t)(key >> kl.sh_bc)], run);
     }
 }
@@ -1086,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_filtered_reads(const KL kl, const uint6
         const uint32_t rc = ((s & ST_CORRECTED) ? 0u : end - upos[k]) + (st_inc1(s) ? inc_all[k] : 0u);
         const uint64_t key = ukey[k];
         if (!tf.filtered(key, rc, false)) continue;
-        const uint32_t lib = (uint32_t)((key >> kl.sh_lib) & lowmask(kl.bits_lib));
+        const uint32_t lib = (uint32_t)((key >> kl.sh_libid) & lowmask(kl.bits_lib));
         atomicAdd(&tab[(size_t)lib * W + (uint32_t)(key >> kl.sh_bc)], rc);
     }
 }
@@ -1113,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_molecule_sums(const KL kl, const uint64
 #pragma unroll
         for (int j = 0; j < MS_ITEMS; j++) {
             if (base + j >= nm) break;
-            const uint32_t lib = (uint32_t)((key[j] >> kl.sh_lib) & lowmask(kl.bits_lib));
+            const uint32_t lib = (uint32_t)((key[j] >> kl.sh_libid) & lowmask(kl.bits_lib));
             const size_t slot = (size_t)lib * W + (uint32_t)(key[j] >> kl.sh_bc);
             if (slot != cur) {
                 if (n_u) {
@@ -1968,21 +1996,25 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
     std::vector<uint32_t> order(nm);
     for (uint64_t i = 0; i < nm; i++) order[i] = (uint32_t)i;
     auto fld = [&](uint64_t k, uint32_t sh, uint32_t bits) { return (uint32_t)((k >> sh) & (bits >= 64 ? ~0ull : ((1ull << bits) - 1))); };
-    // with a single library the device order (barcode, feature, umi) already is the required one
-    if (L.bits_lib != 0) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    // with a single library and one UMI length the device order (barcode, feature, umi) already is the required one;
+    // otherwise UmiCount's derived Ord: library_idx, feature_idx, umi (2-bit), read_count, utype (types.rs:152-160)
+    if (L.bits_lib != 0 || L.bits_ulen != 0) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         const uint64_t ka = keys[a], kb = keys[b];
         const uint32_t bca = (uint32_t)(ka >> L.sh_bc()), bcb = (uint32_t)(kb >> L.sh_bc());
         if (bca != bcb) return bca < bcb;
-        const uint32_t la = fld(ka, L.sh_lib(), L.bits_lib), lb = fld(kb, L.sh_lib(), L.bits_lib);
+        const uint32_t la = fld(ka, L.sh_libid(), L.bits_lib), lb = fld(kb, L.sh_libid(), L.bits_lib);
         if (la != lb) return la < lb;
         const uint32_t fa = fld(ka, L.sh_feat(), L.bits_feat), fb = fld(kb, L.sh_feat(), L.bits_feat);
         if (fa != fb) return fa < fb;
-        return fld(ka, L.sh_umi(), L.bits_umi) < fld(kb, L.sh_umi(), L.bits_umi);
+        const uint32_t ua = fld(ka, L.sh_umi(), L.bits_umi), ub = fld(kb, L.sh_umi(), L.bits_umi);
+        if (ua != ub) return ua < ub;
+        if (reads[a] != reads[b]) return reads[a] < reads[b];
+        return (ka & 1ull) < (kb & 1ull);
     });
     for (uint64_t o = 0; o < nm; o++) {
         const uint64_t k = keys[order[o]];
         if (bc_out) bc_out[o] = (uint32_t)(k >> L.sh_bc());
-        if (lib_out) lib_out[o] = (uint8_t)fld(k, L.sh_lib(), L.bits_lib);
+        if (lib_out) lib_out[o] = (uint8_t)fld(k, L.sh_libid(), L.bits_lib);
         if (feature_out) feature_out[o] = fld(k, L.sh_feat(), L.bits_feat);
         if (umi_out) umi_out[o] = fld(k, L.sh_umi(), L.bits_umi);
         if (read_count_out) read_count_out[o] = reads[order[o]];

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
                 head = (t0 + p == 0) || (ukey[t0 + p - 1] >> kl.sh_lib) != pre;
                 s_umi[p] = (uint32_t)((key >> kl.sh_umi) & umi_mask);
                 const uint32_t end = t0 + p + 1 < nd ? upos[t0 + p + 1] : (uint32_t)n_keys;
-                const uint32_t lib = (uint32_t)(pre & lowmask(kl.bits_lib));
+                const uint32_t lib = (uint32_t)((pre >> kl.bits_ulen) & lowmask(kl.bits_lib));
                 // UmiCorrection::Disable for Multiplexing Capture (aligner.rs:315-318)
                 s_cnt[p] = (end - upos[t0 + p]) | (((kl.mux_mask >> lib) & 1u) ? UC_NOCORR : 0u);
             } else {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
         }
         const uint64_t m = e - s;
         if (SMALL ? m > UES_CAP : m <= UES_CAP) continue;  // the other instantiation's segment
-        const uint32_t lib = (uint32_t)((ukey[s] >> kl.sh_lib) & lowmask(kl.bits_lib));
+        const uint32_t lib = (uint32_t)((ukey[s] >> kl.sh_libid) & lowmask(kl.bits_lib));
         if ((kl.mux_mask >> lib) & 1u) continue;  // UmiCorrection::Disable (aligner.rs:315-318): nothing moves
         if (m <= CAP) {
             const uint32_t mm = (uint32_t)m;

@@ -497,12 +497,21 @@ class Context:
         a = None if on_target is None else np.ascontiguousarray(on_target, dtype=np.uint8)
         self._check(self.L.crgpu_set_target_filter(self.h, ptr(a), 0 if a is None else len(a), int(min_read_count)))
 
-    def records(self, n, umi_len, d_bc_idx, d_umi, d_umi_qualn, d_feature, d_flags=None):
+    def records(self, n, umi_len, d_bc_idx, d_umi, d_umi_qualn, d_feature, d_flags=None, d_umi_len=None):
         r = Records()
         r.n, r.umi_len = n, umi_len
         r.d_bc_idx, r.d_umi, r.d_umi_qualn = _p(d_bc_idx), _p(d_umi), _p(d_umi_qualn)
-        r.d_feature, r.d_flags = _p(d_feature), _p(d_flags)
+        r.d_feature, r.d_flags, r.d_umi_len = _p(d_feature), _p(d_flags), _p(d_umi_len)
         return r
+
+    def set_umi_min_len(self, umi_min_len):
+        """per-read UMI lengths umi_min_len .. umi_len (after set_key_layout)"""
+        self._check(self.L.crgpu_set_umi_min_len(self.h, umi_min_len))
+
+    def pack_rows_var(self, d_seq_rows, d_qual_rows, d_read_len, n, row_stride, offset, length, min_length, d_packed, d_qualn, d_len):
+        """UmiExtractor::extract_umi on read rows: per-read length max(min(read_len - offset, length), min_length)"""
+        self._check(self.L.crgpu_pack_rows_var_dev(self.h, _p(d_seq_rows), _p(d_qual_rows), _p(d_read_len), n, row_stride, offset,
+                                                   length, min_length, _p(d_packed), _p(d_qualn), _p(d_len)))
 
     def build_keys(self, recs, d_keys_out):
         n = C.c_uint64()

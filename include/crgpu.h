@@ -320,6 +320,8 @@ typedef struct {
     const uint8_t *d_umi_qualn;/* n x umi_len, bit7 = N */
     const uint32_t *d_feature; /* conf-mapped feature index or CRGPU_NO_FEATURE */
     const uint8_t *d_flags;    /* library id / NONTXOMIC; nullable (library 0, Txomic) */
+    const uint8_t *d_umi_len;  /* nullable: bases of every read's UMI, umi_min_len .. umi_len (crgpu_set_umi_min_len); the packed
+                                  UMI holds that many bases right-aligned, d_umi_qualn keeps its stride of umi_len bytes */
 } crgpu_records;
 
 /* 64-bit molecule keys: the exchange unit between GPUs and the input of the
@@ -329,6 +331,16 @@ typedef struct {
  * disabled, aligner.rs:315-318). */
 int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_t umi_len, uint32_t n_libs,
                          uint32_t multiplexing_lib_mask);
+/* Per-read UMI lengths: UmiExtractor::extract_umi (cr_types/src/rna_read.rs:103-138) gives a read that ends early
+ * max(min(read_len - offset, length), min_length) bases (3' v3: 12, down to 10).  UMIs of different lengths are different
+ * UmiSeqs: they never correct onto each other and never share a low-support group.  After crgpu_set_key_layout, declare the
+ * shortest length with crgpu_set_umi_min_len (the key gains ceil(log2(umi_len - min + 1)) bits) and pass
+ * crgpu_records.d_umi_len.  crgpu_pack_rows_var_dev slices such UMIs out of read rows: length per the formula above,
+ * d_len_out[i] = it (0 when the range does not fit the read: the reference's check_range fails and the read has no UMI). */
+int crgpu_set_umi_min_len(crgpu_ctx *ctx, uint32_t umi_min_len);
+int crgpu_pack_rows_var_dev(crgpu_ctx *ctx, const uint8_t *d_seq_rows, const uint8_t *d_qual_rows, const uint32_t *d_read_len,
+                            uint64_t n, uint32_t row_stride, uint32_t offset, uint32_t length, uint32_t min_length,
+                            uint32_t *d_packed_out, uint8_t *d_qualn_out, uint8_t *d_len_out);
 int crgpu_build_keys_dev(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out,
                          uint64_t *n_keys_out);
 /* Targeted Gene Expression: DupBuilder::build(.., targeted_umi_min_read_count) with the target set of the feature

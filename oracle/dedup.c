@@ -111,19 +111,29 @@ static keyrec *ds_entry(dupstate *ds, const char *umi, uint32_t gene, int *fresh
     return &ds->recs[s->v0];
 }
 
+/* UMIs of several lengths in one group (UmiExtractor::extract_umi gives short reads shorter UMIs,
+ * cr_types/src/rna_read.rs:103-138): the callers pad the shorter ones with NUL bytes up to ds->umi_len.  A UmiSeq is its
+ * bytes AND its length, so padded strings compare and hash exactly like the reference's keys; only the code that walks
+ * over the bases needs the real length. */
+static uint32_t umi_real_len(const char *umi, uint32_t max_len) {
+    uint32_t l = 0;
+    while (l < max_len && umi[l] != 0) l++;
+    return l;
+}
+
 /* mark_dups.rs:19-59 */
 static void correct_umis(dupstate *ds) {
     static const char nucs[4] = {'A', 'C', 'G', 'T'};
-    uint32_t L = ds->umi_len;
     for (uint64_t i = 0; i < ds->n; i++) {
         keyrec *r = &ds->recs[i];
+        const uint32_t L = ds->umi_len;
         char test_umi[16];
         memcpy(test_umi, r->umi, L);
         uint64_t best_dest_count = r->count;
         char best_dest_umi[16];
         memcpy(best_dest_umi, r->umi, L);
         int64_t best_idx = (int64_t)i;
-        for (uint32_t pos = 0; pos < L; pos++) {
+        for (uint32_t pos = 0; pos < umi_real_len(r->umi, L); pos++) { /* `for pos in 0..umi.len()` */
             for (int c = 0; c < 4; c++) {
                 if (nucs[c] == r->umi[pos]) continue;
                 test_umi[pos] = nucs[c];
@@ -282,7 +292,7 @@ uint64_t oracle_mark_dups_group(const char *umi, uint32_t umi_len, const uint8_t
             di.is_low_support = cr->low;
             int is_min_qname = qname[i] == cr->min_qname;
             di.read_count = (uint32_t)cr->count;
-            di.processed_umi = oracle_encode_2bit_u32(cr->umi, umi_len);
+            di.processed_umi = oracle_encode_2bit_u32(cr->umi, umi_real_len(cr->umi, umi_len));
             /* mark_dups.rs:311-320 (None unless oracle_set_target_filter was called); subsample rate 1.0 (stages/stubs.rs:6-8) */
             di.is_filtered_target = g_target_min_reads && cr->gene < g_n_target_features && g_on_target[cr->gene] &&
                                     (uint64_t)cr->count < g_target_min_reads && !di.is_low_support;

@@ -227,7 +227,9 @@ static void process_barcode(const oracle_reads *reads, const bcref *refs, uint64
             int l = reads->lib ? reads->lib[i] : 0;
             if (l != lib) continue;
             memcpy(umi + k * UL, reads->umi + i * UL, UL);
-            valid[k] = (uint8_t)oracle_umi_is_valid(reads->umi + i * UL, reads->umi_qual + i * UL, UL);
+            uint32_t ul = 0; /* a UMI shorter than umi_len is padded with NUL bytes (variable-length UMIs) */
+            while (ul < UL && reads->umi[i * UL + ul] != 0) ul++;
+            valid[k] = (uint8_t)(ul > 0 && oracle_umi_is_valid(reads->umi + i * UL, reads->umi_qual + i * UL, ul));
             feat[k] = reads->feature[i];
             ut[k] = reads->utype ? reads->utype[i] : 0;
             qn[k] = i; /* read headers are unique; their rank == read index */

@@ -513,3 +513,89 @@ def test_targeted_panel_umi_filter_matches_the_oracle():
     res2, m2 = _compare_with_oracle(c, w, r, n, w.n_genes)
     assert int((res2.dupinfo["is_filtered_target"] != 0).sum()) == 0 and m2.data.sum() > m.data.sum() and m2.nnz >= nnz_filtered
     c.close()
+
+
+def test_per_read_umi_lengths_match_the_oracle():
+    """Reads that end early carry shorter UMIs (UmiExtractor::extract_umi, cr_types/src/rna_read.rs:103-138; the
+    reference's vectors :1581-1637 go through crgpu_pack_rows_var_dev first).  A UmiSeq is its bases AND its length: a
+    10-base UMI never corrects onto a 12-base one and never shares a low-support group with it, even when the packed
+    values coincide.  30 % of the reads get 10- or 11-base UMIs (short UMI space on purpose: many coincidences): every
+    read's DupInfo, the matrix and the molecule table (in UmiCount order) equal the oracle's."""
+    import json
+
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+
+    c = G.fresh_ctx()
+    # 1. the reference's slicing vectors
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "misc_vectors.json")))["umi_extraction"]
+    stride = 64
+    seq = np.zeros((2, stride), np.uint8)
+    qual = np.zeros((2, stride), np.uint8)
+    for i, case in enumerate(g["cases"]):
+        seq[i, :len(case["seq"])] = np.frombuffer(case["seq"].encode(), np.uint8)
+        qual[i, :len(case["qual"])] = np.frombuffer(case["qual"].encode(), np.uint8)
+    rl = np.array([len(x["seq"]) for x in g["cases"]] , np.uint32)
+    d_pk, d_qn, d_len = c.empty(2, np.uint32), c.empty((2, 12), np.uint8), c.empty(2, np.uint8)
+    c.pack_rows_var(c.upload(seq), c.upload(qual), c.upload(rl), 2, stride, g["offset"], g["length"], g["min_length"], d_pk, d_qn, d_len)
+    lens, pk = d_len.to_host(), d_pk.to_host()
+    for i, case in enumerate(g["cases"]):
+        assert lens[i] == case["range_len"]
+        assert E.unpack_seqs(pk[i:i + 1], int(lens[i]))[0].tobytes().decode() == case["umi"]
+    # a read too short even for min_length has no UMI (check_range fails in the reference)
+    c.pack_rows_var(c.upload(seq), c.upload(qual), c.upload(np.array([20, 25], np.uint32)), 2, stride, 16, 12, 10, d_pk, d_qn, d_len)
+    assert list(d_len.to_host()) == [0, 0]
+
+    # 2. parity of the count stage with mixed lengths
+    n, UL = 300_000, 6
+    w = S.Workload(n_total=n, seed=S.SEED0 + 13, n_wl=20_000, n_cells=120, n_ambient=3000, n_genes=200, umi_len=UL, umi_err=0.03,
+                   reads_per_umi=3)
+    r = w.host_reads(0, n)
+    rng = np.random.default_rng(4)
+    L = np.full(n, UL, np.uint8)
+    L[rng.random(n) < 0.2] = UL - 2
+    L[rng.random(n) < 0.1] = UL - 1
+    umi = (r["umi"] >> (2 * (UL - L.astype(np.uint32)))).astype(np.uint32)      # keep the leading L bases
+    uq = r["umi_qualn"].copy()
+    uq[np.arange(UL)[None, :] >= L[:, None]] = 0
+    c.set_whitelist(0, w.wl_packed, length=16)
+    idx_a, idx_b, corr, dev = G.gpu_barcode_stage(c, r, n)
+    c.set_key_layout(w.n_genes, UL, 1, 0)
+    c.set_umi_min_len(UL - 2)
+    d_umi, d_uq, d_ft, d_L = c.upload(umi), c.upload(uq), c.upload(r["feature"]), c.upload(L)
+    recs = c.records(n, UL, dev["idx"], d_umi, d_uq, d_ft, dev["flags"], d_umi_len=d_L)
+    d_pu, d_rc, d_fl = c.empty(n, np.uint32), c.empty(n, np.uint32), c.empty(n, np.uint8)
+    counts = c.count_records(recs, d_pu, d_rc, d_fl)
+    bc, ft, ct = counts.triplets()
+    mol = counts.molecules()
+    m = c.assemble_matrix(bc, ft, ct, w.n_genes)
+    # oracle: ASCII UMIs padded with NUL bytes behind their real length
+    reads = G.oracle_reads_from_packed(r, 16, UL)
+    ascii_umi = np.zeros((n, UL), np.uint8)
+    is_n = (uq & 0x80) != 0
+    for k in range(UL):
+        has = k < L
+        shift = (2 * (L.astype(np.int64) - 1 - k)).clip(0)
+        base = np.frombuffer(b"ACGT", np.uint8)[(umi.astype(np.int64) >> shift) & 3]
+        ascii_umi[:, k] = np.where(has, np.where(is_n[:, k], ord("N"), base), 0)
+    reads["umi"] = ascii_umi
+    reads["umi_qual"] = (uq & 0x7F).astype(np.uint8)
+    res = O.run_pipeline(reads, [O.Whitelist(E.unpack_seqs(w.wl_packed, 16))], n_threads=4, want_dupinfo=True)
+    od = res.dupinfo
+    fl, pu, rc = d_fl.to_host(), d_pu.to_host(), d_rc.to_host()
+    has = od["has_dupinfo"] != 0
+    assert np.array_equal((fl & 1) != 0, has)
+    assert np.array_equal((fl & 2) != 0, od["is_corrected"] != 0) and np.array_equal((fl & 4) != 0, od["is_low_support"] != 0)
+    assert np.array_equal((fl & 8) != 0, od["is_umi_count"] != 0)
+    assert np.array_equal(pu[has], od["processed_umi"][has]) and np.array_equal(rc[has], od["read_count"][has])
+    assert np.array_equal(m.barcodes_ascii(), res.barcodes) and np.array_equal(m.indptr, res.indptr)
+    assert np.array_equal(m.indices, res.indices) and np.array_equal(m.data, res.data)
+    _, canon_sorted = c.canon_order()
+    col_rank = G.ranks_of(canon_sorted, res.barcodes)
+    assert np.array_equal(mol["bc"], col_rank[res.mol_bc_col]) and np.array_equal(mol["feature"], res.mol["feature_idx"])
+    assert np.array_equal(mol["umi"], res.mol["umi"]) and np.array_equal(mol["read_count"], res.mol["read_count"])
+    assert int(((fl & 2) != 0).sum()) > 1000 and int(((fl & 4) != 0).sum()) > 10
+    # the lengths really collide: some packed value occurs with two lengths under one (barcode, feature)
+    c.close()

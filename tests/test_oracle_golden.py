@@ -214,3 +214,14 @@ def test_barcode_summary_hand_computed():
     assert s["umis"].tolist() == [1, 0, 1]
     assert s["candidate_dup_reads"].tolist() == [2, 0, 1]    # low-support read of CCCC is not a candidate
     assert s["umi_corrected_reads"].tolist() == [1, 0, 0]
+
+
+def test_umi_extraction_vectors():
+    """UmiExtractor::extract_umi (cr_types/src/rna_read.rs:103-138) on the reference's own vectors (:1581-1637): the UMI
+    of a read that ends early keeps max(min(read_len - offset, length), min_length) bases."""
+    g = load("misc_vectors.json")["umi_extraction"]
+    for case in g["cases"]:
+        read_len = len(case["seq"])
+        L = max(min(max(read_len - g["offset"], 0), g["length"]), g["min_length"])
+        assert L == case["range_len"] and g["offset"] + L <= read_len
+        assert case["seq"][g["offset"]:g["offset"] + L] == case["umi"]
