@@ -214,6 +214,10 @@ SYMBOLS = {
     "crgpu_count": (_i, [_vp, C.POINTER(Records), _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_set_feature_pattern": (_i, [_vp, _i, C.c_char_p, _u32, _u32, _vp, _vp]),
     "crgpu_match_features_dev": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
+    "crgpu_set_feature_extractor": (_i, [_vp, _i, _vp, _u32, _vp, _u32]),
+    "crgpu_compile_feature_pattern": (_i, [C.c_char_p, _u32, C.c_char_p, _u64]),
+    "crgpu_feature_extractor_regex": (_i, [_vp, _i, _u32, C.c_char_p, _u64, _vp]),
+    "crgpu_extract_features_dev": (_i, [_vp, _i, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp]),
     "crgpu_synth_dev": (_i, [_vp, C.POINTER(SynthParams), _u64, _u64, C.POINTER(SynthOut)]),
     "crgpu_synth_host": (_i, [C.POINTER(SynthParams), _u64, _u64, C.POINTER(SynthOut)]),
 }
@@ -249,3 +253,11 @@ def ptr(a):
         assert a.flags["C_CONTIGUOUS"]
         return a.ctypes.data_as(C.c_void_p)
     return C.c_void_p(int(a))
+
+
+class FeatureDef(C.Structure):
+    """crgpu_feature_def"""
+    _fields_ = [("pattern", C.c_char_p), ("sequence", C.c_char_p), ("index", C.c_uint32), ("read", C.c_uint32)]
+
+
+NO_CAPTURE = 0xFFFFFFFF

@@ -56,6 +56,18 @@ struct FeaturePattern {
     double *d_dist = nullptr;     // n proportions
 };
 
+// the definitions of one feature type compiled for k_extract_features (feature_extract.hip): one device allocation
+struct FeatureExtractorSet {
+    bool set = false;
+    void *d_blob = nullptr;
+    size_t off_pat = 0, off_key = 0, off_dist = 0, off_index = 0, off_ha_key = 0, off_ha_f = 0, off_hb_key = 0, off_hb_f = 0,
+           off_chars = 0;
+    uint32_t n_pat = 0, max_feat = 0;
+    bool has_dist = false;
+    bool uses_read[2] = {false, false};
+    std::vector<std::string> regex;  // regex_str of every pattern as the reference would build it
+};
+
 struct TimedSpan {
     int slot;
     hipEvent_t start, stop;
@@ -128,6 +140,7 @@ struct crgpu_ctx {
 
     WlTables wl[CRGPU_MAX_LIB];
     FeaturePattern pat[CRGPU_MAX_LIB];
+    FeatureExtractorSet fx[CRGPU_MAX_LIB];
     uint32_t *d_canon_keys = nullptr;         // n_canon packed canonical barcodes, ascending (rank -> sequence)
     unsigned long long *d_hot_image = nullptr;  // K1's hot-barcode table (HOT_SLOTS entries) + 256 u32 of scratch
     MissRecords rec;
@@ -135,6 +148,7 @@ struct crgpu_ctx {
     std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
     uint64_t sort_refinished = 0;          // sorts whose finishing pass met a run too long for it and that were redone on all bits
+    uint64_t feature_reads_requeued = 0;   // reads k_extract_features handed to the wide-map launch
     uint64_t sort_fallbacks = 0;           // sorts whose look-back watchdog fired and that were finished by the classic passes
 
     double max_expected_errors = 1.7976931348623157e308;  // corrector.rs:104 (f64::MAX)
@@ -193,6 +207,7 @@ struct CrEnter {
 #define CR_ENTER(ctx) CrEnter _cr_enter(ctx)
 // forget every by-product kept for the next call (K1's miss records, the key histograms)
 void cr_invalidate(crgpu_ctx *ctx);
+void cr_feature_extractors_free(crgpu_ctx *ctx);  // feature_extract.hip
 void cr_comm_destroy(crgpu_ctx *ctx);
 int cr_comm_init(crgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id);
 // comm.hip transports (host arrays of n_ranks entries; offsets / sizes in bytes)

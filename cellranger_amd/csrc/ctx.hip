@@ -120,6 +120,9 @@ extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
         case CRGPU_STAT_SORT_REFINISHED:
             *value_out = ctx->sort_refinished;
             return CRGPU_OK;
+        case CRGPU_STAT_FEATURE_READS_REQUEUED:
+            *value_out = ctx->feature_reads_requeued;
+            return CRGPU_OK;
         default:
             return cr_fail(ctx, CRGPU_EINVAL, "crgpu_get_stat: unknown counter %d", which);
     }
@@ -165,6 +168,7 @@ extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
         hipFree(p.d_index);
         hipFree(p.d_dist);
     }
+    cr_feature_extractors_free(ctx);
     hipFree(ctx->d_on_target);
     hipFree(ctx->d_canon_keys);
     hipFree(ctx->d_hot_image);

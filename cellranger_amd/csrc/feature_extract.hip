@@ -1,0 +1,633 @@
+// feature_extract.hip -- K3x: FeatureExtractor::match_read over whole read rows, every pattern form.
+//
+// Replaces, for the definitions of ONE feature type (cr_types/src/reference/feature_extraction.rs):
+//   FeatureExtractor::new / compile_pattern / compile_bare_patterns   :176-343   (host, crgpu_set_feature_extractor)
+//   match_read                                                        :358-441   (k_extract_features)
+//   find_closest                                                      :443-470
+//   correct_feature_barcode with any number of captures               :34-117
+// feature.hip keeps the fast path for a pre-cut capture of one tethered pattern; this file takes the reads as the FASTQ
+// holds them (crgpu_fastq_to_rows_dev rows) and does the pattern search itself.
+//
+// The reference turns every pattern into a regular expression; the grammar is so small ('^'? literals-or-'.' one group
+// literals-or-'.' '$'?, or a group of same-length alternatives with one '.' each) that the search is restated directly:
+//   tethered  leftmost start s with prefix at s, suffix behind the L captured bases ('^': s = 0, '$': end of read);
+//             one capture (:397-400);
+//   bare      "(BC)": every window of L bases within one mismatch of a feature of the group, left to right (the
+//             reference restarts its search one base behind the previous match, :394-396).  The window test is a
+//             pigeonhole split: a window within one mismatch of a feature equals it on its first or its last half, so
+//             two sorted half-key tables give the candidates and a popcount verifies them.
+// Captures of a pattern stream through correct_feature_barcode's map (whitelist sequence -> best likelihood and the
+// capture it came from, likelihood_sum updated by the difference on replacement) in the reference's order -- capture,
+// position, A<C<G<T -- in f64 without contraction, so the sums are bit-identical.  The map is a 16-entry array per
+// read; a read whose captures reach more distinct features is queued and redone by a second launch with map rows in
+// global memory (one row of n_feat entries per queued read), still on the GPU.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "common.h"
+
+struct FxPat {
+    uint32_t read, tethered, anchor5, anchor3, never;
+    uint32_t pre_off, pre_len, suf_off, suf_len;  // into the character pool, '.' = any
+    uint32_t L;
+    uint32_t feat_off, n_feat;  // this pattern's slice of the feature arrays (keys ascending)
+    uint32_t least_index;       // FeaturePattern::least_feature_index
+};
+
+struct FxView {
+    const FxPat *pat;
+    uint32_t n_pat;
+    const char *chars;
+    const uint64_t *key;     // packed feature sequences, first base in the most significant pair
+    const uint32_t *index;   // FeatureDef::index
+    const double *dist;      // feat_dist[FeatureDef::index]; nullptr without a distribution
+    const uint32_t *ha_key;  // first-half keys ascending + the feature (position in the pattern's slice) of each
+    const uint32_t *ha_f;
+    const uint32_t *hb_key;  // last-half keys
+    const uint32_t *hb_f;
+};
+
+struct FxRows {
+    const uint8_t *seq, *qual;
+    const uint32_t *len;
+    uint32_t stride;
+};
+
+struct FxEntry {  // one entry of whitelist_likelihoods (:57)
+    double like;
+    uint32_t f, cap;
+};
+
+#define FX_LOCAL_ENTRIES 16u
+#define FX_NO_CAPTURE 0xFFFFFFFFu
+
+__device__ __forceinline__ uint32_t fx_code(uint8_t c) {  // 0..3, 4 = anything else
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+
+__device__ __forceinline__ int fx_find(const uint64_t *keys, uint32_t n, uint64_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && keys[lo] == key) ? (int)lo : -1;
+}
+
+__device__ __forceinline__ uint32_t fx_lower(const uint32_t *keys, uint32_t n, uint32_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// is the window (key, nm: a set low bit of a pair = that base is not A/C/G/T) within one mismatch of a feature?
+__device__ __forceinline__ bool fx_near(const FxView &v, const FxPat &P, uint64_t key, uint64_t nm) {
+    if (__popcll(nm) > 1) return false;
+    const uint32_t h = P.L >> 1;  // bases of the last half
+    const uint64_t low_mask = h ? (~0ull >> (64u - 2u * h)) : 0ull;
+    const uint64_t *fk = v.key + P.feat_off;
+    if ((nm >> (2u * h)) == 0) {  // the first half holds no N: features that agree on it
+        const uint32_t ka = (uint32_t)(key >> (2u * h));
+        const uint32_t *hk = v.ha_key + P.feat_off;
+        for (uint32_t j = fx_lower(hk, P.n_feat, ka); j < P.n_feat && hk[j] == ka; j++) {
+            const uint64_t d = key ^ fk[v.ha_f[P.feat_off + j]];
+            if (__popcll(((d | (d >> 1)) & 0x5555555555555555ull) | nm) <= 1) return true;
+        }
+    }
+    if ((nm & low_mask) == 0) {
+        const uint32_t kb = (uint32_t)(key & low_mask);
+        const uint32_t *hk = v.hb_key + P.feat_off;
+        for (uint32_t j = fx_lower(hk, P.n_feat, kb); j < P.n_feat && hk[j] == kb; j++) {
+            const uint64_t d = key ^ fk[v.hb_f[P.feat_off + j]];
+            if (__popcll(((d | (d >> 1)) & 0x5555555555555555ull) | nm) <= 1) return true;
+        }
+    }
+    return false;
+}
+
+struct FxMap {
+    FxEntry *e;
+    uint32_t cap, n;
+    double sum;  // likelihood_sum
+    bool overflow;
+    // insert_hit (:61-75)
+    __device__ __forceinline__ void insert(double like, uint32_t f, uint32_t c) {
+        uint32_t k = 0;
+        while (k < n && e[k].f != f) k++;
+        if (k < n) {
+            if (like > e[k].like) {
+                const double old = e[k].like;
+                e[k].like = like;
+                e[k].cap = c;
+                sum += like - old;
+            }
+        } else if (n < cap) {
+            e[n].like = like;
+            e[n].f = f;
+            e[n].cap = c;
+            n++;
+            sum += like;
+        } else {
+            overflow = true;
+        }
+    }
+};
+
+// one capture through correct_feature_barcode's loop body (:76-98); returns the exact feature or -1
+__device__ __forceinline__ int fx_capture(const FxView &v, const FxPat &P, const double *__restrict__ pedit, const uint8_t *qual,
+                                          uint32_t start, uint64_t key, uint64_t nm, FxMap &map) {
+    const uint64_t *fk = v.key + P.feat_off;
+    const int exact = nm ? -1 : fx_find(fk, P.n_feat, key);
+    if (!v.dist) return exact;
+    const double *dist = v.dist + P.feat_off;
+    if (exact >= 0) {
+        map.insert(dist[exact], (uint32_t)exact, start);
+        return exact;
+    }
+    if (__popcll(nm) > 1) return -1;  // every candidate keeps another N
+    for (uint32_t pos = 0; pos < P.L; pos++) {
+        const uint32_t sh = 2u * (P.L - 1u - pos);
+        const bool is_n = (nm >> sh) & 1ull;
+        if (nm && !is_n) continue;
+        const uint32_t orig = (uint32_t)(key >> sh) & 3u;
+        for (uint32_t b = 0; b < 4; b++) {
+            if (!is_n && b == orig) continue;
+            const int f = fx_find(fk, P.n_feat, (key & ~(3ull << sh)) | ((uint64_t)b << sh));
+            if (f < 0) continue;
+            uint32_t qv = (uint8_t)(qual[start + pos] - 33u);  // u8 arithmetic as in :43
+            qv = qv < 33u ? qv : 33u;
+            map.insert(dist[f] * pedit[qv], (uint32_t)f, start);
+        }
+    }
+    return -1;
+}
+
+// match_read for one read pair; returns false when the map overflowed (the caller queues the read)
+__device__ bool fx_match_read(const FxView &v, const double *__restrict__ pedit, const FxRows &r1, const FxRows &r2, uint64_t i,
+                              FxEntry *entries, uint32_t cap, uint32_t *feature_out, uint32_t *n_ids_out, uint32_t *capture_out) {
+    uint32_t n_ids = 0, the_id = CRGPU_NO_FEATURE;
+    bool have_wl = false, have_pm = false;
+    uint32_t wl_len = 0, wl_idx = 0, wl_cap = 0, pm_len = 0, pm_idx = 0, pm_cap = 0;
+    for (uint32_t p = 0; p < v.n_pat; p++) {
+        const FxPat P = v.pat[p];
+        const FxRows &R = P.read ? r2 : r1;
+        if (!R.seq || P.never) continue;
+        const uint8_t *s = R.seq + i * R.stride, *q = R.qual + i * R.stride;
+        const uint32_t len = R.len ? min(R.len[i], R.stride) : R.stride;
+        const uint32_t L = P.L;
+        const uint64_t mask = ~0ull >> (64u - 2u * L);
+        FxMap map{entries, cap, 0u, 0.0, false};
+        uint32_t n_caps = 0, last_start = 0;
+        int exact0 = -1;
+        if (P.tethered) {
+            const uint32_t need = P.pre_len + L + P.suf_len;
+            if (len < need) continue;
+            const char *pre = v.chars + P.pre_off, *suf = v.chars + P.suf_off;
+            uint32_t s_lo = 0, s_hi = len - need;
+            if (P.anchor3) s_lo = s_hi;
+            if (P.anchor5) {
+                if (s_lo > 0) continue;
+                s_hi = 0;
+            }
+            uint32_t found = FX_NO_CAPTURE;
+            for (uint32_t st = s_lo; st <= s_hi && found == FX_NO_CAPTURE; st++) {
+                bool ok = true;
+                for (uint32_t k = 0; k < P.pre_len && ok; k++) ok = pre[k] == '.' || (uint8_t)pre[k] == s[st + k];
+                for (uint32_t k = 0; k < P.suf_len && ok; k++) ok = suf[k] == '.' || (uint8_t)suf[k] == s[st + P.pre_len + L + k];
+                if (ok) found = st + P.pre_len;
+            }
+            if (found == FX_NO_CAPTURE) continue;
+            uint64_t key = 0, nm = 0;
+            for (uint32_t k = 0; k < L; k++) {
+                const uint32_t c = fx_code(s[found + k]);
+                key = (key << 2) | (c & 3u);
+                nm = (nm << 2) | (c >> 2);
+            }
+            exact0 = fx_capture(v, P, pedit, q, found, key, nm, map);
+            n_caps = 1;
+            last_start = found;
+        } else {
+            if (len < L) continue;
+            uint64_t key = 0, nm = 0;
+            for (uint32_t k = 0; k < len; k++) {
+                const uint32_t c = fx_code(s[k]);
+                key = ((key << 2) | (c & 3u)) & mask;
+                nm = ((nm << 2) | (c >> 2)) & mask;
+                if (k + 1 < L) continue;
+                // a position of an N is coded as A in key; fx_near and fx_capture look at nm first
+                if (!fx_near(v, P, key & ~(nm * 3ull), nm)) continue;
+                const uint32_t st = k + 1 - L;
+                const int ex = fx_capture(v, P, pedit, q, st, key & ~(nm * 3ull), nm, map);
+                if (n_caps == 0) exact0 = ex;
+                n_caps++;
+                last_start = st;
+            }
+            if (n_caps == 0) continue;
+        }
+        if (map.overflow) return false;
+        // find_closest (:443-470)
+        int hit = -1;
+        uint32_t hit_start = last_start;
+        if (n_caps == 1 && exact0 >= 0) {
+            hit = exact0;
+        } else if (v.dist) {
+            double mx = -1.0;
+            for (uint32_t k = 0; k < map.n; k++)
+                if (map.e[k].like > mx) {
+                    mx = map.e[k].like;
+                    hit = (int)map.e[k].f;
+                    hit_start = map.e[k].cap;
+                }
+            if (!((mx / map.sum) >= 0.975)) hit = -1;  // FEATURE_CONF_THRESHOLD; NaN and -inf fail
+        }
+        if (hit >= 0) {
+            const uint32_t idx = v.index[P.feat_off + (uint32_t)hit];
+            n_ids++;
+            the_id = idx;
+            if (!have_wl || L > wl_len || (L == wl_len && idx < wl_idx)) {  // max_by_key (len, Reverse(index)) (:415-420)
+                have_wl = true;
+                wl_len = L;
+                wl_idx = idx;
+                wl_cap = 0x80000000u | (P.read << 30) | (hit_start << 8) | L;
+            }
+        } else if (!have_pm || L > pm_len || (L == pm_len && P.least_index <= pm_idx)) {
+            // pattern_matches (:404-408, :434-437): equal keys only come from one pattern, whose last capture wins
+            have_pm = true;
+            pm_len = L;
+            pm_idx = P.least_index;
+            pm_cap = (P.read << 30) | (last_start << 8) | L;
+        }
+    }
+    feature_out[i] = (have_wl && n_ids == 1) ? the_id : CRGPU_NO_FEATURE;
+    if (n_ids_out) n_ids_out[i] = have_wl ? n_ids : 0u;
+    if (capture_out) capture_out[i] = have_wl ? wl_cap : have_pm ? pm_cap : FX_NO_CAPTURE;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_extract_features(const FxView v, const double *__restrict__ pedit, const FxRows r1, const FxRows r2,
+                                                          uint64_t n, uint32_t *__restrict__ feature_out, uint32_t *__restrict__ n_ids_out,
+                                                          uint32_t *__restrict__ capture_out, uint32_t *__restrict__ n_queued,
+                                                          uint64_t *__restrict__ queue, uint32_t queue_cap) {
+    FxEntry local[FX_LOCAL_ENTRIES];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!fx_match_read(v, pedit, r1, r2, i, local, FX_LOCAL_ENTRIES, feature_out, n_ids_out, capture_out)) {
+            const uint32_t slot = atomicAdd(n_queued, 1u);
+            if (slot < queue_cap) queue[slot] = i;
+        }
+    }
+}
+
+// the queued reads again, every read with a map row of row_entries entries in global memory
+__global__ __launch_bounds__(256) void k_extract_features_queued(const FxView v, const double *__restrict__ pedit, const FxRows r1,
+                                                                 const FxRows r2, const uint64_t *__restrict__ queue, uint32_t n_q,
+                                                                 FxEntry *__restrict__ rows, uint32_t row_entries,
+                                                                 uint32_t *__restrict__ feature_out, uint32_t *__restrict__ n_ids_out,
+                                                                 uint32_t *__restrict__ capture_out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_q) return;
+    (void)fx_match_read(v, pedit, r1, r2, queue[k], rows + (size_t)k * row_entries, row_entries, feature_out, n_ids_out, capture_out);
+}
+
+// ---- host: the patterns ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Parsed {
+    std::string left, right;  // around "(BC)", markers replaced ('^' / '$'), N still N
+};
+
+bool is_base_or_n(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N'; }
+
+// compile_pattern (:307-343) up to the point where the reference hands the string to the regex crate
+bool parse_pattern(const std::string &orig, Parsed &out) {
+    std::string p = orig;
+    if (!p.empty() && p[0] == '5') {  // ^5[Pp]?[-_]?
+        size_t i = 1;
+        if (i < p.size() && (p[i] == 'P' || p[i] == 'p')) i++;
+        if (i < p.size() && (p[i] == '-' || p[i] == '_')) i++;
+        p = "^" + p.substr(i);
+    }
+    for (size_t s = 0; s < p.size(); s++) {  // [-_]?3[Pp]?$ , leftmost
+        size_t j = s;
+        if (p[j] == '-' || p[j] == '_') j++;
+        if (j >= p.size() || p[j] != '3') continue;
+        j++;
+        if (j < p.size() && (p[j] == 'P' || p[j] == 'p')) j++;
+        if (j != p.size()) continue;
+        p = p.substr(0, s) + "$";
+        break;
+    }
+    size_t count = 0;
+    for (size_t at = orig.find("(BC)"); at != std::string::npos; at = orig.find("(BC)", at + 4)) count++;
+    const size_t bc = p.find("(BC)");
+    if (count != 1 || bc == std::string::npos) return false;
+    out.left = p.substr(0, bc);
+    out.right = p.substr(bc + 4);
+    const std::string rest = out.left + out.right;  // must read ^?[ACGTN]*$?
+    size_t k = 0;
+    if (k < rest.size() && rest[k] == '^') k++;
+    while (k < rest.size() && is_base_or_n(rest[k])) k++;
+    if (k < rest.size() && rest[k] == '$') k++;
+    return k == rest.size();
+}
+
+std::string dots(std::string s) {
+    for (char &c : s)
+        if (c == 'N') c = '.';
+    return s;
+}
+
+std::string tethered_regex(const Parsed &p, uint32_t L) {
+    return dots(p.left) + "(.{" + std::to_string(L) + "," + std::to_string(L) + "})" + dots(p.right);
+}
+
+struct HostPattern {
+    int read = 0;
+    bool tethered = true, anchor5 = false, anchor3 = false, never = false;
+    std::string prefix, suffix, regex;
+    uint32_t L = 0;
+    std::vector<std::pair<std::string, uint32_t>> feats;  // (sequence, FeatureDef::index) in definition order
+};
+
+bool pack_seq(const std::string &s, uint64_t *out) {
+    uint64_t k = 0;
+    for (char c : s) {
+        uint64_t b;
+        switch (c) {
+            case 'A': b = 0; break;
+            case 'C': b = 1; break;
+            case 'G': b = 2; break;
+            case 'T': b = 3; break;
+            default: return false;
+        }
+        k = (k << 2) | b;
+    }
+    *out = k;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int crgpu_compile_feature_pattern(const char *pattern, uint32_t length, char *regex_out, uint64_t cap) {
+    if (!pattern || !regex_out || cap == 0) return CRGPU_EINVAL;
+    Parsed p;
+    if (std::strcmp(pattern, "(BC)") == 0 || !parse_pattern(pattern, p)) return CRGPU_EINVAL;
+    const std::string r = tethered_regex(p, length);
+    if (r.size() + 1 > cap) return CRGPU_ERANGE;
+    std::memcpy(regex_out, r.c_str(), r.size() + 1);
+    return CRGPU_OK;
+}
+
+static void fx_release(FeatureExtractorSet &X) {
+    (void)hipFree(X.d_blob);
+    X = FeatureExtractorSet();
+}
+
+void cr_feature_extractors_free(crgpu_ctx *ctx) {
+    for (int k = 0; k < CRGPU_MAX_LIB; k++) fx_release(ctx->fx[k]);
+}
+
+extern "C" int crgpu_set_feature_extractor(crgpu_ctx *ctx, int extractor, const crgpu_feature_def *defs, uint32_t n_defs,
+                                           const double *feat_dist, uint32_t n_dist) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, extractor >= 0 && extractor < CRGPU_MAX_LIB, CRGPU_EINVAL, "extractor id %d out of range", extractor);
+    CR_REQUIRE(ctx, defs && n_defs > 0, CRGPU_EINVAL, "no feature definitions");
+    std::vector<HostPattern> pats;
+    std::map<std::string, size_t> by_key;  // (read, regex_str) -> pattern, as FeatureExtractor::insert keys them
+    for (uint32_t d = 0; d < n_defs; d++) {
+        const crgpu_feature_def &fd = defs[d];
+        CR_REQUIRE(ctx, fd.pattern && fd.sequence && fd.read <= 1, CRGPU_EINVAL, "feature definition %u is incomplete", d);
+        const std::string seq = fd.sequence, pat = fd.pattern;
+        CR_REQUIRE(ctx, !seq.empty() && std::all_of(seq.begin(), seq.end(), is_base_or_n), CRGPU_EINVAL,
+                   "Invalid sequence: '%s'. The only allowed characters are A, C, G, T, and N.", fd.sequence);
+        CR_REQUIRE(ctx, seq.size() <= 32, CRGPU_ERANGE, "feature barcode of %zu bases unsupported (<= 32)", seq.size());
+        CR_REQUIRE(ctx, !feat_dist || fd.index < n_dist, CRGPU_EINVAL, "feature index %u outside the distribution", fd.index);
+        HostPattern hp;
+        hp.read = (int)fd.read;
+        hp.L = (uint32_t)seq.size();
+        std::string key;
+        if (pat == "(BC)") {
+            hp.tethered = false;
+            key = std::to_string(fd.read) + "|bare|" + std::to_string(seq.size());
+        } else {
+            Parsed p;
+            CR_REQUIRE(ctx, parse_pattern(pat, p), CRGPU_EINVAL,
+                       "Invalid pattern: '%s'. The pattern must optionally start with '5P', optionally end with '3P', contain "
+                       "exactly one instance of the string '(BC)' and otherwise contain only the characters A, C, G, T, and N.",
+                       fd.pattern);
+            hp.regex = tethered_regex(p, hp.L);
+            hp.anchor5 = !p.left.empty() && p.left[0] == '^';
+            hp.anchor3 = !p.right.empty() && p.right.back() == '$';
+            // "(BC)^..." and "...$(BC)" pass the reference's validation and compile, but can never match
+            hp.never = p.right.find('^') != std::string::npos || p.left.find('$') != std::string::npos;
+            hp.prefix = dots(p.left.substr(hp.anchor5 ? 1 : 0));
+            hp.suffix = dots(p.right.substr(0, p.right.size() - (hp.anchor3 ? 1 : 0)));
+            key = std::to_string(fd.read) + "|" + hp.regex;
+        }
+        auto it = by_key.find(key);
+        if (it == by_key.end()) {
+            it = by_key.emplace(key, pats.size()).first;
+            pats.push_back(hp);
+        }
+        HostPattern &P = pats[it->second];
+        for (const auto &f : P.feats)
+            CR_REQUIRE(ctx, f.first != seq, CRGPU_EINVAL,
+                       "Found two feature definitions with the same read, pattern ('%s') and barcode sequence ('%s')", fd.pattern,
+                       fd.sequence);
+        P.feats.emplace_back(seq, fd.index);
+    }
+    // device image
+    std::vector<FxPat> hp(pats.size());
+    std::string chars;
+    std::vector<uint64_t> key;
+    std::vector<uint32_t> index, ha_key, ha_f, hb_key, hb_f;
+    std::vector<double> dist;
+    std::vector<std::string> regexes;
+    uint32_t max_feat = 0;
+    for (size_t p = 0; p < pats.size(); p++) {
+        HostPattern &P = pats[p];
+        if (!P.tethered) {  // compile_bare_patterns (:291-305), for crgpu_feature_extractor_regex
+            std::string r = "(";
+            for (const auto &f : P.feats)
+                for (uint32_t i = 0; i < P.L; i++) {
+                    if (r.size() > 1) r += '|';
+                    std::string a = f.first;
+                    a[i] = '.';
+                    r += a;
+                }
+            P.regex = r + ")";
+        }
+        regexes.push_back(P.regex);
+        struct E {
+            uint64_t k;
+            uint32_t idx;
+        };
+        std::vector<E> es;
+        for (const auto &f : P.feats) {
+            uint64_t k;
+            CR_REQUIRE(ctx, pack_seq(f.first, &k), CRGPU_EINVAL, "feature sequence '%s': N in feature sequences is unsupported",
+                       f.first.c_str());
+            es.push_back({k, f.second});
+        }
+        std::sort(es.begin(), es.end(), [](const E &a, const E &b) { return a.k < b.k; });
+        FxPat &D = hp[p];
+        D.read = (uint32_t)P.read;
+        D.tethered = P.tethered;
+        D.anchor5 = P.anchor5;
+        D.anchor3 = P.anchor3;
+        D.never = P.never;
+        D.pre_off = (uint32_t)chars.size();
+        D.pre_len = (uint32_t)P.prefix.size();
+        chars += P.prefix;
+        D.suf_off = (uint32_t)chars.size();
+        D.suf_len = (uint32_t)P.suffix.size();
+        chars += P.suffix;
+        D.L = P.L;
+        D.feat_off = (uint32_t)key.size();
+        D.n_feat = (uint32_t)es.size();
+        D.least_index = 0xFFFFFFFFu;
+        max_feat = std::max(max_feat, D.n_feat);
+        const uint32_t h = P.L / 2;
+        std::vector<std::pair<uint32_t, uint32_t>> a, b;
+        for (uint32_t f = 0; f < es.size(); f++) {
+            key.push_back(es[f].k);
+            index.push_back(es[f].idx);
+            dist.push_back(feat_dist ? feat_dist[es[f].idx] : 0.0);
+            D.least_index = std::min(D.least_index, es[f].idx);
+            a.emplace_back((uint32_t)(es[f].k >> (2 * h)), f);
+            b.emplace_back((uint32_t)(h ? es[f].k & (~0ull >> (64 - 2 * h)) : 0ull), f);
+        }
+        std::sort(a.begin(), a.end());
+        std::sort(b.begin(), b.end());
+        for (const auto &x : a) {
+            ha_key.push_back(x.first);
+            ha_f.push_back(x.second);
+        }
+        for (const auto &x : b) {
+            hb_key.push_back(x.first);
+            hb_f.push_back(x.second);
+        }
+    }
+    // one allocation: patterns | keys | dist | index | ha_key | ha_f | hb_key | hb_f | chars
+    const size_t nf = key.size();
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    FeatureExtractorSet X;
+    X.off_pat = 0;
+    X.off_key = up8(hp.size() * sizeof(FxPat));
+    X.off_dist = X.off_key + nf * 8;
+    X.off_index = X.off_dist + nf * 8;
+    X.off_ha_key = X.off_index + up8(nf * 4);
+    X.off_ha_f = X.off_ha_key + up8(nf * 4);
+    X.off_hb_key = X.off_ha_f + up8(nf * 4);
+    X.off_hb_f = X.off_hb_key + up8(nf * 4);
+    X.off_chars = X.off_hb_f + up8(nf * 4);
+    const size_t total = X.off_chars + up8(chars.size() + 1);
+    std::vector<uint8_t> blob(total, 0);
+    std::memcpy(blob.data() + X.off_pat, hp.data(), hp.size() * sizeof(FxPat));
+    std::memcpy(blob.data() + X.off_key, key.data(), nf * 8);
+    std::memcpy(blob.data() + X.off_dist, dist.data(), nf * 8);
+    std::memcpy(blob.data() + X.off_index, index.data(), nf * 4);
+    std::memcpy(blob.data() + X.off_ha_key, ha_key.data(), nf * 4);
+    std::memcpy(blob.data() + X.off_ha_f, ha_f.data(), nf * 4);
+    std::memcpy(blob.data() + X.off_hb_key, hb_key.data(), nf * 4);
+    std::memcpy(blob.data() + X.off_hb_f, hb_f.data(), nf * 4);
+    std::memcpy(blob.data() + X.off_chars, chars.data(), chars.size());
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    fx_release(ctx->fx[extractor]);
+    CR_HIP(ctx, hipMalloc(&X.d_blob, total));
+    CR_HIP(ctx, hipMemcpy(X.d_blob, blob.data(), total, hipMemcpyHostToDevice));
+    X.n_pat = (uint32_t)hp.size();
+    X.max_feat = max_feat;
+    X.has_dist = feat_dist != nullptr;
+    X.uses_read[0] = X.uses_read[1] = false;
+    for (const auto &P : pats) X.uses_read[P.read] = true;
+    X.regex = regexes;
+    X.set = true;
+    ctx->fx[extractor] = X;
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_feature_extractor_regex(crgpu_ctx *ctx, int extractor, uint32_t pattern, char *regex_out, uint64_t cap,
+                                             uint32_t *n_patterns_out) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, extractor >= 0 && extractor < CRGPU_MAX_LIB && ctx->fx[extractor].set, CRGPU_ESTATE,
+               "feature extractor %d not set", extractor);
+    const FeatureExtractorSet &X = ctx->fx[extractor];
+    if (n_patterns_out) *n_patterns_out = X.n_pat;
+    if (!regex_out) return CRGPU_OK;
+    CR_REQUIRE(ctx, pattern < X.n_pat, CRGPU_EINVAL, "pattern %u out of range", pattern);
+    CR_REQUIRE(ctx, X.regex[pattern].size() + 1 <= cap, CRGPU_ERANGE, "regex buffer too small");
+    std::memcpy(regex_out, X.regex[pattern].c_str(), X.regex[pattern].size() + 1);
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const uint8_t *d_r1_seq, const uint8_t *d_r1_qual,
+                                          const uint32_t *d_r1_len, uint32_t r1_stride, const uint8_t *d_r2_seq,
+                                          const uint8_t *d_r2_qual, const uint32_t *d_r2_len, uint32_t r2_stride, uint64_t n,
+                                          uint32_t *d_feature_out, uint32_t *d_n_ids_out, uint32_t *d_capture_out) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, extractor >= 0 && extractor < CRGPU_MAX_LIB && ctx->fx[extractor].set, CRGPU_ESTATE,
+               "feature extractor %d not set", extractor);
+    if (n == 0) return CRGPU_OK;
+    const FeatureExtractorSet &X = ctx->fx[extractor];
+    CR_REQUIRE(ctx, d_feature_out, CRGPU_EINVAL, "crgpu_extract_features_dev: NULL output");
+    CR_REQUIRE(ctx, !X.uses_read[0] || (d_r1_seq && d_r1_qual && r1_stride), CRGPU_EINVAL,
+               "the extractor holds R1 patterns but no R1 rows were given");
+    CR_REQUIRE(ctx, !X.uses_read[1] || (d_r2_seq && d_r2_qual && r2_stride), CRGPU_EINVAL,
+               "the extractor holds R2 patterns but no R2 rows were given");
+    CR_REQUIRE(ctx, r1_stride < (1u << 22) && r2_stride < (1u << 22), CRGPU_ERANGE, "rows longer than 4 Mi bases");
+    double pe[34];
+    for (int q = 0; q < 34; q++) pe[q] = std::pow(10.0, -(double)q / 10.0);  // host libm as in :45
+    double *d_pe = (double *)(ctx->d_scalars + 128);
+    uint32_t *d_nq = ctx->d_scalars + 16;
+    CR_HIP(ctx, hipMemcpyAsync(d_pe, pe, sizeof(pe), hipMemcpyHostToDevice, ctx->stream));
+    CR_HIP(ctx, hipMemsetAsync(d_nq, 0, sizeof(uint32_t), ctx->stream));
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pe is a stack buffer
+    const uint8_t *base = (const uint8_t *)X.d_blob;
+    FxView v{(const FxPat *)(base + X.off_pat), X.n_pat, (const char *)(base + X.off_chars), (const uint64_t *)(base + X.off_key),
+             (const uint32_t *)(base + X.off_index), X.has_dist ? (const double *)(base + X.off_dist) : nullptr,
+             (const uint32_t *)(base + X.off_ha_key), (const uint32_t *)(base + X.off_ha_f), (const uint32_t *)(base + X.off_hb_key),
+             (const uint32_t *)(base + X.off_hb_f)};
+    FxRows r1{d_r1_seq, d_r1_qual, d_r1_len, r1_stride}, r2{d_r2_seq, d_r2_qual, d_r2_len, r2_stride};
+    // the queue of reads whose map outgrew the local array: sized so that their global map rows stay below 256 MB;
+    // more than that many are handled by further rounds over what is left
+    const uint32_t row_entries = std::max(X.max_feat, 1u);
+    const uint64_t by_rows = std::max<uint64_t>(1, (256ull << 20) / ((uint64_t)row_entries * sizeof(FxEntry)));
+    const uint32_t queue_cap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n, by_rows), 1u << 20);
+    void *queue_p = nullptr;
+    CR_TRY(cr_pool_alloc(ctx, &queue_p, (uint64_t)queue_cap * sizeof(uint64_t)));
+    struct Release {
+        crgpu_ctx *c;
+        void *p;
+        ~Release() { cr_pool_free(c, p); }
+    } rel_q{ctx, queue_p};
+    uint64_t *d_queue = (uint64_t *)queue_p;
+    CrTimer t(ctx, CRGPU_T_MATCH, n);
+    hipLaunchKernelGGL(k_extract_features, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, v, d_pe, r1, r2, n, d_feature_out,
+                       d_n_ids_out, d_capture_out, d_nq, d_queue, queue_cap);
+    CR_HIP(ctx, hipGetLastError());
+    uint32_t nq = 0;
+    CR_HIP(ctx, hipMemcpyAsync(&nq, d_nq, sizeof(nq), hipMemcpyDeviceToHost, ctx->stream));
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nq == 0) return CRGPU_OK;
+    ctx->feature_reads_requeued += nq;
+    CR_REQUIRE(ctx, nq <= queue_cap, CRGPU_ERANGE,
+               "%u reads need the wide correction map but only %u fit in one call; split the batch", nq, queue_cap);
+    void *rows_p = nullptr;
+    CR_TRY(cr_pool_alloc(ctx, &rows_p, (uint64_t)nq * row_entries * sizeof(FxEntry)));
+    Release rel_r{ctx, rows_p};
+    hipLaunchKernelGGL(k_extract_features_queued, dim3((nq + 255u) / 256u), dim3(256), 0, ctx->stream, v, d_pe, r1, r2, d_queue, nq,
+                       (FxEntry *)rows_p, row_entries, d_feature_out, d_n_ids_out, d_capture_out);
+    CR_HIP(ctx, hipGetLastError());
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the rows go back to the pool
+    return CRGPU_OK;
+}

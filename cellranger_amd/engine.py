@@ -39,6 +39,13 @@ def unpack_seqs(packed, length):
     return out
 
 
+def compile_feature_pattern(pattern, length):
+    """compile_pattern (feature_extraction.rs:307-343): the regular expression as text, None for a rejected pattern"""
+    buf = C.create_string_buffer(4096)
+    rc = _lib.load().crgpu_compile_feature_pattern(pattern.encode(), length, buf, 4096)
+    return buf.value.decode() if rc == 0 else None
+
+
 def ascii_matrix(seqs, length=None):
     if isinstance(seqs, np.ndarray) and seqs.dtype == np.uint8 and seqs.ndim == 2:
         return np.ascontiguousarray(seqs)
@@ -661,6 +668,33 @@ class Context:
 
     def match_features(self, pattern, d_seq, d_qualn, n, d_feature_out):
         self._check(self.L.crgpu_match_features_dev(self.h, pattern, _p(d_seq), _p(d_qualn), n, _p(d_feature_out)))
+
+    # whole reads, every pattern form (FeatureExtractor::match_read)
+    def set_feature_extractor(self, extractor, defs, feat_dist=None):
+        """defs: [(pattern, sequence, FeatureDef::index, read)] of ONE feature type, read 0 = R1, 1 = R2"""
+        keep = [(p.encode(), s.encode()) for p, s, _, _ in defs]
+        arr = (_lib.FeatureDef * len(defs))()
+        for k, (_, _, index, read) in enumerate(defs):
+            arr[k] = _lib.FeatureDef(keep[k][0], keep[k][1], index, read)
+        d = None if feat_dist is None else np.ascontiguousarray(feat_dist, dtype=np.float64)
+        self._check(self.L.crgpu_set_feature_extractor(self.h, extractor, arr, len(defs), ptr(d), 0 if d is None else len(d)))
+
+    def feature_extractor_regexes(self, extractor):
+        n = C.c_uint32(0)
+        self._check(self.L.crgpu_feature_extractor_regex(self.h, extractor, 0, None, 0, C.byref(n)))
+        out = []
+        for p in range(n.value):
+            buf = C.create_string_buffer(1 << 20)
+            self._check(self.L.crgpu_feature_extractor_regex(self.h, extractor, p, buf, 1 << 20, None))
+            out.append(buf.value.decode())
+        return out
+
+    def extract_features(self, extractor, n, d_feature_out, r1=None, r2=None, d_n_ids_out=None, d_capture_out=None):
+        """r1 / r2: (d_seq_rows, d_qual_rows, d_len or None, stride) or None"""
+        a = r1 or (None, None, None, 0)
+        b = r2 or (None, None, None, 0)
+        self._check(self.L.crgpu_extract_features_dev(self.h, extractor, _p(a[0]), _p(a[1]), _p(a[2]), a[3], _p(b[0]), _p(b[1]),
+                                                      _p(b[2]), b[3], n, _p(d_feature_out), _p(d_n_ids_out), _p(d_capture_out)))
 
     # ---- synthetic data --------------------------------------------------------------------------------
     def synth(self, params, first, n, cb=None, cb_qualn=None, umi=None, umi_qualn=None, feature=None, flags=None):

@@ -95,6 +95,7 @@ int crgpu_set_option(crgpu_ctx *ctx, int option, int64_t value);
 int crgpu_invalidate(crgpu_ctx *ctx);
 /* counters since the context was made */
 #define CRGPU_STAT_SORT_FALLBACKS 0  /* sorts whose look-back watchdog fired and that the classic passes finished */
+#define CRGPU_STAT_FEATURE_READS_REQUEUED 2 /* reads of crgpu_extract_features_dev redone with the wide correction map */
 #define CRGPU_STAT_SORT_REFINISHED 1 /* sorts redone on all key bits because a run of equal top bits was too long for the finishing pass */
 int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out);
 /* ctx may be NULL: returns the message of the last failed crgpu_create on this thread. */
@@ -529,6 +530,45 @@ int crgpu_set_feature_pattern(crgpu_ctx *ctx, int pattern, const char *feat_seqs
                               const uint32_t *feat_index, const double *feat_dist);
 int crgpu_match_features_dev(crgpu_ctx *ctx, int pattern, const uint32_t *d_seq, const uint8_t *d_qualn,
                              uint64_t n, uint32_t *d_feature_out);
+
+/* ---- feature extraction over whole reads, every pattern form (K3x) --------------------------------------------------
+ * Replaces FeatureExtractor::new and FeatureExtractor::match_read (cr_types/src/reference/feature_extraction.rs:176-262,
+ * :358-441) together with find_closest (:443-470) and correct_feature_barcode over any number of captures (:34-117):
+ * tethered patterns ("5P" / '^', "3P" / '$', N wildcards around "(BC)"; one capture, the leftmost) and bare "(BC)"
+ * patterns (every window within one mismatch of a feature of the same read and length is a capture).
+ * One extractor holds the definitions of ONE feature type -- match_read skips the groups of other types (:376-378) --
+ * so the caller registers one per library type with feature barcodes and routes its reads by library type.
+ *   crgpu_set_feature_extractor  defs[n_defs]: pattern, sequence (A/C/G/T, <= 32 bases; N is refused), FeatureDef::index,
+ *                                read (0 = R1, 1 = R2).  feat_dist (nullable) = compute_feature_dist proportions indexed
+ *                                by FeatureDef::index (n_dist entries); without it only single exact captures match.
+ *                                CRGPU_EINVAL with the reference's message for an invalid pattern or sequence and for
+ *                                two definitions with the same read, pattern and sequence (:152-163).
+ *   crgpu_compile_feature_pattern  compile_pattern (:307-343): the regular expression the reference would build, as text
+ *                                (CRGPU_EINVAL for a pattern it rejects); crgpu_feature_extractor_regex returns the
+ *                                expression of one compiled pattern (tethered or bare, :291-305) and the pattern count.
+ *   crgpu_extract_features_dev   n read pairs as rows (crgpu_fastq_to_rows_dev layout: stride bytes per read, d_len
+ *                                nullable = every row is full); a read the extractor has no pattern for may be NULL.
+ *       d_feature_out[i]  the feature index when FeatureData::ids holds exactly one id (the reads that are counted:
+ *                         tx_annotation read.rs:983-987, make_shard_metrics.rs:342), else CRGPU_NO_FEATURE
+ *       d_n_ids_out[i]    (nullable) ids.len()
+ *       d_capture_out[i]  (nullable) FeatureData::barcode / qual as a span: bit 31 = corrected_barcode is Some, bit 30 = read,
+ *                         bits 8..29 = start, bits 0..7 = length; CRGPU_NO_CAPTURE when match_read returns None. */
+typedef struct crgpu_feature_def {
+    const char *pattern;
+    const char *sequence;
+    uint32_t index;
+    uint32_t read;
+} crgpu_feature_def;
+#define CRGPU_NO_CAPTURE 0xFFFFFFFFu
+int crgpu_set_feature_extractor(crgpu_ctx *ctx, int extractor, const crgpu_feature_def *defs, uint32_t n_defs,
+                                const double *feat_dist, uint32_t n_dist);
+int crgpu_compile_feature_pattern(const char *pattern, uint32_t length, char *regex_out, uint64_t cap);
+int crgpu_feature_extractor_regex(crgpu_ctx *ctx, int extractor, uint32_t pattern, char *regex_out, uint64_t cap,
+                                  uint32_t *n_patterns_out);
+int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const uint8_t *d_r1_seq, const uint8_t *d_r1_qual,
+                               const uint32_t *d_r1_len, uint32_t r1_stride, const uint8_t *d_r2_seq,
+                               const uint8_t *d_r2_qual, const uint32_t *d_r2_len, uint32_t r2_stride, uint64_t n,
+                               uint32_t *d_feature_out, uint32_t *d_n_ids_out, uint32_t *d_capture_out);
 
 /* ---- synthetic workloads (bench / tests) ---------------------------------------------
  * Counter-based integer generator: read i of a given seed is identical on the host and on the

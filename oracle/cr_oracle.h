@@ -214,6 +214,37 @@ int64_t oracle_find_closest_feature(const char *feat_seqs, uint32_t n_feat, uint
 void oracle_compute_feature_dist(const int64_t *counts, const uint32_t *feature_type,
                                  uint32_t n_feat, double *dist_out);
 
+/* ---- FeatureExtractor with every pattern form (cr_types/src/reference/feature_extraction.rs:176-470): tethered
+ * patterns ("5P...(BC)...3P", '^' / '$', N wildcards) and bare "(BC)" patterns whose every window within one mismatch
+ * of a feature is a capture; several captures go through correct_feature_barcode's replace-if-greater map.  One
+ * extractor holds the definitions of ONE feature type (match_read skips the groups of other types, :376-378). */
+typedef struct {
+    const char *pattern;  /* FeatureDef::pattern */
+    const char *sequence; /* FeatureDef::sequence */
+    uint32_t index;       /* FeatureDef::index (into feat_dist) */
+    uint32_t read;        /* FeatureDef::read: 0 = R1, 1 = R2 */
+} oracle_feature_def;
+#define ORACLE_MAX_FEATURE_IDS 16
+typedef struct {
+    int matched;   /* match_read returned Some */
+    int corrected; /* FeatureData::corrected_barcode is Some */
+    uint32_t n_ids;
+    uint32_t ids[ORACLE_MAX_FEATURE_IDS]; /* FeatureData::ids (feature indices), in pattern creation order */
+    uint32_t read, start, len;            /* FeatureData::barcode / qual as a span of the read */
+    char corrected_barcode[64];
+} oracle_feature_data;
+typedef struct oracle_extractor oracle_extractor;
+oracle_extractor *oracle_extractor_new(const oracle_feature_def *defs, uint32_t n_defs, const double *feat_dist /* nullable */,
+                                       uint32_t n_dist, char *err, size_t err_cap);
+void oracle_extractor_free(oracle_extractor *x);
+uint32_t oracle_extractor_n_patterns(const oracle_extractor *x);
+const char *oracle_extractor_regex(const oracle_extractor *x, uint32_t pattern);
+int oracle_match_read(const oracle_extractor *x, const char *r1, const uint8_t *q1, uint32_t l1, const char *r2,
+                      const uint8_t *q2, uint32_t l2, oracle_feature_data *out);
+/* compile_pattern (:307-343) / compile_bare_patterns (:291-305): the regular expression as a string; -1 = invalid */
+int oracle_compile_feature_pattern(const char *orig_pat, uint32_t length, char *out, size_t out_cap);
+int oracle_compile_bare_patterns(const char *const *seqs, uint32_t n, char *out, size_t out_cap);
+
 /* ---- MAKE_SHARD read metrics over the barcode / UMI parts of a read (cr_lib/src/make_shard_metrics.rs:263-332,
  * :355-392; constants :20-23; RnaRead::barcode_min_qual / umi_min_qual cr_types/src/rna_read.rs:738-749).
  * PercentMetric numerators / denominators as plain counts.  bc_state: the oracle_barcode_stage result

@@ -66,6 +66,15 @@ class BcResult(C.Structure):
     _fields_ = [("corrected_cb", C.c_void_p), ("bc_state", C.c_void_p)]
 
 
+class FeatureDef(C.Structure):
+    _fields_ = [("pattern", C.c_char_p), ("sequence", C.c_char_p), ("index", C.c_uint32), ("read", C.c_uint32)]
+
+
+class FeatureData(C.Structure):
+    _fields_ = [("matched", C.c_int), ("corrected", C.c_int), ("n_ids", C.c_uint32), ("ids", C.c_uint32 * 16),
+                ("read", C.c_uint32), ("start", C.c_uint32), ("len", C.c_uint32), ("corrected_barcode", C.c_char * 64)]
+
+
 class Matrix(C.Structure):
     _fields_ = [
         ("n_barcodes", C.c_uint64),
@@ -126,6 +135,19 @@ def lib():
     L.oracle_find_closest_feature.restype = i64
     L.oracle_find_closest_feature.argtypes = [C.c_char_p, u32, u32, vp, C.c_char_p, vp]
     L.oracle_compute_feature_dist.argtypes = [vp, vp, u32, vp]
+    L.oracle_extractor_new.restype = vp
+    L.oracle_extractor_new.argtypes = [vp, u32, vp, u32, C.c_char_p, C.c_size_t]
+    L.oracle_extractor_free.argtypes = [vp]
+    L.oracle_extractor_n_patterns.restype = u32
+    L.oracle_extractor_n_patterns.argtypes = [vp]
+    L.oracle_extractor_regex.restype = C.c_char_p
+    L.oracle_extractor_regex.argtypes = [vp, u32]
+    L.oracle_match_read.restype = C.c_int
+    L.oracle_match_read.argtypes = [vp, C.c_char_p, vp, u32, C.c_char_p, vp, u32, C.POINTER(FeatureData)]
+    L.oracle_compile_feature_pattern.restype = C.c_int
+    L.oracle_compile_feature_pattern.argtypes = [C.c_char_p, u32, C.c_char_p, C.c_size_t]
+    L.oracle_compile_bare_patterns.restype = C.c_int
+    L.oracle_compile_bare_patterns.argtypes = [vp, u32, C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -404,6 +426,61 @@ def find_closest_feature(feat_seqs, feat_dist, seq, qual):
     s = seq.encode() if isinstance(seq, str) else bytes(seq)
     q = np.frombuffer(qual.encode() if isinstance(qual, str) else bytes(qual), dtype=np.uint8).copy()
     return lib().oracle_find_closest_feature(fs.tobytes(), fs.shape[0], fs.shape[1], _ptr(d), s, _ptr(q))
+
+
+def compile_feature_pattern(pattern, length):
+    """compile_pattern: the regular expression string, or None for an invalid pattern"""
+    buf = C.create_string_buffer(1024)
+    rc = lib().oracle_compile_feature_pattern(pattern.encode(), length, buf, 1024)
+    return buf.value.decode() if rc == 0 else None
+
+
+def compile_bare_patterns(seqs):
+    arr = (C.c_char_p * len(seqs))(*[s.encode() for s in seqs])
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib().oracle_compile_bare_patterns(arr, len(seqs), buf, 1 << 16)
+    return buf.value.decode() if rc == 0 else None
+
+
+class FeatureExtractor:
+    """FeatureExtractor of ONE feature type: defs = [(pattern, sequence, index, read)], read 0 = R1, 1 = R2."""
+
+    def __init__(self, defs, feat_dist=None):
+        self._keep = [(p.encode(), s.encode()) for p, s, _, _ in defs]
+        arr = (FeatureDef * len(defs))()
+        for k, (_, _, index, read) in enumerate(defs):
+            arr[k] = FeatureDef(self._keep[k][0], self._keep[k][1], index, read)
+        err = C.create_string_buffer(256)
+        d = None if feat_dist is None else np.ascontiguousarray(feat_dist, dtype=np.float64)
+        self.h = lib().oracle_extractor_new(arr, len(defs), None if d is None else _ptr(d), 0 if d is None else len(d), err, 256)
+        if not self.h:
+            raise ValueError(err.value.decode())
+
+    def regexes(self):
+        return [lib().oracle_extractor_regex(self.h, p).decode() for p in range(lib().oracle_extractor_n_patterns(self.h))]
+
+    def match_read(self, r1=None, q1=None, r2=None, q2=None):
+        """-> None or dict(corrected, ids (sorted), read, start, len, corrected_barcode)"""
+        def prep(s, q):
+            if s is None:
+                return None, None, 0, None
+            s = s.encode() if isinstance(s, str) else bytes(s)
+            qa = np.frombuffer(q.encode() if isinstance(q, str) else bytes(q), np.uint8).copy()
+            return s, _ptr(qa), len(s), qa
+        s1, p1, l1, k1 = prep(r1, q1)
+        s2, p2, l2, k2 = prep(r2, q2)
+        out = FeatureData()
+        if not lib().oracle_match_read(self.h, s1, p1, l1, s2, p2, l2, C.byref(out)):
+            return None
+        return dict(corrected=bool(out.corrected), n_ids=out.n_ids, ids=sorted(out.ids[:min(out.n_ids, 16)]), read=out.read,
+                    start=out.start, len=out.len, corrected_barcode=out.corrected_barcode.decode() if out.corrected else None)
+
+    def close(self):
+        if self.h:
+            lib().oracle_extractor_free(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def compute_feature_dist(counts, feature_types):

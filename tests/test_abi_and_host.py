@@ -133,3 +133,14 @@ def test_bench_launcher_starts_its_own_ranks_and_refuses_a_world_mismatch():
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads-per-gpu", "1000"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "ranks failed" in r.stderr  # the first rank to die ends the other one, too
+
+
+def test_compile_feature_pattern_golden():
+    """compile_pattern (feature_extraction.rs:307-343) is host code behind the C ABI: the reference's test_compile_pattern
+    cases (:585-635) need no GPU"""
+    import json
+    from cellranger_amd import engine as E
+    with open(os.path.join(os.path.dirname(__file__), "golden", "feature_vectors.json")) as f:
+        g = json.load(f)
+    for case in g["compile_pattern"]:
+        assert E.compile_feature_pattern(case["pattern"], case["length"]) == case["regex"], case

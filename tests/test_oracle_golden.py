@@ -137,11 +137,76 @@ def test_feature_correction_golden(name):
     g = load("feature_vectors.json")[name]
     dist = O.compute_feature_dist(g["counts"], g["types"])
     for case in g["cases"]:
+        if case.get("multi_capture"):
+            continue  # several captures: the extractor tests below
         sel = [i for i, t in enumerate(g["types"]) if t == case["type"]]
         feats = [g["features"][i] for i in sel]
         got = O.correct_feature_barcode(feats, dist[sel], case["seq"], case["qual"])
         want = None if case["expect"] is None else case["expect"]
         assert (feats[got] if got >= 0 else None) == want, case
+
+
+def test_compile_pattern_golden():
+    """test_compile_pattern (feature_extraction.rs:585-635)"""
+    g = load("feature_vectors.json")
+    for case in g["compile_pattern"]:
+        assert O.compile_feature_pattern(case["pattern"], case["length"]) == case["regex"], case
+    assert O.compile_bare_patterns(g["compile_bare"]["sequences"]) == g["compile_bare"]["regex"]
+
+
+@pytest.mark.parametrize("name", ["correct_feature", "correct_bare_feature"])
+def test_feature_extractor_golden(name):
+    """the reference's tests run through match_read (their helper, feature_extraction.rs:490-524): the read is the
+    sequence itself, so a bare pattern sees every window of it -- ACCTTTT holds three captures."""
+    g = load("feature_vectors.json")[name]
+    dist = O.compute_feature_dist(g["counts"], g["types"])
+    ext = {}
+    for t in sorted(set(g["types"])):
+        defs = [(g["pattern"], g["features"][i], i, 0) for i, x in enumerate(g["types"]) if x == t]
+        ext[t] = O.FeatureExtractor(defs, dist)
+    for case in g["cases"]:
+        r = ext[case["type"]].match_read(case["seq"], case["qual"], case["seq"], case["qual"])
+        got = r["corrected_barcode"] if r else None
+        assert got == case["expect"], case
+
+
+def test_feature_extractor_rules():
+    """hand-checked consequences of match_read / find_closest (feature_extraction.rs:358-470); no reference fixture
+    covers them (parity unpinned beyond the vectors above)"""
+    # a duplicate (read, pattern, sequence) is refused (:152-163), an invalid pattern too
+    with pytest.raises(ValueError):
+        O.FeatureExtractor([("^(BC)", "ACGT", 0, 0), ("^(BC)", "ACGT", 1, 0)])
+    with pytest.raises(ValueError):
+        O.FeatureExtractor([("(BC)Q", "ACGT", 0, 0)])
+    x = O.FeatureExtractor([("5PNN(BC)", "ACGT", 0, 1), ("(BC)GG3P", "TTTTT", 1, 1), ("(BC)", "CCCC", 2, 1)], None)
+    assert x.regexes() == ["^..(.{4,4})", "(.{5,5})GG$", "(.CCC|C.CC|CC.C|CCC.)"]
+    # exact hit of the first pattern only
+    r = x.match_read(r2="GGACGTAAAA", q2="IIIIIIIIII")
+    assert r == dict(corrected=True, n_ids=1, ids=[0], read=1, start=2, len=4, corrected_barcode="ACGT")
+    # two patterns hit: both ids, the longer corrected barcode is reported
+    r = x.match_read(r2="GGACGTTTTTGG", q2="I" * 12)
+    assert r["ids"] == [0, 1] and r["corrected_barcode"] == "TTTTT" and (r["start"], r["len"]) == (5, 5)
+    # no distribution: one mismatch is not corrected, the raw capture is still reported (pattern_matches)
+    r = x.match_read(r2="GGACCTAAAA", q2="IIIIIIIIII")
+    assert r == dict(corrected=False, n_ids=0, ids=[], read=1, start=2, len=4, corrected_barcode=None)
+    # the tethered pattern's capture ACCC (least feature index 0) outranks the bare pattern's captures (index 2)
+    r = x.match_read(r2="AAACCCACCCC", q2="I" * 11)
+    assert r["corrected"] is False and (r["start"], r["len"]) == (2, 4)
+    assert x.match_read(r2="AAAAA", q2="I" * 5) is None  # too short for the tethered patterns, no window near CCCC
+    # bare pattern alone: the windows at 2..7 are all within one mismatch of CCCC; without a distribution find_closest
+    # gives up on several captures although the last one is exact, and the LAST capture is the one reported
+    b = O.FeatureExtractor([("(BC)", "CCCC", 2, 1)], None)
+    r = b.match_read(r2="AAACCCACCCC", q2="I" * 11)
+    assert r["corrected"] is False and (r["start"], r["len"]) == (7, 4)
+    # one capture and exact: the fast path needs no distribution
+    assert b.match_read(r2="CCCC", q2="IIII")["ids"] == [2]
+    r = b.match_read(r2="GGGGCCCCGGGG", q2="I" * 12)  # windows GCCC, CCCC, CCCG -> three captures -> no decision
+    assert r["corrected"] is False
+    # with a distribution the exact capture carries the decision: CCCC exact (p) against two edits of it (p * 1e-3.3)
+    # collapse into ONE map entry (replace-if-greater), ratio 1
+    b2 = O.FeatureExtractor([("(BC)", "CCCC", 2, 1)], [0.0, 0.0, 1.0])
+    r = b2.match_read(r2="GGGGCCCCGGGG", q2="I" * 12)
+    assert r["ids"] == [2] and (r["start"], r["len"]) == (4, 4)
 
 
 def test_barcode_index_golden():
