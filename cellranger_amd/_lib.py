@@ -56,6 +56,7 @@ class MatrixView(C.Structure):
         ("indices", C.c_void_p),
         ("data", C.c_void_p),
         ("gem_group", C.c_void_p),
+        ("barcode_seq_hi", C.c_void_p),
     ]
 
 
@@ -214,6 +215,8 @@ SYMBOLS = {
     "crgpu_count": (_i, [_vp, C.POINTER(Records), _u32, C.POINTER(C.POINTER(MatrixView))]),
     "crgpu_set_feature_pattern": (_i, [_vp, _i, C.c_char_p, _u32, _u32, _vp, _vp]),
     "crgpu_match_features_dev": (_i, [_vp, _i, _vp, _vp, _u64, _vp]),
+    "crgpu_set_barcode_segments": (_i, [_vp, _i, _u32, _vp, _vp, _vp]),
+    "crgpu_combine_segments_dev": (_i, [_vp, _i, _vp, _u32, _u64, _i, _vp]),
     "crgpu_set_feature_extractor": (_i, [_vp, _i, _vp, _u32, _vp, _u32]),
     "crgpu_compile_feature_pattern": (_i, [C.c_char_p, _u32, C.c_char_p, _u64]),
     "crgpu_feature_extractor_regex": (_i, [_vp, _i, _u32, C.c_char_p, _u64, _vp]),

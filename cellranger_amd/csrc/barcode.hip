@@ -896,6 +896,8 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_match_and_count: no whitelist set");
+    CR_REQUIRE(ctx, ctx->n_segments == 0, CRGPU_ESTATE,
+               "crgpu_match_and_count: this context holds a segmented barcode space; run the barcode stage on the segment contexts");
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_cb && d_idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
     cr_drop_miss_records(ctx);
@@ -1344,6 +1346,8 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
                             uint64_t n, uint32_t *d_idx_inout, uint8_t *d_corrected_out, bool fake_quals) {
     if (!ctx) return CRGPU_EINVAL;
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "crgpu_correct: no whitelist set");
+    CR_REQUIRE(ctx, ctx->n_segments == 0, CRGPU_ESTATE,
+               "crgpu_correct: this context holds a segmented barcode space; run the barcode stage on the segment contexts");
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_cb && d_idx_inout, CRGPU_EINVAL, "crgpu_correct: NULL buffer");
     CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_correct: batches are limited to 2^32-2 reads");
@@ -1435,6 +1439,103 @@ extern "C" int crgpu_correct_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uin
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     return correct_dev_impl(ctx, d_cb, d_qualn, d_flags, n, d_idx_inout, d_corrected_out, false);
+}
+
+// ------------------------------------------------------------------------------------------------
+// segmented constructs: combined rank of the segments' ranks + the whole-barcode histograms
+// (MakeShardHistograms::observe, make_shard_metrics.rs:171-190; corrected_barcode_counts, barcode_correction.rs:401-407)
+// ------------------------------------------------------------------------------------------------
+struct SegIdx {
+    const uint32_t *idx[CRGPU_MAX_SEGMENTS];
+    uint32_t n[CRGPU_MAX_SEGMENTS];
+    uint32_t n_seg;
+};
+
+// AFTER == false: out[i] = combined rank or MISS.  AFTER == true: a read that had no barcode and has one now gets its
+// rank in out[i] and in fresh[i] (the array the CORRECTED histogram is made of); everything else is MISS in fresh.
+template <bool AFTER>
+__global__ __launch_bounds__(256) void k_combine_segments(const SegIdx S, uint64_t n, uint32_t *__restrict__ out,
+                                                          uint32_t *__restrict__ fresh) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t r = 0;
+        bool ok = true;
+        for (uint32_t s = 0; s < S.n_seg; s++) {
+            const uint32_t v = S.idx[s][i];
+            ok = ok && v < S.n[s];
+            r = r * S.n[s] + (ok ? v : 0u);
+        }
+        if (!ok) r = CRGPU_MISS;
+        if constexpr (AFTER) {
+            const bool is_new = out[i] == CRGPU_MISS && r != CRGPU_MISS;
+            if (is_new) out[i] = r;
+            fresh[i] = is_new ? r : CRGPU_MISS;
+        } else {
+            out[i] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hist_ranks_atomic(const uint32_t *__restrict__ idx, uint64_t n, uint32_t *__restrict__ table) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t r = idx[i];
+        if (r != CRGPU_MISS) atomicAdd(&table[r], 1u);
+    }
+}
+
+extern "C" int crgpu_combine_segments_dev(crgpu_ctx *ctx, int lib, const uint32_t *const *d_seg_idx, uint32_t n_segments,
+                                          uint64_t n, int after_correction, uint32_t *d_idx_inout) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, ctx->n_segments > 0, CRGPU_ESTATE, "crgpu_combine_segments_dev: call crgpu_set_barcode_segments first");
+    CR_REQUIRE(ctx, lib >= 0 && lib < CRGPU_MAX_LIB && ctx->wl[lib].set, CRGPU_ESTATE, "library %d has no barcode space", lib);
+    CR_REQUIRE(ctx, n_segments == ctx->n_segments && d_seg_idx, CRGPU_EINVAL, "crgpu_combine_segments_dev: %u segments expected",
+               ctx->n_segments);
+    if (n == 0) return CRGPU_OK;
+    CR_REQUIRE(ctx, d_idx_inout, CRGPU_EINVAL, "crgpu_combine_segments_dev: NULL output");
+    SegIdx S{};
+    S.n_seg = n_segments;
+    for (uint32_t s = 0; s < n_segments; s++) {
+        CR_REQUIRE(ctx, d_seg_idx[s], CRGPU_EINVAL, "crgpu_combine_segments_dev: NULL idx array of segment %u", s);
+        S.idx[s] = d_seg_idx[s];
+        S.n[s] = ctx->seg_n[s];
+    }
+    cr_invalidate(ctx);
+    uint32_t *d_fresh = nullptr;
+    if (after_correction) CR_TRY(cr_pool_alloc(ctx, (void **)&d_fresh, n * sizeof(uint32_t)));
+    struct Release {
+        crgpu_ctx *c;
+        void *p;
+        ~Release() { cr_pool_free(c, p); }
+    } rel{ctx, d_fresh};
+    CrTimer t(ctx, after_correction ? CRGPU_T_CORRECT : CRGPU_T_MATCH, n);
+    if (after_correction)
+        hipLaunchKernelGGL(k_combine_segments<true>, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, S, n, d_idx_inout, d_fresh);
+    else
+        hipLaunchKernelGGL(k_combine_segments<false>, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, S, n, d_idx_inout, d_fresh);
+    CR_HIP(ctx, hipGetLastError());
+    // the histogram of the new ranks: K1's staging kernels when the space fits their 31 buckets of 32768 ranks, device
+    // atomics otherwise (a product space of millions of barcodes; ~20 G reads/s, same-barcode runs serialise)
+    const WlTables &w = ctx->wl[lib];
+    uint32_t *table = after_correction ? w.d_corrected : w.d_valid;
+    const uint32_t *src = after_correction ? d_fresh : d_idx_inout;
+    BinPlan plan;
+    for (int l = 0; l < CRGPU_MAX_LIB; l++) plan.lib_slot[l] = l == 0 ? 0u : 0xFFFFFFFFu;
+    plan.buckets_per_lib = (ctx->n_canon + BIN_SIZE - 1) / BIN_SIZE;
+    plan.n_buckets = plan.buckets_per_lib;
+    if (plan.n_buckets <= SI_MISS_BUCKET) {
+        WlViewSet vs{};
+        vs.n_canon = ctx->n_canon;
+        vs.ulib = (uint32_t)lib;
+        vs.v[0].valid = table;
+        CR_TRY(hist_from_idx(ctx, vs, plan, src, n));
+    } else {
+        hipLaunchKernelGGL(k_hist_ranks_atomic, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, src, n, table);
+        CR_HIP(ctx, hipGetLastError());
+    }
+    if (d_fresh) CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the block goes back to the pool
+    return CRGPU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -138,6 +138,12 @@ struct crgpu_ctx {
     std::vector<uint32_t> canon_sorted;  // packed, ascending
     std::vector<uint32_t> canon_order;   // rank -> caller position
 
+    // segmented barcode construct (crgpu_set_barcode_segments): the canonical space is the product of the segments'
+    // whitelists, rank = mixed radix of the segment ranks, first segment most significant; canon_sorted stays empty
+    uint32_t n_segments = 0;
+    uint32_t seg_n[CRGPU_MAX_SEGMENTS] = {0}, seg_len[CRGPU_MAX_SEGMENTS] = {0};
+    std::vector<uint32_t> seg_seq[CRGPU_MAX_SEGMENTS];  // packed, ascending
+
     WlTables wl[CRGPU_MAX_LIB];
     FeaturePattern pat[CRGPU_MAX_LIB];
     FeatureExtractorSet fx[CRGPU_MAX_LIB];
@@ -208,6 +214,9 @@ struct CrEnter {
 // forget every by-product kept for the next call (K1's miss records, the key histograms)
 void cr_invalidate(crgpu_ctx *ctx);
 void cr_feature_extractors_free(crgpu_ctx *ctx);  // feature_extract.hip
+// the sequence of a canonical rank as up to 32 bases: *lo = the first min(16, cb_len) bases packed, *hi = the rest (0 when
+// cb_len <= 16); whitelist.hip
+void cr_rank_to_seq(const crgpu_ctx *ctx, uint32_t rank, uint32_t *lo, uint32_t *hi);
 void cr_comm_destroy(crgpu_ctx *ctx);
 int cr_comm_init(crgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id);
 // comm.hip transports (host arrays of n_ranks entries; offsets / sizes in bytes)

@@ -10,9 +10,18 @@
 
 #include "common.h"
 
+// a barcode of cb_len <= 32 bases as text: lo = the first min(16, cb_len) bases packed, hi = the rest
+static void format_barcode(char *buf, uint32_t lo, uint32_t hi, uint32_t cb_len) {
+    static const char acgt[4] = {'A', 'C', 'G', 'T'};
+    const uint32_t n_lo = cb_len < 16 ? cb_len : 16, n_hi = cb_len - n_lo;
+    for (uint32_t p = 0; p < n_lo; p++) buf[p] = acgt[(lo >> (2 * (n_lo - 1 - p))) & 3u];
+    for (uint32_t p = 0; p < n_hi; p++) buf[n_lo + p] = acgt[(hi >> (2 * (n_hi - 1 - p))) & 3u];
+    buf[cb_len] = 0;
+}
+
 struct MatrixImpl {
     crgpu_matrix view;
-    std::vector<uint32_t> rank, seq;
+    std::vector<uint32_t> rank, seq, seq_hi;  // seq_hi: bases 17.. of a segmented construct's barcodes, else empty
     std::vector<int64_t> indptr;
     std::vector<int32_t> indices, data;
     std::vector<uint16_t> gem_group;
@@ -89,7 +98,10 @@ extern "C" int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const u
         if (seen[r]) {
             col_of_rank[r] = (uint32_t)m->rank.size();
             m->rank.push_back(r);
-            m->seq.push_back(ctx->canon_sorted[r]);
+            uint32_t lo, hi;
+            cr_rank_to_seq(ctx, r, &lo, &hi);
+            m->seq.push_back(lo);
+            if (ctx->cb_len > 16) m->seq_hi.push_back(hi);
         }
     const uint64_t V = m->rank.size();
 
@@ -134,6 +146,7 @@ extern "C" int crgpu_assemble_matrix(crgpu_ctx *ctx, const uint32_t *bc, const u
     m->view.cb_len = ctx->cb_len;
     m->view.barcode_rank = m->rank.data();
     m->view.barcode_seq = m->seq.data();
+    m->view.barcode_seq_hi = m->seq_hi.empty() ? nullptr : m->seq_hi.data();
     m->view.indptr = m->indptr.data();
     m->view.indices = m->indices.data();
     m->view.data = m->data.data();
@@ -164,6 +177,7 @@ extern "C" int crgpu_concat_matrices(crgpu_ctx *ctx, const crgpu_matrix *const *
         const int64_t shift = (int64_t)m->data.size();
         m->rank.insert(m->rank.end(), a.barcode_rank, a.barcode_rank + a.n_barcodes);
         m->seq.insert(m->seq.end(), a.barcode_seq, a.barcode_seq + a.n_barcodes);
+        if (a.barcode_seq_hi) m->seq_hi.insert(m->seq_hi.end(), a.barcode_seq_hi, a.barcode_seq_hi + a.n_barcodes);
         m->gem_group.insert(m->gem_group.end(), a.n_barcodes, gem_groups[i]);
         for (uint64_t c = 0; c < a.n_barcodes; c++) m->indptr.push_back(shift + a.indptr[c + 1]);
         m->indices.insert(m->indices.end(), a.indices, a.indices + a.nnz);
@@ -175,6 +189,7 @@ extern "C" int crgpu_concat_matrices(crgpu_ctx *ctx, const crgpu_matrix *const *
     m->view.cb_len = mats[0]->cb_len;
     m->view.barcode_rank = m->rank.data();
     m->view.barcode_seq = m->seq.data();
+    m->view.barcode_seq_hi = m->seq_hi.empty() ? nullptr : m->seq_hi.data();
     m->view.indptr = m->indptr.data();
     m->view.indices = m->indices.data();
     m->view.data = m->data.data();
@@ -190,6 +205,7 @@ static void finish_view(MatrixImpl *m, uint32_t n_features, uint32_t cb_len) {
     m->view.cb_len = cb_len;
     m->view.barcode_rank = m->rank.data();
     m->view.barcode_seq = m->seq.data();
+    m->view.barcode_seq_hi = m->seq_hi.empty() ? nullptr : m->seq_hi.data();
     m->view.indptr = m->indptr.data();
     m->view.indices = m->indices.data();
     m->view.data = m->data.data();
@@ -207,12 +223,15 @@ extern "C" int crgpu_sum_matrices(crgpu_ctx *ctx, const crgpu_matrix *a, const c
                "crgpu_sum_matrices: shapes differ (%u x %llu vs %u x %llu)", a->n_features, (unsigned long long)a->n_barcodes,
                b->n_features, (unsigned long long)b->n_barcodes);
     for (uint64_t c = 0; c < a->n_barcodes; c++)
-        CR_REQUIRE(ctx, a->barcode_seq[c] == b->barcode_seq[c] && (a->gem_group ? a->gem_group[c] : 0) == (b->gem_group ? b->gem_group[c] : 0),
+        CR_REQUIRE(ctx, a->barcode_seq[c] == b->barcode_seq[c] &&
+                            (a->barcode_seq_hi ? a->barcode_seq_hi[c] : 0) == (b->barcode_seq_hi ? b->barcode_seq_hi[c] : 0) &&
+                            (a->gem_group ? a->gem_group[c] : 0) == (b->gem_group ? b->gem_group[c] : 0),
                    CRGPU_EINVAL, "crgpu_sum_matrices: column %llu holds different barcodes", (unsigned long long)c);
     MatrixImpl *m = new (std::nothrow) MatrixImpl();
     if (!m) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
     m->rank.assign(a->barcode_rank, a->barcode_rank + a->n_barcodes);
     m->seq.assign(a->barcode_seq, a->barcode_seq + a->n_barcodes);
+    if (a->barcode_seq_hi) m->seq_hi.assign(a->barcode_seq_hi, a->barcode_seq_hi + a->n_barcodes);
     if (a->gem_group) m->gem_group.assign(a->gem_group, a->gem_group + a->n_barcodes);
     m->indptr.push_back(0);
     for (uint64_t c = 0; c < a->n_barcodes; c++) {
@@ -257,6 +276,7 @@ extern "C" int crgpu_select_barcodes(crgpu_ctx *ctx, const crgpu_matrix *a, cons
         const uint64_t c = cols[k];
         m->rank.push_back(a->barcode_rank[c]);
         m->seq.push_back(a->barcode_seq[c]);
+        if (a->barcode_seq_hi) m->seq_hi.push_back(a->barcode_seq_hi[c]);
         if (a->gem_group) m->gem_group.push_back(a->gem_group[c]);
         m->indices.insert(m->indices.end(), a->indices + a->indptr[c], a->indices + a->indptr[c + 1]);
         m->data.insert(m->data.end(), a->data + a->indptr[c], a->data + a->indptr[c + 1]);
@@ -291,11 +311,9 @@ extern "C" int crgpu_write_mtx(crgpu_ctx *ctx, const crgpu_matrix *m, const char
     if (barcodes_tsv_path) {
         FILE *f = fopen(barcodes_tsv_path, "wb");
         if (!f) return cr_fail(ctx, CRGPU_EINVAL, "cannot open %s", barcodes_tsv_path);
-        static const char acgt[4] = {'A', 'C', 'G', 'T'};
-        char buf[32];
+        char buf[40];
         for (uint64_t c = 0; c < m->n_barcodes; c++) {
-            for (uint32_t p = 0; p < m->cb_len; p++) buf[p] = acgt[(m->barcode_seq[c] >> (2 * (m->cb_len - 1 - p))) & 3u];
-            buf[m->cb_len] = 0;
+            format_barcode(buf, m->barcode_seq[c], m->barcode_seq_hi ? m->barcode_seq_hi[c] : 0u, m->cb_len);
             fprintf(f, "%s-%u\n", buf, (unsigned)(m->gem_group ? m->gem_group[c] : gem_group));  // Barcode Display: "{content}-{gem_group}" (barcode/src/lib.rs:197-201)
         }
         fclose(f);
@@ -359,16 +377,15 @@ extern "C" int crgpu_write_barcode_summary_csv(crgpu_ctx *ctx, const crgpu_barco
     FILE *f = fopen(path, "wb");
     if (!f) return cr_fail(ctx, CRGPU_EINVAL, "cannot open %s", path);
     fprintf(f, "library_type,barcode,reads,umis,candidate_dup_reads,umi_corrected_reads\n");
-    static const char acgt[4] = {'A', 'C', 'G', 'T'};
-    char buf[32];
+    char buf[40];
     for (size_t i = 0; i < merged.size();) {
         Row acc = merged[i];
         size_t j = i + 1;
         for (; j < merged.size() && merged[j].order == acc.order && merged[j].rank == acc.rank; j++)
             for (int k = 0; k < 4; k++) acc.v[k] += merged[j].v[k];
-        const uint32_t seq = ctx->canon_sorted[acc.rank];
-        for (uint32_t p = 0; p < ctx->cb_len; p++) buf[p] = acgt[(seq >> (2 * (ctx->cb_len - 1 - p))) & 3u];
-        buf[ctx->cb_len] = 0;
+        uint32_t lo, hi;
+        cr_rank_to_seq(ctx, acc.rank, &lo, &hi);
+        format_barcode(buf, lo, hi, ctx->cb_len);
         fprintf(f, "%s,%s-%u,%llu,%llu,%llu,%llu\n", library_type_name[acc.lib], buf, (unsigned)gem_group,
                 (unsigned long long)acc.v[0], (unsigned long long)acc.v[1], (unsigned long long)acc.v[2],
                 (unsigned long long)acc.v[3]);

@@ -174,6 +174,82 @@ extern "C" int crgpu_set_whitelist(crgpu_ctx *ctx, int lib, const char *keys, ui
     return crgpu_set_whitelist_packed(ctx, lib, pk.data(), n, len, pc.data(), n_canon, translate_to);
 }
 
+void cr_rank_to_seq(const crgpu_ctx *ctx, uint32_t rank, uint32_t *lo, uint32_t *hi) {
+    if (ctx->n_segments == 0) {
+        *lo = ctx->canon_sorted[rank];
+        *hi = 0;
+        return;
+    }
+    // mixed radix, first segment most significant -> the concatenated sequence as up to 64 bits
+    uint32_t r[CRGPU_MAX_SEGMENTS];
+    for (int s = (int)ctx->n_segments - 1; s >= 0; s--) {
+        r[s] = rank % ctx->seg_n[s];
+        rank /= ctx->seg_n[s];
+    }
+    uint64_t full = 0;
+    for (uint32_t s = 0; s < ctx->n_segments; s++) full = (full << (2 * ctx->seg_len[s])) | ctx->seg_seq[s][r[s]];
+    if (ctx->cb_len <= 16) {
+        *lo = (uint32_t)full;
+        *hi = 0;
+    } else {
+        const uint32_t n_hi = ctx->cb_len - 16;
+        *lo = (uint32_t)(full >> (2 * n_hi));
+        *hi = (uint32_t)(full & ((1ull << (2 * n_hi)) - 1ull));
+    }
+}
+
+extern "C" int crgpu_set_barcode_segments(crgpu_ctx *ctx, int lib, uint32_t n_segments, const uint32_t *seg_n,
+                                          const uint32_t *seg_len, const uint32_t *const *seg_seqs) {
+    if (!ctx) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, lib >= 0 && lib < CRGPU_MAX_LIB, CRGPU_EINVAL, "library id %d out of range", lib);
+    CR_REQUIRE(ctx, n_segments >= 1 && n_segments <= CRGPU_MAX_SEGMENTS && seg_n && seg_len && seg_seqs, CRGPU_EINVAL,
+               "crgpu_set_barcode_segments: 1..%d segments", CRGPU_MAX_SEGMENTS);
+    uint64_t space = 1;
+    uint32_t total_len = 0;
+    for (uint32_t s = 0; s < n_segments; s++) {
+        CR_REQUIRE(ctx, seg_n[s] > 0 && seg_seqs[s] && seg_len[s] >= 1 && seg_len[s] <= 16, CRGPU_EINVAL,
+                   "segment %u: empty whitelist or more than 16 bases", s);
+        const uint64_t lim = seg_len[s] == 16 ? (1ull << 32) : (1ull << (2 * seg_len[s]));
+        for (uint32_t i = 0; i < seg_n[s]; i++) {
+            CR_REQUIRE(ctx, seg_seqs[s][i] < lim, CRGPU_EINVAL, "segment %u: sequence %u does not fit %u bases", s, i, seg_len[s]);
+            CR_REQUIRE(ctx, i == 0 || seg_seqs[s][i] > seg_seqs[s][i - 1], CRGPU_EINVAL,
+                       "segment %u: the sequences must be ascending and distinct (a segment context's canonical order)", s);
+        }
+        space *= seg_n[s];
+        total_len += seg_len[s];
+        CR_REQUIRE(ctx, space < (1ull << 31), CRGPU_ERANGE, "the product of the segment whitelists exceeds 2^31 barcodes");
+    }
+    CR_REQUIRE(ctx, total_len <= 32, CRGPU_ERANGE, "segmented barcodes of %u bases unsupported (<= 32)", total_len);
+    if (ctx->canon_set) {
+        bool same = ctx->n_segments == n_segments && ctx->n_canon == (uint32_t)space;
+        for (uint32_t s = 0; same && s < n_segments; s++)
+            same = ctx->seg_n[s] == seg_n[s] && ctx->seg_len[s] == seg_len[s] &&
+                   std::equal(ctx->seg_seq[s].begin(), ctx->seg_seq[s].end(), seg_seqs[s]);
+        CR_REQUIRE(ctx, same, CRGPU_EINVAL, "all libraries of a context must share one canonical barcode space");
+    } else {
+        ctx->n_segments = n_segments;
+        for (uint32_t s = 0; s < n_segments; s++) {
+            ctx->seg_n[s] = seg_n[s];
+            ctx->seg_len[s] = seg_len[s];
+            ctx->seg_seq[s].assign(seg_seqs[s], seg_seqs[s] + seg_n[s]);
+        }
+        ctx->n_canon = (uint32_t)space;
+        ctx->cb_len = total_len;
+        ctx->canon_set = true;
+    }
+    CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    cr_drop_miss_records(ctx);
+    WlTables &w = ctx->wl[lib];
+    cr_free_wl(w);
+    std::vector<uint32_t> zeros(ctx->n_canon, 0);
+    CR_TRY(upload(ctx, &w.d_valid, zeros));
+    CR_TRY(upload(ctx, &w.d_corrected, zeros));
+    w.n = 0;  // no lookup tables: the barcode stage runs on the segment contexts
+    w.set = true;
+    return CRGPU_OK;
+}
+
 extern "C" int crgpu_whitelist_info(crgpu_ctx *ctx, uint32_t *n_canon_out, uint32_t *len_out) {
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
@@ -187,6 +263,7 @@ extern "C" int crgpu_get_canon_order(crgpu_ctx *ctx, uint32_t *order_out, uint32
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     CR_REQUIRE(ctx, ctx->canon_set, CRGPU_ESTATE, "no whitelist set");
+    CR_REQUIRE(ctx, ctx->n_segments == 0, CRGPU_ESTATE, "a segmented barcode space has no sequence list: ranks are mixed radix");
     if (order_out) memcpy(order_out, ctx->canon_order.data(), sizeof(uint32_t) * ctx->n_canon);
     if (seqs_out) memcpy(seqs_out, ctx->canon_sorted.data(), sizeof(uint32_t) * ctx->n_canon);
     return CRGPU_OK;

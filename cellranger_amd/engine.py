@@ -144,9 +144,13 @@ class Matrix:
         self.indices = arr(m.indices, np.int32, self.nnz)
         self.data = arr(m.data, np.int32, self.nnz)
         self.gem_group = arr(m.gem_group, np.uint16, self.n_barcodes) if m.gem_group else None
+        # barcodes longer than 16 bases (segmented constructs): barcode_seq = the first 16 bases, barcode_seq_hi = the rest
+        self.barcode_seq_hi = arr(m.barcode_seq_hi, np.uint32, self.n_barcodes) if m.barcode_seq_hi else None
 
     def barcodes_ascii(self):
-        return unpack_seqs(self.barcode_seq, self.cb_len)
+        if self.barcode_seq_hi is None:
+            return unpack_seqs(self.barcode_seq, self.cb_len)
+        return np.concatenate([unpack_seqs(self.barcode_seq, 16), unpack_seqs(self.barcode_seq_hi, self.cb_len - 16)], axis=1)
 
     def write_mtx(self, mtx_path, barcodes_path=None, metadata_line='%metadata_json: {"format_version": 2}',
                   gem_group=1):
@@ -668,6 +672,21 @@ class Context:
 
     def match_features(self, pattern, d_seq, d_qualn, n, d_feature_out):
         self._check(self.L.crgpu_match_features_dev(self.h, pattern, _p(d_seq), _p(d_qualn), n, _p(d_feature_out)))
+
+    # ---- segmented barcode constructs (GelBeadAndProbe) ---------------------------------------------------
+    def set_barcode_segments(self, lib, seg_seqs, seg_lens):
+        """seg_seqs: per segment the packed sequences, ascending (a segment context's canonical list)"""
+        k = len(seg_seqs)
+        keep = [np.ascontiguousarray(a, dtype=np.uint32) for a in seg_seqs]
+        n = (C.c_uint32 * k)(*[len(a) for a in keep])
+        ln = (C.c_uint32 * k)(*seg_lens)
+        pp = (C.c_void_p * k)(*[a.ctypes.data for a in keep])
+        self._check(self.L.crgpu_set_barcode_segments(self.h, lib, k, n, ln, pp))
+        self.cb_len, self.n_canon = int(sum(seg_lens)), int(np.prod([len(a) for a in keep], dtype=np.int64))
+
+    def combine_segments(self, lib, d_seg_idx, n, d_idx_inout, after_correction=False):
+        pp = (C.c_void_p * len(d_seg_idx))(*[_p(a) for a in d_seg_idx])
+        self._check(self.L.crgpu_combine_segments_dev(self.h, lib, pp, len(d_seg_idx), n, int(after_correction), _p(d_idx_inout)))
 
     # whole reads, every pattern form (FeatureExtractor::match_read)
     def set_feature_extractor(self, extractor, defs, feat_dist=None):

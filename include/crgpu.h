@@ -151,6 +151,33 @@ int crgpu_whitelist_info(crgpu_ctx *ctx, uint32_t *n_canon_out, uint32_t *len_ou
  * Either may be NULL.  n_canon entries each. */
 int crgpu_get_canon_order(crgpu_ctx *ctx, uint32_t *order_out, uint32_t *seqs_out);
 
+/* ---- segmented barcodes: GelBeadAndProbe and friends -------------------------------------------------------------
+ * A barcode construct of several segments (BarcodeConstruct, e.g. gel bead 16 + probe 8 bases) is corrected segment by
+ * segment, each against its own whitelist with its own prior (correct_barcode_in_read, BarcodeExtraction::Independent:
+ * cr_lib/src/stages/barcode_correction.rs:85-99; the priors are MAKE_SHARD's valid_bc_segment_counts,
+ * make_shard_metrics.rs:176-190), and the read's barcode is valid when every segment is.  Here: ONE CONTEXT PER SEGMENT
+ * runs the barcode stage on that segment's bases (crgpu_pack_rows_dev with the segment's offset, crgpu_match_and_count_dev,
+ * crgpu_correct_dev: its VALID table is that segment's valid_bc_segment_counts), and a COUNTING CONTEXT whose canonical
+ * space is the product of the segments' whitelists takes the combined ranks:
+ *   crgpu_set_barcode_segments  seg_seqs[s] = seg_n[s] packed sequences of seg_len[s] (<= 16) bases, ascending -- the
+ *                               canonical lists of the segment contexts (crgpu_get_canon_order's seqs_out).  The space
+ *                               has prod(seg_n) ranks (< 2^31): rank = (r0 * n1 + r1) * n2 + ..., which is the order of the
+ *                               concatenated sequences (barcode/src/lib.rs:119-124).  Replaces crgpu_set_whitelist on
+ *                               this context; `lib` gets VALID / CORRECTED tables over the product space.
+ *   crgpu_combine_segments_dev  d_seg_idx[s] (host array of device pointers) = the segment contexts' idx arrays.
+ *       after_correction == 0   d_idx_inout[i] = combined rank when every segment matched, else CRGPU_MISS; the
+ *                               matched reads are counted into VALID (MakeShardHistograms::valid_bc_counts, :172-174)
+ *       after_correction != 0   reads whose d_idx_inout[i] is CRGPU_MISS and whose segments are all valid now get their
+ *                               combined rank and are counted into CORRECTED (corrected_barcode_counts,
+ *                               barcode_correction.rs:401-407)
+ * The count stage, matrices, summaries and collectives then work on this context as on any other; a matrix reports a
+ * barcode as two words (crgpu_matrix::barcode_seq = the first 16 bases, barcode_seq_hi = the rest). */
+#define CRGPU_MAX_SEGMENTS 4
+int crgpu_set_barcode_segments(crgpu_ctx *ctx, int lib, uint32_t n_segments, const uint32_t *seg_n, const uint32_t *seg_len,
+                               const uint32_t *const *seg_seqs);
+int crgpu_combine_segments_dev(crgpu_ctx *ctx, int lib, const uint32_t *const *d_seg_idx, uint32_t n_segments, uint64_t n,
+                               int after_correction, uint32_t *d_idx_inout);
+
 /* ---- packing (ASCII -> 2-bit + N-flagged quality) ----------------------------------------------
  * Device-side part of RnaProcessor::process_read's slicing (cr_types/src/rna_read.rs:103-138,
  * 352-366): seq/qual are n x len ASCII (device).  packed_out n x u32, qualn_out n x len bytes,
@@ -459,6 +486,7 @@ typedef struct {
     const int32_t *indices;        /* nnz  (written as int64 on disk, count_matrix.rs:399) */
     const int32_t *data;           /* nnz */
     const uint16_t *gem_group;     /* V gem groups of a merged matrix (crgpu_concat_matrices), else NULL */
+    const uint32_t *barcode_seq_hi; /* V: bases 17.. of barcodes longer than 16 bases (segmented constructs), else NULL */
 } crgpu_matrix;
 /* triplets may come from several ranks (concatenated in any order of disjoint barcodes; they are
  * re-sorted by barcode here).  Host arrays. */

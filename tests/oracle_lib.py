@@ -316,7 +316,7 @@ def last_timing():
 
 
 def run_pipeline(reads, whitelists, n_lib=1, multiplexing_lib_mask=0, n_threads=1,
-                 max_expected_errors=DBL_MAX, threshold=0.975, count=True, want_dupinfo=False):
+                 max_expected_errors=DBL_MAX, threshold=0.975, count=True, want_dupinfo=False, bc_override=None):
     """reads: dict with cb (n,L) u8, cb_qual (n,L) u8, optional umi/umi_qual/feature/lib/utype.
     whitelists: list indexed by library id of tests.oracle_lib.Whitelist (or None)."""
     cb = np.ascontiguousarray(reads["cb"], dtype=np.uint8)
@@ -358,9 +358,19 @@ def run_pipeline(reads, whitelists, n_lib=1, multiplexing_lib_mask=0, n_threads=
     out.bc_state = np.zeros(n, dtype=np.uint8)
     B = BcResult()
     B.corrected_cb, B.bc_state = _ptr(out.corrected_cb), _ptr(out.bc_state)
-    rc = lib().oracle_barcode_stage(C.byref(R), wl_arr, v_arr, c_arr, None, max_expected_errors, threshold,
-                                    n_threads, C.byref(B))
-    assert rc == 0
+    if bc_override is None:
+        rc = lib().oracle_barcode_stage(C.byref(R), wl_arr, v_arr, c_arr, None, max_expected_errors, threshold,
+                                        n_threads, C.byref(B))
+        assert rc == 0
+    else:
+        # barcodes made elsewhere (a segmented construct corrected segment by segment): final content, validity and the
+        # whole-barcode histograms of library 0 are given; only the count stage runs
+        ccb, state, vh, ch = bc_override
+        out.corrected_cb[:] = ccb
+        out.bc_state[:] = state
+        valid[0], corr[0] = vh, ch
+        v_arr = (C.c_void_p * MAX_LIB)(*[h.h for h in valid])
+        c_arr = (C.c_void_p * MAX_LIB)(*[h.h for h in corr])
     out.valid_hist, out.corrected_hist = valid, corr
     if count and umi is not None:
         dup = np.zeros(n, dtype=DUPINFO_DTYPE) if want_dupinfo else None

@@ -1,0 +1,161 @@
+"""Segmented barcode constructs (GelBeadAndProbe: gel bead 16 + probe 8 bases): every segment is corrected against its own
+whitelist with its own prior (correct_barcode_in_read / BarcodeExtraction::Independent, barcode_correction.rs:85-99) on its own
+context; a counting context over the product space takes the combined ranks.  Checked read by read and array by array
+against the oracle: its barcode stage once per segment, its count stage on the concatenated 24-base barcodes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MISS = 0xFFFFFFFF
+
+
+def _mutate(rng, seqs, p_sub, p_n):
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    s = seqs.copy()
+    n, L = s.shape
+    sub = rng.random(n) < p_sub
+    pos = rng.integers(0, L, n)
+    s[sub, pos[sub]] = acgt[rng.integers(0, 4, int(sub.sum()))]
+    two = rng.random(n) < p_sub / 4
+    for _ in range(2):
+        pos = rng.integers(0, L, n)
+        s[two, pos[two]] = acgt[rng.integers(0, 4, int(two.sum()))]
+    nn = rng.random(n) < p_n
+    pos = rng.integers(0, L, n)
+    s[nn, pos[nn]] = ord("N")
+    return s
+
+
+def _segment_stage(c, rows_s, rows_q, n, stride, offset, length):
+    """pack + K1 + K2 of one segment on its own context -> (idx after match, idx after correction, device idx, flags)"""
+    d_rs, d_rq = c.upload(rows_s), c.upload(rows_q)
+    d_pk, d_qn, d_fl = c.empty(n, np.uint32), c.empty((n, length), np.uint8), c.zeros(n, np.uint8)
+    c.pack_rows(d_rs, d_rq, n, stride, offset, length, d_pk, d_qn, d_fl)
+    d_idx = c.empty(n, np.uint32)
+    c.match_and_count(d_pk, d_fl, n, d_idx)
+    d_idx_a = c.empty(n, np.uint32)
+    d_idx_a.upload(d_idx.to_host())
+    c.correct(d_pk, d_qn, d_fl, n, d_idx)
+    c.synchronize()
+    return d_idx_a, d_idx, d_fl
+
+
+@pytest.mark.parametrize("n_probe,seed", [(16, 1), (3, 2)])
+def test_gel_bead_and_probe_construct_matches_the_oracle(n_probe, seed, tmp_path):
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    LA, LB, LU = 16, 8, 12
+    n_gb, n_feat, n = 3000, 60, 80_000
+    wl_a = np.unique(rng.integers(0, 1 << 32, n_gb * 2, dtype=np.uint64).astype(np.uint32))[:n_gb]
+    wl_b = np.unique(rng.integers(0, 1 << 16, n_probe * 8, dtype=np.uint64).astype(np.uint32))
+    wl_b = np.sort(rng.permutation(wl_b)[:n_probe])
+    a_ascii, b_ascii = E.unpack_seqs(wl_a, LA), E.unpack_seqs(wl_b, LB)
+    # 400 cells x probes; reads: cell (Zipf-ish), probe, gene, UMI from a small pool per (cell, gene) so that duplicates,
+    # one-mismatch UMIs and UMIs shared between genes all occur
+    cells = rng.integers(0, n_gb, 400)
+    cell = cells[np.minimum(rng.zipf(1.3, n) - 1, 399)]
+    probe = rng.integers(0, n_probe, n)
+    gene = np.minimum(rng.zipf(1.5, n) - 1, n_feat - 1).astype(np.uint32)
+    gene[rng.random(n) < 0.03] = MISS  # no feature
+    pool = rng.integers(0, 1 << 24, 64, dtype=np.uint64).astype(np.uint32)
+    umi_pk = pool[rng.integers(0, 64, n)] ^ ((cell.astype(np.uint32) * 2654435761) & 0xFFF000).astype(np.uint32)
+    flip = rng.random(n) < 0.05
+    umi_pk[flip] ^= (np.uint32(1) << (2 * rng.integers(0, LU, int(flip.sum())).astype(np.uint32)))
+    umi_ascii = E.unpack_seqs(umi_pk, LU)
+    umi_ascii[rng.random(n) < 0.01, 3] = ord("N")
+    seg_a = _mutate(rng, a_ascii[cell], 0.08, 0.01)
+    seg_b = _mutate(rng, b_ascii[probe], 0.08, 0.01)
+    stride = LA + LU + LB  # one row per read: [gel bead 16][UMI 12][probe barcode 8]
+    rows_s = np.hstack([seg_a, umi_ascii, seg_b])
+    rows_q = rng.integers(35, 74, (n, stride)).astype(np.uint8)
+    rows_q[rng.random((n, stride)) < 0.03] = 33 + 2
+
+    # ---- GPU: one context per segment, one for counting ----------------------------------------------------
+    ca, cb, cc = G.fresh_ctx(), G.fresh_ctx(), G.fresh_ctx()
+    ca.set_whitelist(0, wl_a, length=LA)
+    cb.set_whitelist(0, wl_b, length=LB)
+    _, a_sorted = ca.canon_order()
+    _, b_sorted = cb.canon_order()
+    cc.set_barcode_segments(0, [a_sorted, b_sorted], [LA, LB])
+    with pytest.raises(E.CrgpuError, match="segment contexts"):
+        cc.match_and_count(cc.empty(4, np.uint32), None, 4, cc.empty(4, np.uint32))
+    with pytest.raises(E.CrgpuError):
+        cc.set_barcode_segments(0, [a_sorted[::-1].copy(), b_sorted], [LA, LB])  # not ascending
+    da_a, da, dfl = _segment_stage(ca, rows_s, rows_q, n, stride, 0, LA)
+    db_a, db, _ = _segment_stage(cb, rows_s, rows_q, n, stride, LA + LU, LB)
+    d_idx = cc.empty(n, np.uint32)
+    cc.combine_segments(0, [da_a, db_a], n, d_idx)                         # after the exact match: VALID
+    idx_a = d_idx.to_host()
+    cc.combine_segments(0, [da, db], n, d_idx, after_correction=True)      # after correction: CORRECTED
+    idx_b = d_idx.to_host()
+    # count stage on the counting context
+    d_rs, d_rq = cc.upload(rows_s), cc.upload(rows_q)
+    d_um, d_uq = cc.empty(n, np.uint32), cc.empty((n, LU), np.uint8)
+    cc.pack_rows(d_rs, d_rq, n, stride, LA, LU, d_um, d_uq)
+    d_ft, d_fl = cc.upload(gene), cc.zeros(n, np.uint8)
+    cc.set_key_layout(n_feat, LU, 1, 0)
+    recs = cc.records(n, LU, d_idx, d_um, d_uq, d_ft, d_fl)
+    d_pu, d_rc, d_df = cc.empty(n, np.uint32), cc.empty(n, np.uint32), cc.empty(n, np.uint8)
+    counts = cc.count_records(recs, d_pu, d_rc, d_df)
+    bc, ft, ct = counts.triplets()
+    m = cc.assemble_matrix(bc, ft, ct, n_feat)
+    mol = counts.molecules()
+
+    # ---- oracle: the barcode stage per segment, the count stage on the concatenated barcodes ---------------------
+    def seg_oracle(seqs, quals, wl_ascii):
+        return O.run_pipeline(dict(cb=seqs, cb_qual=quals), [O.Whitelist(wl_ascii)], count=False)
+
+    ra = seg_oracle(seg_a, rows_q[:, :LA], a_ascii)
+    rb = seg_oracle(seg_b, rows_q[:, LA + LU:], b_ascii)
+    # per-segment results agree with the segment contexts (their VALID tables are valid_bc_segment_counts, the priors)
+    exp_a, exp_b = G.oracle_expected_idx(ra, a_sorted)
+    assert np.array_equal(da_a.to_host(), exp_a) and np.array_equal(da.to_host(), exp_b)
+    exp_a2, exp_b2 = G.oracle_expected_idx(rb, b_sorted)
+    assert np.array_equal(db_a.to_host(), exp_a2) and np.array_equal(db.to_host(), exp_b2)
+    valid_before = (ra.bc_state == 1) & (rb.bc_state == 1)
+    valid_after = (ra.bc_state > 0) & (rb.bc_state > 0)
+    assert valid_after.sum() > valid_before.sum() > n // 2
+    full = np.hstack([ra.corrected_cb, rb.corrected_cb])
+    want = np.full(n, MISS, np.uint32)
+    want[valid_after] = exp_b[valid_after] * np.uint32(n_probe) + exp_b2[valid_after]
+    assert np.array_equal(idx_b, want)
+    assert np.array_equal(idx_a, np.where(valid_before, want, MISS))
+    # whole-barcode histograms (MakeShardHistograms::valid_bc_counts; corrected_barcode_counts)
+    vh, ch = O.Hist(), O.Hist()
+    for i in np.nonzero(valid_after)[0]:
+        (vh if valid_before[i] else ch).observe_by(bytes(full[i]))
+    tab_v, tab_c = cc.get_counts(0, 0), cc.get_counts(0, 1)
+    assert tab_v.sum() == valid_before.sum() and tab_c.sum() == valid_after.sum() - valid_before.sum()
+    assert np.array_equal(np.bincount(want[valid_before], minlength=len(tab_v)), tab_v)
+    reads = dict(cb=np.hstack([seg_a, seg_b]), cb_qual=np.hstack([rows_q[:, :LA], rows_q[:, LA + LU:]]), umi=umi_ascii,
+                 umi_qual=rows_q[:, LA:LA + LU], feature=gene)
+    res = O.run_pipeline(reads, [None], n_threads=4, want_dupinfo=True,
+                         bc_override=(full, valid_after.astype(np.uint8), vh, ch))
+    # the matrix: 24-base barcodes as two words, columns, entries
+    assert m.cb_len == 24 and m.barcode_seq_hi is not None
+    assert np.array_equal(m.barcodes_ascii(), res.barcodes)
+    assert np.array_equal(m.indptr, res.indptr) and np.array_equal(m.indices, res.indices) and np.array_equal(m.data, res.data)
+    assert m.nnz > 1000
+    # per-read DupInfo and the molecule table
+    od = res.dupinfo
+    fl = d_df.to_host()
+    has = od["has_dupinfo"] != 0
+    assert np.array_equal((fl & 1) != 0, has)
+    for bit, name in ((2, "is_corrected"), (4, "is_low_support"), (8, "is_umi_count")):
+        assert np.array_equal((fl & bit) != 0, od[name] != 0), name
+    assert np.array_equal(d_pu.to_host()[has], od["processed_umi"][has])
+    assert np.array_equal(d_rc.to_host()[has], od["read_count"][has])
+    assert np.array_equal(mol["feature"], res.mol["feature_idx"]) and np.array_equal(mol["umi"], res.mol["umi"])
+    assert np.array_equal(mol["read_count"], res.mol["read_count"])
+    assert np.array_equal(m.barcode_rank[res.mol_bc_col], mol["bc"])
+    # barcodes.tsv holds the 24-base sequences
+    p = tmp_path / "barcodes.tsv"
+    m.write_mtx(None, p)
+    lines = p.read_text().split()
+    assert lines == [bytes(b).decode() + "-1" for b in res.barcodes]
+    for c in (ca, cb, cc):
+        c.close()
