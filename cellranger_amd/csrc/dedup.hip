@@ -668,6 +668,308 @@ struct EmitTriplet {
     __device__ __forceinline__ void operator()(uint64_t i, uint32_t o, Pre) const { tpos[o] = (uint32_t)i; }
 };
 
+// ---- run lengths of the sorted keys (DupBuilder::observe): distinct keys + the start of every run -------------------------
+// The generic compaction evaluates HeadFlag with two loads per key (keys[i], keys[i - 1]) and EmitRun with a third; these
+// passes are bound by load instructions in flight, not by bytes.  With the wave-blocked layout (a wave owns 64 * CP_ITEMS
+// consecutive keys of a round) the left neighbour comes from the lane below or from the previous item slot's lane 63, and
+// only a wave's first key of a round looks at memory: one load per key.
+__device__ __forceinline__ bool rl_is_head(uint64_t key, uint64_t &carry_key, bool &carry_valid, uint32_t shift, uint32_t lane) {
+    uint64_t left = __shfl_up(key, 1);
+    if (lane == 0) left = carry_key;
+    const bool head = (lane == 0 && !carry_valid) || (key >> shift) != (left >> shift);
+    carry_key = __shfl(key, 63);
+    carry_valid = true;
+    return head;
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void k_rl_count(const uint64_t *__restrict__ keys, const uint32_t shift, const uint64_t n,
+                                                       const uint64_t tile, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t ws[CP_WAVES];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = lo + tile < n ? lo + tile : n;
+    uint32_t c = 0;
+    for (uint64_t base = lo; base < hi; base += CP_ROUND) {
+        uint64_t key[CP_ITEMS];
+        const uint64_t w0 = base + (uint64_t)wave * (64u * CP_ITEMS);
+        const uint64_t wb = w0 > 0 ? (w0 - 1 < n ? w0 - 1 : n - 1) : 0;
+        uint64_t carry_key = keys[wb];
+        bool carry_valid = w0 > 0;
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            key[j] = keys[i < hi ? i : hi - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            const bool head = rl_is_head(key[j], carry_key, carry_valid, shift, lane);
+            c += (head && i < hi) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane == 0) ws[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < CP_WAVES; w++) t += ws[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(CP_BLOCK) void k_rl_write(const uint64_t *__restrict__ keys, const uint32_t shift, const uint64_t n,
+                                                       const uint64_t tile, const uint32_t *__restrict__ block_offs,
+                                                       uint64_t *__restrict__ ukey, uint32_t *__restrict__ upos) {
+    __shared__ uint32_t ws[CP_ITEMS * CP_WAVES];  // heads of (wave, item slot), then their exclusive prefix
+    __shared__ uint32_t round_total;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = lo + tile < n ? lo + tile : n;
+    uint32_t run = block_offs[blockIdx.x];
+    for (uint64_t base = lo; base < hi; base += CP_ROUND) {
+        uint64_t key[CP_ITEMS];
+        bool f[CP_ITEMS];
+        uint32_t below[CP_ITEMS];
+        const uint64_t w0 = base + (uint64_t)wave * (64u * CP_ITEMS);
+        const uint64_t wb = w0 > 0 ? (w0 - 1 < n ? w0 - 1 : n - 1) : 0;
+        uint64_t carry_key = keys[wb];
+        bool carry_valid = w0 > 0;
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            key[j] = keys[i < hi ? i : hi - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            f[j] = rl_is_head(key[j], carry_key, carry_valid, shift, lane) && i < hi;
+            const unsigned long long m = __ballot(f[j]);
+            below[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) ws[wave * CP_ITEMS + j] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if (threadIdx.x < CP_ITEMS * CP_WAVES) {  // 32 lanes of wave 0: exclusive scan in (wave, slot) order = key order
+            const uint32_t v = ws[threadIdx.x];
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < CP_ITEMS * CP_WAVES; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (threadIdx.x >= (uint32_t)d) x += y;
+            }
+            ws[threadIdx.x] = x - v;
+            if (threadIdx.x == CP_ITEMS * CP_WAVES - 1) round_total = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++)
+            if (f[j]) {
+                const uint32_t o = run + ws[wave * CP_ITEMS + j] + below[j];
+                ukey[o] = key[j];
+                upos[o] = (uint32_t)(w0 + (uint64_t)j * 64 + lane);
+            }
+        run += round_total;
+        __syncthreads();
+    }
+}
+
+static int run_lengths(crgpu_ctx *ctx, const uint64_t *keys, uint32_t shift, uint64_t n, uint64_t *ukey, uint32_t *upos,
+                       uint32_t *d_block, uint32_t *d_total_out) {
+    uint64_t tile;
+    const uint32_t nb = cp_blocks(n, &tile);
+    hipLaunchKernelGGL(k_rl_count, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, keys, shift, n, tile, d_block);
+    CR_TRY(cr_scan_small(ctx, d_block, nb, d_total_out));
+    hipLaunchKernelGGL(k_rl_write, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, keys, shift, n, tile, d_block, ukey, upos);
+    CR_HIP(ctx, hipGetLastError());
+    return CRGPU_OK;
+}
+
+// ---- molecules and (barcode, feature) triplets from the same two launches over the distinct keys ---------------------
+// The molecule compaction (count + write over st / ukey / upos) was followed by a second compaction over the molecule keys
+// just to find the first molecule of every (barcode, feature) and by k_triplets: two more reads of the 3.2 GB molecule table
+// per 1 B records.  Here the count launch counts molecules AND the molecules that open a triplet, and the write launch
+// emits both (block offsets from two small scans), so both outputs keep the key order.  A molecule opens a triplet when no
+// earlier molecule shares its (barcode, feature): inside a wave that is ballot arithmetic on the lanes' own keys, from one
+// item slot to the next a wave-uniform carry in registers, and for a wave's first slot of a round one walk back over the
+// distinct keys that yield no molecule (corrected away / low support), rarely more than one step.
+// (A single launch with tickets and a decoupled look-back carrying both counts in one status word was measured first: with
+// 2048-key chunks +2.5 ms, with 4096-key chunks of one 1024-thread workgroup per CU equal to the separate passes -- the
+// same-address ticket atomics and one look-back per chunk cost what the saved reads gain; A/B in profiles/r02_mol_trip_ab.txt.)
+// Wave-blocked layout: in a round a wave owns 64 * CP_ITEMS consecutive keys and item slot j is the j-th run of 64 of them,
+// so what lies in front of slot j > 0 is slot j - 1 of the same wave (registers) and only slot 0 looks at memory.
+struct MtCarry {       // wave-uniform: the run of equal (barcode, feature) that ends in front of the current slot
+    uint64_t prefix;   // its prefix
+    bool has_mol;      // it holds a molecule
+    bool valid;        // there is something in front at all
+};
+
+// what lies in front of a wave's first slot of a round: the key before i0 and, if it yields no molecule, the keys before it
+template <typename Flag>
+__device__ __forceinline__ MtCarry mt_carry_from_memory(const Flag &flag, const uint64_t *__restrict__ ukey, uint32_t sh_feat,
+                                                        uint64_t nd, uint64_t i0) {
+    MtCarry c{0ull, false, false};
+    if (i0 == 0 || i0 >= nd) return c;
+    c.valid = true;
+    uint64_t p = i0 - 1;
+    c.prefix = ukey[p] >> sh_feat;
+    c.has_mol = flag(p);
+    while (!c.has_mol && p > 0) {
+        p--;
+        if ((ukey[p] >> sh_feat) != c.prefix) break;
+        c.has_mol = flag(p);
+    }
+    return c;
+}
+
+// does this lane's molecule open a triplet?  Updates the carry to describe the run that ends with lane 63.
+__device__ __forceinline__ bool mt_opens_triplet(bool is_mol, uint64_t key, uint32_t sh_feat, uint32_t lane, MtCarry &carry) {
+    const uint64_t prefix = key >> sh_feat;
+    const uint64_t left = __shfl_up(prefix, 1);
+    const unsigned long long starts = __ballot(lane == 0 || prefix != left), mols = __ballot(is_mol);
+    const unsigned long long upto = ~0ull >> (63u - lane);                       // lanes 0 .. lane
+    const uint32_t rs = 63u - (uint32_t)__clzll((long long)(starts & upto));     // first lane of this lane's run
+    const unsigned long long between = (upto >> 1) & ~((1ull << rs) - 1ull);     // lanes rs .. lane - 1
+    const uint64_t prefix0 = __shfl(prefix, 0);
+    const bool carried = carry.valid && carry.prefix == prefix0 && carry.has_mol;  // a molecule of lane 0's run lies in front
+    const bool open = (mols & between) == 0ull && !(rs == 0u && carried);
+    // the run that ends with lane 63
+    const uint32_t rs_last = 63u - (uint32_t)__clzll((long long)starts);
+    const bool last_has = (mols >> rs_last) != 0ull || (rs_last == 0u && carried);
+    carry.prefix = __shfl(prefix, 63);
+    carry.has_mol = last_has;
+    carry.valid = true;
+    return is_mol && open;
+}
+
+#define MT_WAVE_SPAN (64u * CP_ITEMS)
+template <typename Flag>
+__global__ __launch_bounds__(CP_BLOCK) void k_mt_count(const Flag flag, const uint64_t *__restrict__ ukey, const uint32_t sh_feat,
+                                                       const uint64_t nd, const uint64_t tile, uint32_t *__restrict__ mol_counts,
+                                                       uint32_t *__restrict__ head_counts) {
+    __shared__ uint32_t ws[2 * CP_WAVES];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = lo + tile < nd ? lo + tile : nd;
+    uint32_t cm = 0, ch = 0;
+    for (uint64_t base = lo; base < hi; base += CP_ROUND) {
+        bool f[CP_ITEMS];
+        uint64_t key[CP_ITEMS];
+        const uint64_t w0 = base + (uint64_t)wave * MT_WAVE_SPAN;
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            const uint64_t ic = i < hi ? i : hi - 1;
+            f[j] = flag(ic);
+            key[j] = ukey[ic];
+        }
+        MtCarry carry = mt_carry_from_memory(flag, ukey, sh_feat, nd, w0);
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            const bool m = f[j] && i < hi;
+            const bool h = mt_opens_triplet(m, key[j], sh_feat, lane, carry);
+            cm += m ? 1u : 0u;
+            ch += h ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cm += __shfl_xor(cm, d);
+        ch += __shfl_xor(ch, d);
+    }
+    if (lane == 0) {
+        ws[wave] = cm;
+        ws[CP_WAVES + wave] = ch;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tm = 0, th = 0;
+        for (int w = 0; w < CP_WAVES; w++) {
+            tm += ws[w];
+            th += ws[CP_WAVES + w];
+        }
+        mol_counts[blockIdx.x] = tm;
+        head_counts[blockIdx.x] = th;
+    }
+}
+
+template <typename Flag>
+__global__ __launch_bounds__(CP_BLOCK) void k_mt_write(const Flag flag, const EmitMol emit, const uint32_t sh_bc, const uint32_t sh_feat,
+                                                       const uint32_t bits_feat, const uint64_t nd, const uint64_t tile,
+                                                       const uint32_t *__restrict__ mol_offs, const uint32_t *__restrict__ head_offs,
+                                                       uint32_t *__restrict__ tbc, uint32_t *__restrict__ tfeat,
+                                                       uint32_t *__restrict__ tpos) {
+    __shared__ uint32_t ws[CP_ITEMS * CP_WAVES];  // (molecules | heads << 16) of (wave, item slot), then their exclusive prefix
+    __shared__ uint32_t round_total;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * tile;
+    const uint64_t hi = lo + tile < nd ? lo + tile : nd;
+    uint32_t run_m = mol_offs[blockIdx.x], run_h = head_offs[blockIdx.x];
+    for (uint64_t base = lo; base < hi; base += CP_ROUND) {
+        bool f[CP_ITEMS], h[CP_ITEMS];
+        EmitMol::Pre pre[CP_ITEMS];
+        const uint64_t w0 = base + (uint64_t)wave * MT_WAVE_SPAN;
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            const uint64_t ic = i < hi ? i : hi - 1;
+            f[j] = flag(ic);
+            pre[j] = emit.pre(ic);
+        }
+        MtCarry carry = mt_carry_from_memory(flag, emit.ukey, sh_feat, nd, w0);
+        uint32_t below_m[CP_ITEMS], below_h[CP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            f[j] = f[j] && i < hi;
+            h[j] = mt_opens_triplet(f[j], pre[j].key, sh_feat, lane, carry);
+            const unsigned long long mm = __ballot(f[j]), mh = __ballot(h[j]);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            below_m[j] = (uint32_t)__popcll(mm & lt);
+            below_h[j] = (uint32_t)__popcll(mh & lt);
+            if (lane == 0) ws[wave * CP_ITEMS + j] = (uint32_t)__popcll(mm) | ((uint32_t)__popcll(mh) << 16);
+        }
+        __syncthreads();
+        if (threadIdx.x < CP_ITEMS * CP_WAVES) {  // 32 lanes of wave 0: exclusive scan in (wave, slot) order = key order
+            const uint32_t v = ws[threadIdx.x];
+            uint32_t x = v;
+#pragma unroll
+            for (int d = 1; d < CP_ITEMS * CP_WAVES; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d);
+                if (threadIdx.x >= (uint32_t)d) x += y;
+            }
+            ws[threadIdx.x] = x - v;
+            if (threadIdx.x == CP_ITEMS * CP_WAVES - 1) round_total = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CP_ITEMS; j++)
+            if (f[j]) {
+                const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+                const uint32_t w = ws[wave * CP_ITEMS + j];
+                const uint32_t o = run_m + (w & 0xFFFFu) + below_m[j];
+                emit(i, o, pre[j]);
+                if (h[j]) {
+                    const uint32_t t = run_h + (w >> 16) + below_h[j];
+                    tbc[t] = (uint32_t)(pre[j].key >> sh_bc);
+                    tfeat[t] = (uint32_t)((pre[j].key >> sh_feat) & lowmask(bits_feat));
+                    tpos[t] = o;
+                }
+            }
+        run_m += round_total & 0xFFFFu;
+        run_h += round_total >> 16;
+        __syncthreads();
+    }
+}
+
+// molecules per triplet = distance to the next triplet's first molecule (types.rs:180-188)
+__global__ __launch_bounds__(256) void k_trip_counts(const uint32_t *__restrict__ tpos, uint64_t nt, uint64_t nm,
+                                                     uint32_t *__restrict__ cnt) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += stride)
+        cnt[t] = (t + 1 < nt ? tpos[t + 1] : (uint32_t)nm) - tpos[t];
+}
+
 // ------------------------------------------------------------------------------------------------
 // UMI correction (correct_umis, mark_dups.rs:19-59)
 // ------------------------------------------------------------------------------------------------
@@ -1264,7 +1566,10 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         uint32_t nd32 = 0;
         {
             CrTimer t(ctx, CRGPU_T_DEDUP, n_keys);  // the family's unit: one sorted key (counted here, once per call)
-            CR_TRY(compact(ctx, HeadFlag{keys, 1u}, EmitRun{keys, ukey, upos}, n_keys, d_block, d_total));
+            if (getenv("CRGPU_RL_GENERIC"))  // A/B: the generic compaction with its three loads per key
+                CR_TRY(compact(ctx, HeadFlag{keys, 1u}, EmitRun{keys, ukey, upos}, n_keys, d_block, d_total));
+            else
+                CR_TRY(run_lengths(ctx, keys, 1u, n_keys, ukey, upos, d_block, d_total));
         }
         CR_TRY(read_u32(ctx, d_total, &nd32));
         nd = nd32;
@@ -1359,13 +1664,48 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         }
     }
 
-    // 5. molecules = distinct keys some read lands on and that are not low support
-    DevBuf mkeys_b, mreads_b;
+    // 5. molecules = distinct keys some read lands on and that are not low support; with them, in the same two launches,
+    //    the (barcode, feature) triplets (6.): CRGPU_MOL_FUSED=0 keeps the separate passes (the A/B path)
+    DevBuf mkeys_b, mreads_b, tpos_b;
     CR_TRY(dmalloc(ctx, mkeys_b, nd * sizeof(uint64_t)));
     CR_TRY(dmalloc(ctx, mreads_b, nd * sizeof(uint32_t)));
-    uint32_t nm32 = 0;
+    uint32_t nm32 = 0, nt32 = 0;
     const TargetFilter tf{ctx->d_on_target, ctx->n_target_features, L.sh_feat(), L.bits_feat, ctx->d_on_target ? ctx->target_min_reads : 0};
-    {
+    const char *fused_env = getenv("CRGPU_MOL_FUSED");
+    const bool fused = nd > 0 && !(fused_env && fused_env[0] == '0');
+    if (fused) {
+        CR_TRY(dmalloc(ctx, tpos_b, (nd + 1) * sizeof(uint32_t)));
+        // the triplet arrays are sized before the number of triplets is known: one entry per distinct key is the bound
+        CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_bc, nd * sizeof(uint32_t)));
+        CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_feature, nd * sizeof(uint32_t)));
+        uint32_t *d_heads = d_block + 4096;      // the second set of block counters
+        uint32_t *d_total_h = ctx->d_scalars + 17;
+        {
+            CrTimer t(ctx, CRGPU_T_DEDUP);
+            const EmitMol emit{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()};
+            uint64_t tile;
+            const uint32_t nb = cp_blocks(nd, &tile);
+            const MolFlagTargeted flag_t{st, ukey, upos, inc_all, n_keys, nd, tf};
+            const MolFlag flag_p{st};
+            if (tf.min_reads)
+                hipLaunchKernelGGL(k_mt_count<MolFlagTargeted>, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, flag_t, ukey, L.sh_feat(), nd,
+                                   tile, d_block, d_heads);
+            else
+                hipLaunchKernelGGL(k_mt_count<MolFlag>, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, flag_p, ukey, L.sh_feat(), nd, tile,
+                                   d_block, d_heads);
+            CR_TRY(cr_scan_small(ctx, d_block, nb, d_total));
+            CR_TRY(cr_scan_small(ctx, d_heads, nb, d_total_h));
+            if (tf.min_reads)
+                hipLaunchKernelGGL(k_mt_write<MolFlagTargeted>, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, flag_t, emit, L.sh_bc(),
+                                   L.sh_feat(), L.bits_feat, nd, tile, d_block, d_heads, res->d_bc, res->d_feature, tpos_b.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(k_mt_write<MolFlag>, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, flag_p, emit, L.sh_bc(), L.sh_feat(),
+                                   L.bits_feat, nd, tile, d_block, d_heads, res->d_bc, res->d_feature, tpos_b.as<uint32_t>());
+            CR_HIP(ctx, hipGetLastError());
+        }
+        CR_TRY(read_u32(ctx, d_total, &nm32));
+        CR_TRY(read_u32(ctx, d_total_h, &nt32));
+    } else {
         CrTimer t(ctx, CRGPU_T_DEDUP);
         const EmitMol emit{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()};
         if (tf.min_reads)
@@ -1373,7 +1713,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         else
             CR_TRY(compact(ctx, MolFlag{st}, emit, nd, d_block, d_total));
     }
-    CR_TRY(read_u32(ctx, d_total, &nm32));
+    if (!fused) CR_TRY(read_u32(ctx, d_total, &nm32));
     const uint64_t nm = nm32;
 
     // 5b. optional per-read DupInfo
@@ -1453,25 +1793,31 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     }
 
     // 6. (barcode, feature) triplets = run lengths of the molecule keys at the feature boundary
-    DevBuf tpos_b;
-    CR_TRY(dmalloc(ctx, tpos_b, (nm + 1) * sizeof(uint32_t)));
-    uint32_t nt32 = 0;
-    if (nm) {
-        {
-            CrTimer t(ctx, CRGPU_T_DEDUP);
-            CR_TRY(compact(ctx, HeadFlag{mkeys_b.as<uint64_t>(), L.sh_feat()}, EmitTriplet{mkeys_b.as<uint64_t>(), tpos_b.as<uint32_t>()},
-                           nm, d_block, d_total));
+    if (!fused) {
+        CR_TRY(dmalloc(ctx, tpos_b, (nm + 1) * sizeof(uint32_t)));
+        if (nm) {
+            {
+                CrTimer t(ctx, CRGPU_T_DEDUP);
+                CR_TRY(compact(ctx, HeadFlag{mkeys_b.as<uint64_t>(), L.sh_feat()}, EmitTriplet{mkeys_b.as<uint64_t>(), tpos_b.as<uint32_t>()},
+                               nm, d_block, d_total));
+            }
+            CR_TRY(read_u32(ctx, d_total, &nt32));
         }
-        CR_TRY(read_u32(ctx, d_total, &nt32));
     }
     const uint64_t nt = nt32;
-    CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_bc, nt * sizeof(uint32_t)));
-    CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_feature, nt * sizeof(uint32_t)));
+    if (!fused) {
+        CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_bc, nt * sizeof(uint32_t)));
+        CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_feature, nt * sizeof(uint32_t)));
+    }
     CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_count, nt * sizeof(uint32_t)));
     if (nt) {
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        hipLaunchKernelGGL(k_triplets, dim3(cr_grid(nt, 256)), dim3(256), 0, ctx->stream, kl, mkeys_b.as<uint64_t>(),
-                           tpos_b.as<uint32_t>(), nt, nm, res->d_bc, res->d_feature, res->d_count);
+        if (fused)
+            hipLaunchKernelGGL(k_trip_counts, dim3(cr_grid(nt, 256)), dim3(256), 0, ctx->stream, tpos_b.as<uint32_t>(), nt, nm,
+                               res->d_count);
+        else
+            hipLaunchKernelGGL(k_triplets, dim3(cr_grid(nt, 256)), dim3(256), 0, ctx->stream, kl, mkeys_b.as<uint64_t>(),
+                               tpos_b.as<uint32_t>(), nt, nm, res->d_bc, res->d_feature, res->d_count);
         CR_HIP(ctx, hipGetLastError());
     }
     res->n_triplets = nt;
