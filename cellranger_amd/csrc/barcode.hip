@@ -321,13 +321,15 @@ template <bool UNIFORM, bool FROM_IDX = false>
 __global__ __launch_bounds__(256) void k_match_binned(const WlViewSet vs, const BinPlan plan,
                                                       const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
                                                       uint64_t n, uint32_t *__restrict__ idx_out,
-                                                      uint16_t *__restrict__ stage, uint32_t *__restrict__ cursor) {
+                                                      uint16_t *__restrict__ stage, uint32_t *__restrict__ cursor,
+                                                      const uint32_t *__restrict__ skip_if = nullptr) {
     __shared__ uint32_t bcnt[MB_MAX_BUCKETS];    // tile counts, then global base of each bucket
     __shared__ uint32_t bstart[MB_MAX_BUCKETS];  // tile-local exclusive prefix
     __shared__ uint16_t sval[MB_TILE];
     __shared__ uint16_t sbkt[MB_TILE];
     __shared__ uint32_t lds[8];
     __shared__ uint32_t tile_hits;
+    if (skip_if && *skip_if) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t NB = plan.n_buckets;
     const uint64_t n_tiles = (n + MB_TILE - 1) / MB_TILE;
@@ -549,6 +551,19 @@ __device__ __forceinline__ uint32_t hot_probe(const unsigned long long *s_hot, u
     r = y.z == key && y.w < r ? y.w : r;
     return r;
 }
+// the same, also telling which of the HOT_SLOTS entries answered (0xFFFF: none) -- the key of the hot-hit histogram
+__device__ __forceinline__ uint32_t hot_probe_slot(const unsigned long long *s_hot, uint32_t key, uint32_t &slot) {
+    const uint32_t b0 = hot_hash(key), b1 = (b0 + 1u) & (HOT_BUCKETS - 1u);
+    const uint4 x = *reinterpret_cast<const uint4 *>(s_hot + 2u * b0);
+    const uint4 y = *reinterpret_cast<const uint4 *>(s_hot + 2u * b1);
+    uint32_t r = CRGPU_MISS, s = 0xFFFFu;
+    if (x.x == key && x.y < r) { r = x.y; s = 2u * b0; }
+    if (x.z == key && x.w < r) { r = x.w; s = 2u * b0 + 1u; }
+    if (y.x == key && y.y < r) { r = y.y; s = 2u * b1; }
+    if (y.z == key && y.w < r) { r = y.w; s = 2u * b1 + 1u; }
+    slot = s;
+    return r;
+}
 // monotone bucketing of a count >= 1 into 256 classes (8 per octave)
 __device__ __forceinline__ uint32_t hot_class(uint32_t c) {
     const uint32_t e = 31u - (uint32_t)__clz((int)c);
@@ -566,9 +581,11 @@ __global__ __launch_bounds__(256) void k_hot_hist(const uint32_t *__restrict__ v
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
+// sums[0] += reads of all barcodes, sums[1] += reads of the barcodes that enter the table (the caller estimates from them
+// which share of the hits the table will NOT answer)
 __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ valid, const uint32_t *__restrict__ keys,
                                                    uint32_t n, const uint32_t *__restrict__ hist,
-                                                   unsigned long long *__restrict__ image) {
+                                                   unsigned long long *__restrict__ image, unsigned long long *__restrict__ sums) {
     __shared__ uint32_t h[256];
     __shared__ uint32_t s_min;
     h[threadIdx.x] = hist[threadIdx.x];
@@ -584,15 +601,31 @@ __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ 
     }
     __syncthreads();
     const uint32_t cmin = s_min;
+    unsigned long long all = 0, hot = 0;
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
         const uint32_t c = valid[r];
+        all += c;
         if (!c || hot_class(c) < cmin) continue;
         const uint32_t key = keys[r];
         const unsigned long long e = ((unsigned long long)r << 32) | key;
         const uint32_t b0 = hot_hash(key), b1 = (b0 + 1u) & (HOT_BUCKETS - 1u);
         const uint32_t slots[4] = {2u * b0, 2u * b0 + 1u, 2u * b1, 2u * b1 + 1u};
         for (int k = 0; k < 4; k++)
-            if (atomicCAS(&image[slots[k]], HOT_EMPTY, e) == HOT_EMPTY) break;
+            if (atomicCAS(&image[slots[k]], HOT_EMPTY, e) == HOT_EMPTY) {
+                hot += c;
+                break;
+            }
+    }
+    if (sums) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            all += __shfl_xor(all, d);
+            hot += __shfl_xor(hot, d);
+        }
+        if ((threadIdx.x & 63u) == 0u) {
+            atomicAdd(&sums[0], all);
+            atomicAdd(&sums[1], hot);
+        }
     }
 }
 
@@ -607,13 +640,21 @@ __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ 
 #define LH_QITEMS 4                  // item slots packed into the cold queue at a time
 #endif
 #define LH_QUEUE (64 * LH_QITEMS)    // entries of a wave's queue: every lane of every slot could be cold
+template <bool SPLIT>
 __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                                                            const unsigned long long *__restrict__ hot_image,
                                                            const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
                                                            uint64_t n, uint32_t *__restrict__ idx_out,
                                                            uint32_t *__restrict__ rec_i, uint32_t *__restrict__ rec_key,
                                                            uint8_t *__restrict__ rec_fl, uint32_t *__restrict__ rec_count,
-                                                           uint32_t rec_cap, uint32_t rec_regions, uint32_t i_offset) {
+                                                           uint32_t rec_cap, uint32_t rec_regions, uint32_t i_offset,
+                                                           uint16_t *__restrict__ hot_slot_out, uint32_t *__restrict__ cold_rank,
+                                                           uint32_t *__restrict__ cold_count, uint32_t cold_cap,
+                                                           uint32_t cold_regions) {
+    // hot_slot_out / cold_rank (both or neither): the histogram's inputs.  A hit answered by the LDS table is recorded as
+    // the table slot that answered (2 bytes per read, 0xFFFF otherwise) and counted later in LDS by k_hist_hot_slots; a hit
+    // found in the global tables is appended to this wave's region of cold_rank (no atomics, cursor in a register) and goes
+    // through the staged histogram -- 15 % of the reads instead of all of them.
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hot[];  // HOT_SLOTS, then the cold queues
     uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_hot + HOT_SLOTS);          // LH_THREADS / 64 queues of LH_QUEUE
     const uint32_t tid = threadIdx.x;
@@ -626,6 +667,7 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
     // miss records (for K2): every wave appends to its own region, no atomics; the cursor lives in a register
     const uint32_t region = blockIdx.x * (LH_THREADS / 64) + (tid >> 6);
     uint32_t rec_cur = rec_i ? rec_count[region] : 0u;
+    uint32_t cold_cur = SPLIT ? cold_count[region] : 0u;
     // the keys of the next chunk are requested before this chunk's table probes and global lookups
     uint32_t nkey[LH_ITEMS], nfl[LH_ITEMS];
 #pragma unroll
@@ -635,7 +677,7 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
         nfl[j] = (i < n && flags) ? CR_LOAD_STREAM(&flags[i]) : 0u;
     }
     for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < n; base += (uint64_t)gridDim.x * chunk) {
-        uint32_t key[LH_ITEMS], rank[LH_ITEMS], cfl[LH_ITEMS];
+        uint32_t key[LH_ITEMS], rank[LH_ITEMS], cfl[LH_ITEMS], hslot[LH_ITEMS];
         bool todo[LH_ITEMS];  // live read that the LDS table did not answer
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
@@ -653,11 +695,26 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
         }
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
-            const uint32_t r = hot_probe(s_hot, key[j]);
+            uint32_t sl = 0xFFFFu;
+            const uint32_t r = SPLIT ? hot_probe_slot(s_hot, key[j], sl) : hot_probe(s_hot, key[j]);
+            hslot[j] = 0xFFFFu;
             if (todo[j] && r != CRGPU_MISS) {
                 rank[j] = r;
                 todo[j] = false;
+                hslot[j] = sl;
             }
+        }
+        if (SPLIT) {
+            // the table slots that answered this thread's LH_ITEMS reads, as one 16-byte store: the histogram does not care
+            // which read a slot belongs to, so the stream is laid out by (chunk, thread), not by read
+            static_assert(LH_ITEMS == 8, "eight 16-bit slots per 16-byte store");
+            const uint64_t chunk_id = base / chunk;
+            cr_u32x4 pk;
+            pk.x = hslot[0] | (hslot[1] << 16);
+            pk.y = hslot[2] | (hslot[3] << 16);
+            pk.z = hslot[4] | (hslot[5] << 16);
+            pk.w = hslot[6] | (hslot[7] << 16);
+            CR_STORE_STREAM(pk, reinterpret_cast<cr_u32x4 *>(hot_slot_out) + chunk_id * LH_THREADS + tid);
         }
         // The rest (~20 % of the reads: ambient barcodes, the smaller cells, sequencing errors) goes to the global
         // tables.  Executing that path once per item slot costs every lane its instructions although only a fifth
@@ -679,11 +736,11 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
             __builtin_amdgcn_wave_barrier();  // keep the compiler from moving queue reads above these writes
             for (uint32_t r0 = 0; r0 < tot; r0 += 64) {  // uniform: tot comes from ballots
                 const uint32_t dpos = r0 + lane;
+                uint32_t found = CRGPU_MISS;
                 if (dpos < tot) {
                     const uint32_t k = q[dpos];
                     const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offE + (uint32_t)((uint64_t)k >> w.shiftE));
                     const uint32_t lo = b2.a, hi = b2.b;
-                    uint32_t found = CRGPU_MISS;
                     if (hi > lo) {
                         const U32x4 d = *reinterpret_cast<const U32x4 *>(tw + (lo >> 1));
                         const uint32_t tail = k & tail_mask;
@@ -700,6 +757,12 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                             });
                     }
                     q[dpos] = found;  // valA == nullptr on this path: sorted position == rank
+                }
+                if (SPLIT) {  // the hits of this batch of 64 cold lookups, densely, behind the wave's earlier ones
+                    const unsigned long long cm = __ballot(found != CRGPU_MISS);
+                    const uint32_t pos = cold_cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                    if (found != CRGPU_MISS && pos < cold_cap) cold_rank[(uint64_t)region * cold_cap + pos] = found;
+                    cold_cur += (uint32_t)__popcll(cm);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -730,6 +793,50 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
         rec_count[region] = rec_cur;
         if (rec_cur > rec_cap) atomicOr(&rec_count[rec_regions], 1u);  // overflow: K2 falls back to scanning idx
     }
+    if (SPLIT && (tid & 63u) == 0u) {
+        cold_count[region] = cold_cur;
+        if (cold_cur > cold_cap) atomicOr(&cold_count[cold_regions], 1u);  // overflow: this round is counted by k_hist_ranks_atomic
+    }
+}
+
+// Histogram of the hits the LDS table answered: 16384 counters (one per table slot) in LDS, the slot stream read with
+// 16-byte loads; at the end every non-zero counter is added to the valid count of the slot's barcode.
+// skip_if (nullable): do nothing when *skip_if != 0 (a cold region overflowed: the round is counted another way).
+#define HH_THREADS 1024
+__global__ __launch_bounds__(HH_THREADS) void k_hist_hot_slots(const uint16_t *__restrict__ slots, uint64_t groups,
+                                                               const unsigned long long *__restrict__ hot_image,
+                                                               uint32_t *__restrict__ valid, const uint32_t *__restrict__ skip_if) {
+    extern __shared__ uint32_t s_cnt[];  // HOT_SLOTS
+    if (skip_if && *skip_if) return;
+    for (uint32_t s = threadIdx.x; s < HOT_SLOTS; s += HH_THREADS) s_cnt[s] = 0;
+    __syncthreads();
+    // groups of eight slots (16 bytes), one per (chunk, thread) of k_lookup_hot; the stream is a 16-byte aligned pool block
+    const uint4 *__restrict__ g = reinterpret_cast<const uint4 *>(slots);
+    for (uint64_t k = (uint64_t)blockIdx.x * HH_THREADS + threadIdx.x; k < groups; k += (uint64_t)gridDim.x * HH_THREADS) {
+        const uint4 v = g[k];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t s = (w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+            if (s != 0xFFFFu) atomicAdd(&s_cnt[s], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < HOT_SLOTS; s += HH_THREADS) {
+        const uint32_t c = s_cnt[s];
+        if (c) atomicAdd(&valid[(uint32_t)(hot_image[s] >> 32)], c);
+    }
+}
+
+// plain device atomics on a table of counts: the fallback of the fallbacks (run_if nullable: only when *run_if != 0)
+__global__ __launch_bounds__(256) void k_hist_ranks_atomic(const uint32_t *__restrict__ idx, uint64_t n, uint32_t *__restrict__ table,
+                                                          const uint32_t *__restrict__ run_if) {
+    if (run_if && *run_if == 0u) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t r = idx[i];
+        if (r != CRGPU_MISS) atomicAdd(&table[r], 1u);
+    }
 }
 
 // Histogram staging from the ranks in idx for at most 31 buckets (whitelists of up to ~1 M barcodes, one
@@ -743,13 +850,15 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
 #define SI_TILE (256 * SI_ITEMS)
 #define SI_MISS_BUCKET 31u
 __global__ __launch_bounds__(256) void k_stage_idx(const BinPlan plan, const uint32_t *__restrict__ idx, uint64_t n,
-                                                   uint16_t *__restrict__ stage, uint32_t *__restrict__ cursor) {
+                                                   uint16_t *__restrict__ stage, uint32_t *__restrict__ cursor,
+                                                   const uint32_t *__restrict__ skip_if = nullptr) {
     __shared__ uint32_t wcount[4][32];  // per-wave bucket counts -> tile-local start of (wave, bucket)
     __shared__ uint32_t gbase[32];      // global base of the tile's run of each bucket
     __shared__ uint32_t tstart[32];     // tile-local start of each bucket
     __shared__ uint16_t sval[SI_TILE];
     __shared__ uint8_t sbkt[SI_TILE];
     __shared__ uint32_t tile_hits;
+    if (skip_if && *skip_if) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t n_tiles = (n + SI_TILE - 1) / SI_TILE;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -973,7 +1082,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     const size_t hot_lds = HOT_SLOTS * sizeof(unsigned long long);                       // table image
     const size_t lookup_lds = hot_lds + (LH_THREADS / 64) * LH_QUEUE * sizeof(uint32_t);  // + per-wave cold queues
     if (use_hot && !ctx->d_hot_image) {
-        if (hipMalloc((void **)&ctx->d_hot_image, hot_lds + 256 * sizeof(uint32_t)) != hipSuccess) {
+        if (hipMalloc((void **)&ctx->d_hot_image, hot_lds + 256 * sizeof(uint32_t) + 2 * sizeof(unsigned long long)) != hipSuccess) {
             cr_pool_free(ctx, d_stage);
             cr_pool_free(ctx, d_cursor);
             return cr_fail(ctx, CRGPU_ENOMEM, "hipMalloc hot table failed");
@@ -1005,20 +1114,78 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
             cr_drop_miss_records(ctx);  // not fatal: K2 scans idx as before
         }
     }
-    if (use_hot) cr_allow_lds(ctx, (const void *)k_lookup_hot, lookup_lds);
+    if (use_hot) {
+        cr_allow_lds(ctx, (const void *)k_lookup_hot<false>, lookup_lds);
+        cr_allow_lds(ctx, (const void *)k_lookup_hot<true>, lookup_lds);
+    }
     hipError_t e = hipSuccess;
     bool hot_ready = false;
+    // Split histogram of the table rounds (k_lookup_hot's comment): hits the table answers are counted per table slot in
+    // LDS, the others are appended to per-wave regions and staged -- a sixth of the entries the staging used to see, so the
+    // rounds can be that much longer.  Sized after the sampling batch from the share of the reads the table's barcodes
+    // carry; a region that overflows makes its round fall back to device atomics (cold_count[regions] != 0).
+    const uint32_t cold_regions = 256u * (LH_THREADS / 64);
+    uint16_t *d_hot_slot = nullptr;
+    uint32_t *d_cold = nullptr, *d_cold_count = nullptr;
+    uint64_t hot_round = 0;   // reads per table round (0: the split histogram is off)
+    uint32_t cold_cap = 0;
+    struct ColdRelease {
+        crgpu_ctx *c;
+        uint16_t *&a;
+        uint32_t *&b, *&d;
+        ~ColdRelease() {
+            cr_pool_free(c, a);
+            cr_pool_free(c, b);
+            cr_pool_free(c, d);
+        }
+    } cold_release{ctx, d_hot_slot, d_cold, d_cold_count};
     for (uint64_t off = 0; off < n && e == hipSuccess;) {
         uint64_t m = n - off < sb ? n - off : sb;
         if (use_hot && off == 0 && m > first) m = first;
+        if (hot_ready && hot_round) m = n - off < hot_round ? n - off : hot_round;
         {
             CrTimer t(ctx, CRGPU_T_MATCH, m);
             e = hipMemsetAsync(d_cursor, 0, plan.n_buckets * MB_CURSOR_STRIDE * sizeof(uint32_t), ctx->stream);
-            if (hot_ready) {
-                hipLaunchKernelGGL(k_lookup_hot, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
+            if (hot_ready && hot_round) {
+                ctx->k1_split_rounds++;
+                const uint64_t C = (uint64_t)cold_regions * cold_cap;
+                const uint32_t *d_over = d_cold_count + cold_regions;
+                if (e == hipSuccess) e = hipMemsetAsync(d_cold_count, 0, (cold_regions + 1) * sizeof(uint32_t), ctx->stream);
+                if (e == hipSuccess) e = hipMemsetAsync(d_cold, 0xFF, C * sizeof(uint32_t), ctx->stream);
+                hipLaunchKernelGGL(k_lookup_hot<true>, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
                                    ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
                                    d_idx_out + off, rec.valid ? rec.d_i : nullptr, rec.d_key, rec.d_fl, rec.d_count, rec.cap,
-                                   rec.regions, (uint32_t)off);
+                                   rec.regions, (uint32_t)off, d_hot_slot, d_cold, d_cold_count, cold_cap, cold_regions);
+                const uint64_t lh_chunk = (uint64_t)LH_THREADS * LH_ITEMS;
+                hipLaunchKernelGGL(k_hist_hot_slots, dim3(128), dim3(HH_THREADS), HOT_SLOTS * sizeof(uint32_t), ctx->stream, d_hot_slot,
+                                   (m + lh_chunk - 1) / lh_chunk * LH_THREADS, ctx->d_hot_image, uw.d_valid, d_over);
+                if (plan.n_buckets <= SI_MISS_BUCKET)
+                    hipLaunchKernelGGL(k_stage_idx, dim3(cr_grid((C + SI_TILE - 1) / SI_TILE, 1, 256u * 6u)), dim3(256), 0, ctx->stream,
+                                       plan, d_cold, C, d_stage, d_cursor, d_over);
+                else
+                    hipLaunchKernelGGL((k_match_binned<true, true>), dim3(cr_grid((C + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)),
+                                       dim3(256), 0, ctx->stream, vs, plan, (const uint32_t *)nullptr, (const uint8_t *)nullptr, C, d_cold,
+                                       d_stage, d_cursor, d_over);
+                hipLaunchKernelGGL(k_hist_ranks_atomic, dim3(cr_grid(m, 256)), dim3(256), 0, ctx->stream, d_idx_out + off, m, uw.d_valid,
+                                   d_over);
+                if (getenv("CRGPU_K1_DEBUG")) {
+                    std::vector<uint32_t> cc(cold_regions + 1);
+                    (void)hipMemcpyAsync(cc.data(), d_cold_count, cc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+                    (void)hipStreamSynchronize(ctx->stream);
+                    uint32_t mx = 0;
+                    uint64_t tot = 0;
+                    for (uint32_t r = 0; r < cold_regions; r++) {
+                        mx = std::max(mx, cc[r]);
+                        tot += cc[r];
+                    }
+                    fprintf(stderr, "K1 round off=%llu m=%llu cap=%u max_region=%u total_cold=%llu overflow=%u\n",
+                            (unsigned long long)off, (unsigned long long)m, cold_cap, mx, (unsigned long long)tot, cc[cold_regions]);
+                }
+            } else if (hot_ready) {
+                hipLaunchKernelGGL(k_lookup_hot<false>, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
+                                   ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
+                                   d_idx_out + off, rec.valid ? rec.d_i : nullptr, rec.d_key, rec.d_fl, rec.d_count, rec.cap,
+                                   rec.regions, (uint32_t)off, (uint16_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, 0u);
                 if (plan.n_buckets <= SI_MISS_BUCKET)
                     hipLaunchKernelGGL(k_stage_idx, dim3(cr_grid((m + SI_TILE - 1) / SI_TILE, 1, 256u * 6u)), dim3(256), 0,
                                        ctx->stream, plan, d_idx_out + off, m, d_stage, d_cursor);
@@ -1043,9 +1210,50 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                 if (e == hipSuccess) e = hipMemsetAsync(ctx->d_hot_image, 0xFF, hot_lds, ctx->stream);
                 if (e == hipSuccess) e = hipMemsetAsync(d_hh, 0, 256 * sizeof(uint32_t), ctx->stream);
                 hipLaunchKernelGGL(k_hot_hist, dim3(128), dim3(256), 0, ctx->stream, uw.d_valid, ctx->n_canon, d_hh);
+                unsigned long long *d_sums = reinterpret_cast<unsigned long long *>(d_hh + 256);
+                if (e == hipSuccess) e = hipMemsetAsync(d_sums, 0, 2 * sizeof(unsigned long long), ctx->stream);
                 hipLaunchKernelGGL(k_hot_build, dim3(128), dim3(256), 0, ctx->stream, uw.d_valid, ctx->d_canon_keys,
-                                   ctx->n_canon, d_hh, ctx->d_hot_image);
+                                   ctx->n_canon, d_hh, ctx->d_hot_image, d_sums);
                 hot_ready = true;
+                // share of the hits that the table will not answer (one read-back per call) -> size of the cold regions
+                unsigned long long sums[2] = {0, 0};
+                // Where it pays (measured, profiles/r02_k1_split_ab.txt): whitelists beyond the 31 buckets of k_stage_idx (the
+                // 6.8 M-entry list: 208 buckets, 49 staging rounds) -4 ms per 1 B reads; on the 737 K list the 2 bytes per read
+                // of the slot stream cost the lookup what the shorter staging saves (8.05 against 8.07 ms) and 100 M-read calls
+                // lose 5 %.  CRGPU_K1_SPLIT=1 / 0 forces it on / off.
+                const char *split_env = getenv("CRGPU_K1_SPLIT");
+                const bool want_split = split_env ? split_env[0] != '0' : plan.n_buckets > SI_MISS_BUCKET;
+                if (e == hipSuccess && want_split && !getenv("CRGPU_K1_FULL_STAGING") &&
+                    hipMemcpyAsync(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess && sums[0] > 0) {
+                    const double cold_frac = 1.0 - (double)sums[1] / (double)sums[0];
+                    // head room for the spread between the waves; in steps of 0.05 (and the round in steps of 32 Mi reads
+                    // below) so that a caller's repeated calls ask the pool for the same block sizes -- the table's content,
+                    // and with it this estimate, varies a little from call to call (insertion order)
+                    const double f = std::ceil((cold_frac * 1.5 + 0.02) * 20.0) / 20.0;
+                    if (f < 0.5) {
+                        // all cold hits of a round may fall into one bucket of the staging area (plan.cap entries)
+                        uint64_t per_region = plan.cap / cold_regions;
+                        uint64_t round = per_region > 128 ? (uint64_t)((double)(per_region - 64) * cold_regions / f) : 0;
+                        if (round > (1ull << 30)) round = 1ull << 30;
+                        if (round > (32ull << 20)) round = round / (32ull << 20) * (32ull << 20);
+                        if (round > n - first) round = n - first;
+                        round = (round + MB_TILE - 1) / MB_TILE * MB_TILE;
+                        uint64_t cap = (uint64_t)((double)round * f / cold_regions) + 64;
+                        if (const char *env = getenv("CRGPU_COLD_CAP")) cap = strtoull(env, nullptr, 10);  // tests: force the overflow fallback
+                        if ((round >= sb || round >= (n - first) / MB_TILE * MB_TILE) && round > 0 && cap * cold_regions <= plan.cap) {
+                            const uint64_t lh_chunk = (uint64_t)LH_THREADS * LH_ITEMS;
+                            int rr = cr_pool_alloc(ctx, (void **)&d_hot_slot, (round + lh_chunk) / lh_chunk * lh_chunk * sizeof(uint16_t));
+                            if (rr == CRGPU_OK) rr = cr_pool_alloc(ctx, (void **)&d_cold, cap * cold_regions * sizeof(uint32_t));
+                            if (rr == CRGPU_OK) rr = cr_pool_alloc(ctx, (void **)&d_cold_count, (cold_regions + 1) * sizeof(uint32_t));
+                            if (rr == CRGPU_OK) {
+                                hot_round = round;
+                                cold_cap = (uint32_t)cap;
+                                cr_allow_lds(ctx, (const void *)k_hist_hot_slots, HOT_SLOTS * sizeof(uint32_t));
+                            }  // else: not fatal, the rounds are staged in full as before
+                        }
+                    }
+                }
             }
             if (e == hipSuccess) e = hipGetLastError();
         }
@@ -1476,14 +1684,6 @@ __global__ __launch_bounds__(256) void k_combine_segments(const SegIdx S, uint64
     }
 }
 
-__global__ __launch_bounds__(256) void k_hist_ranks_atomic(const uint32_t *__restrict__ idx, uint64_t n, uint32_t *__restrict__ table) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t r = idx[i];
-        if (r != CRGPU_MISS) atomicAdd(&table[r], 1u);
-    }
-}
-
 extern "C" int crgpu_combine_segments_dev(crgpu_ctx *ctx, int lib, const uint32_t *const *d_seg_idx, uint32_t n_segments,
                                           uint64_t n, int after_correction, uint32_t *d_idx_inout) {
     if (!ctx) return CRGPU_EINVAL;
@@ -1531,7 +1731,7 @@ extern "C" int crgpu_combine_segments_dev(crgpu_ctx *ctx, int lib, const uint32_
         vs.v[0].valid = table;
         CR_TRY(hist_from_idx(ctx, vs, plan, src, n));
     } else {
-        hipLaunchKernelGGL(k_hist_ranks_atomic, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, src, n, table);
+        hipLaunchKernelGGL(k_hist_ranks_atomic, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, src, n, table, (const uint32_t *)nullptr);
         CR_HIP(ctx, hipGetLastError());
     }
     if (d_fresh) CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the block goes back to the pool

@@ -154,6 +154,7 @@ struct crgpu_ctx {
     std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
     uint64_t sort_refinished = 0;          // sorts whose finishing pass met a run too long for it and that were redone on all bits
+    uint64_t k1_split_rounds = 0;          // table rounds of K1 whose histogram was split (table slots in LDS + staged cold hits)
     uint64_t feature_reads_requeued = 0;   // reads k_extract_features handed to the wide-map launch
     uint64_t sort_fallbacks = 0;           // sorts whose look-back watchdog fired and that were finished by the classic passes
 

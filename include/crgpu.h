@@ -95,6 +95,7 @@ int crgpu_set_option(crgpu_ctx *ctx, int option, int64_t value);
 int crgpu_invalidate(crgpu_ctx *ctx);
 /* counters since the context was made */
 #define CRGPU_STAT_SORT_FALLBACKS 0  /* sorts whose look-back watchdog fired and that the classic passes finished */
+#define CRGPU_STAT_K1_SPLIT_ROUNDS 3 /* table rounds of pass A whose histogram was split: table hits counted per slot in LDS, the other hits staged */
 #define CRGPU_STAT_FEATURE_READS_REQUEUED 2 /* reads of crgpu_extract_features_dev redone with the wide correction map */
 #define CRGPU_STAT_SORT_REFINISHED 1 /* sorts redone on all key bits because a run of equal top bits was too long for the finishing pass */
 int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out);

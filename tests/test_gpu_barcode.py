@@ -125,6 +125,7 @@ def _compare_barcode_stage(w, n, first=0, threshold=0.975, max_err=None):
         ranks, counts = c.total_barcode_counts(thr)
         exp = np.where(v >= thr, v, 0) + np.where(cc >= thr, cc, 0)
         assert np.array_equal(ranks, np.nonzero(exp)[0].astype(np.uint32)) and np.array_equal(counts, exp[exp > 0])
+    stats["k1_split_rounds"] = c.stat(3)  # CRGPU_STAT_K1_SPLIT_ROUNDS
     c.close()
     return stats
 
@@ -150,6 +151,23 @@ def test_hot_barcode_table_path_bit_exact(monkeypatch):
     # few cells on a tiny whitelist: nearly every read is answered by the table; TTTT...T (all ones) is a valid key
     w = S.Workload(n_total=200_000, seed=31, n_wl=64, n_cells=20, n_ambient=30, cb_len=4, umi_len=6, cb_err=0.05)
     _compare_barcode_stage(w, 200_000)
+
+
+def test_split_histogram_rounds_and_their_overflow_fallback(monkeypatch):
+    """With the LDS table, pass A counts table hits per table slot in LDS and stages only the other hits (per-wave regions);
+    a region that overflows makes the round fall back to device atomics.  Both ways the histograms equal the oracle's, as
+    does the full staging of round 1 (CRGPU_K1_FULL_STAGING=1)."""
+    from cellranger_amd import synth as S
+
+    monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")
+    monkeypatch.setenv("CRGPU_K1_SPLIT", "1")   # the default takes it only for whitelists of more than 31 x 32768 barcodes
+    w = S.Workload(n_total=600_000, seed=S.SEED0 + 9)
+    assert _compare_barcode_stage(w, 600_000)["k1_split_rounds"] >= 1
+    monkeypatch.setenv("CRGPU_COLD_CAP", "5")
+    assert _compare_barcode_stage(w, 600_000)["k1_split_rounds"] >= 1   # overflow: counted by the atomics fallback
+    monkeypatch.delenv("CRGPU_COLD_CAP")
+    monkeypatch.setenv("CRGPU_K1_SPLIT", "0")
+    assert _compare_barcode_stage(w, 600_000)["k1_split_rounds"] == 0
 
 
 def test_miss_record_overflow_falls_back_to_the_scan(monkeypatch):
@@ -424,3 +442,5 @@ def test_3m_whitelist_1m_reads_bit_exact(hot, monkeypatch):
     st = _compare_barcode_stage(w, 1_000_000)
     # a denser list: more reads with an error land on ANOTHER whitelist entry or find two candidates
     assert st["corrected"] > 20_000 and st["invalid"] > 1_000 and st["valid"] > 800_000
+    # 208 histogram buckets: with the table on, the rounds behind the sampling batch split their histogram by default
+    assert (st["k1_split_rounds"] >= 1) == hot
