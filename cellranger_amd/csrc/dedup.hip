@@ -643,6 +643,15 @@ struct EmitMol {
         p.s = st[k];
         return p;
     }
+    // the same without the next key's run start (the caller takes it from the neighbouring lane)
+    __device__ __forceinline__ Pre pre_own(uint64_t k) const {
+        Pre p;
+        p.key = ukey[k];
+        p.p0 = upos[k];
+        p.p1 = 0u;
+        p.s = st[k];
+        return p;
+    }
     __device__ __forceinline__ void operator()(uint64_t k, uint32_t o, const Pre &p) const {
         // Only a key that other keys were corrected onto (a few per cent) has anything in inc_all / minidx.
         // UmiType of the representative read (mark_dups.rs:250-268,326-329): the min (utype, qname)
@@ -914,7 +923,21 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mt_write(const Flag flag, const Em
             const uint64_t i = w0 + (uint64_t)j * 64 + lane;
             const uint64_t ic = i < hi ? i : hi - 1;
             f[j] = flag(ic);
-            pre[j] = emit.pre(ic);
+            pre[j] = emit.pre_own(ic);
+        }
+        {
+            // run start of the NEXT key: the lane above, the next slot's lane 0, and memory only behind the wave's last key
+            const uint64_t il = w0 + (uint64_t)MT_WAVE_SPAN;  // the key behind this wave's span
+            uint32_t after = emit.upos[il < nd ? il : nd - 1];
+#pragma unroll
+            for (int j = CP_ITEMS - 1; j >= 0; j--) {
+                uint32_t nx = __shfl_down(pre[j].p0, 1);
+                if (lane == 63u) nx = after;
+                pre[j].p1 = nx;
+                after = __shfl(pre[j].p0, 0);
+            }
+            // keys clamped to hi - 1 (the tail of the last round) repeat one key: their p1 is never used (f is false there),
+            // and the last real key of the array takes n_keys inside emit()
         }
         MtCarry carry = mt_carry_from_memory(flag, emit.ukey, sh_feat, nd, w0);
         uint32_t below_m[CP_ITEMS], below_h[CP_ITEMS];
