@@ -284,15 +284,22 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
               }
           __syncthreads();
       } else {
-          // one global atomic per 4096-read chunk (same-address atomics saturate near 88 per microsecond)
-          unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_out, lds);
+          // one global atomic per 4096-read chunk (same-address atomics saturate near 88 per microsecond); inside a wave
+          // the kept keys leave item slot by item slot, so that a store instruction writes consecutive addresses
+          const unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_out, lds);
+          unsigned long long wo = __shfl(o, 0);  // the wave's base = the offset of its first lane
+          const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-          for (int j = 0; j < KEY_ITEMS; j++)
-              if (mask & (1u << j)) {
-                  keys_out[o] = keys[j];
-                  if (vals_out) vals_out[o] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);  // read ordinal
-                  o++;
+          for (int j = 0; j < KEY_ITEMS; j++) {
+              const bool k = (mask >> j) & 1u;
+              const unsigned long long m = __ballot(k);
+              if (k) {
+                  const unsigned long long p = wo + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                  keys_out[p] = keys[j];
+                  if (vals_out) vals_out[p] = (uint32_t)(c * chunk + (uint64_t)j * 256 + threadIdx.x);  // read ordinal
               }
+              wo += (uint32_t)__popcll(m);
+          }
       }
     }
     if (HIST) {
@@ -300,6 +307,121 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
         for (uint32_t x = threadIdx.x; x < plan.n_passes * RADIX_MAX; x += 256)
             if (s_hist[x]) atomicAdd(&ghist[x], s_hist[x]);
     }
+}
+
+// ---- the same for the common case, four consecutive reads per lane --------------------------------------------------------
+// k_build_keys is bound by the number of loads in flight, not by bytes (five loads of 1 to 12 bytes per read).  Here a lane
+// takes four consecutive reads with 16-byte loads: barcode ranks, features and UMIs as one uint4 each, the four flag bytes
+// as one dword, the four quality rows (4 * LQW dwords) as LQW uint4 -- 1.75 loads per read instead of 5.  Keys only (no
+// ordinals, fixed UMI length, dword quality rows), n a multiple of 4, 16-byte aligned arrays; everything else takes
+// k_build_keys.  The kept keys leave in thread-major order inside a chunk, as there: the sort does not care.
+#ifndef KEY_VB
+#define KEY_VB 1
+#endif
+template <int LQW, bool HIST>
+__global__ __launch_bounds__(256) void k_build_keys_v4(const KL kl, const uint32_t *__restrict__ bc_idx, const uint32_t *__restrict__ umi,
+                                                       const uint8_t *__restrict__ umi_q, const uint32_t *__restrict__ feature,
+                                                       const uint8_t *__restrict__ flags, uint64_t n, uint64_t *__restrict__ keys_out,
+                                                       unsigned long long *__restrict__ n_out, const SweepPlan plan,
+                                                       uint32_t *__restrict__ ghist) {
+    static_assert(LQW >= 1 && LQW <= 4, "dword quality rows");
+    __shared__ __attribute__((aligned(8))) uint32_t lds[10];
+    __shared__ uint32_t s_hist[HIST ? OS_MAX_PASSES * RADIX_MAX : 1];
+    if (HIST) {
+        for (uint32_t x = threadIdx.x; x < plan.n_passes * RADIX_MAX; x += 256) s_hist[x] = 0;
+        __syncthreads();
+    }
+    constexpr int NV = KEY_ITEMS / 4;  // vectors of four reads per thread and chunk
+    const uint32_t L = kl.umi_len;
+    const uint64_t chunk = 256ull * KEY_ITEMS;
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    const uint64_t n_vec = n / 4;  // n is a multiple of 4
+    const uint32_t umi_mask = (uint32_t)lowmask(kl.bits_umi), adj_mask = (uint32_t)lowmask(kl.bits_umi - 2u);
+    const uint4 *__restrict__ bc4 = reinterpret_cast<const uint4 *>(bc_idx);
+    const uint4 *__restrict__ ft4 = reinterpret_cast<const uint4 *>(feature);
+    const uint4 *__restrict__ um4 = reinterpret_cast<const uint4 *>(umi);
+    const uint32_t *__restrict__ fl4 = reinterpret_cast<const uint32_t *>(flags);
+    const uint4 *__restrict__ q4 = reinterpret_cast<const uint4 *>(umi_q);
+    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        uint64_t keys[KEY_ITEMS];
+        uint32_t mask = 0;
+#pragma unroll
+      for (int v0 = 0; v0 < NV; v0 += KEY_VB) {  // KEY_VB vectors' loads are in flight together
+        uint4 vb[KEY_VB], vf[KEY_VB], vu[KEY_VB], vq[KEY_VB][LQW];
+        uint32_t vfl[KEY_VB];
+#pragma unroll
+        for (int vv = 0; vv < KEY_VB; vv++) {
+            const int v = v0 + vv;
+            const uint64_t iv = c * (chunk / 4) + (uint64_t)v * 256 + threadIdx.x;  // index of the vector
+            const uint64_t ic = iv < n_vec ? iv : n_vec - 1;                         // loads from a clamped address
+            vb[vv] = bc4[ic];
+            vf[vv] = ft4[ic];
+            vu[vv] = um4[ic];
+            vfl[vv] = fl4 ? fl4[ic] : 0u;
+#pragma unroll
+            for (int k = 0; k < LQW; k++) vq[vv][k] = q4[ic * LQW + k];
+        }
+#pragma unroll
+        for (int vv = 0; vv < KEY_VB; vv++) {
+            const int v = v0 + vv;
+            const uint64_t iv = c * (chunk / 4) + (uint64_t)v * 256 + threadIdx.x;
+            const uint32_t b4[4] = {vb[vv].x, vb[vv].y, vb[vv].z, vb[vv].w};
+            const uint32_t f4[4] = {vf[vv].x, vf[vv].y, vf[vv].z, vf[vv].w};
+            const uint32_t u4[4] = {vu[vv].x, vu[vv].y, vu[vv].z, vu[vv].w};
+            uint32_t qw[4 * LQW];
+#pragma unroll
+            for (int k = 0; k < LQW; k++) {
+                qw[4 * k + 0] = vq[vv][k].x;
+                qw[4 * k + 1] = vq[vv][k].y;
+                qw[4 * k + 2] = vq[vv][k].z;
+                qw[4 * k + 3] = vq[vv][k].w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = v * 4 + r;
+                const uint32_t b = b4[r], f = f4[r], fl = (vfl[vv] >> (8 * r)) & 0xFFu;
+                const uint32_t lib = fl & CRGPU_FLAG_LIB_MASK;
+                bool keep = iv < n_vec && b != CRGPU_MISS && f != CRGPU_NO_FEATURE && f < kl.n_features && lib < kl.n_libs;
+                const uint32_t u = u4[r] & umi_mask;
+                // UmiInfo::new (umi/src/info.rs:20-37)
+                bool has_n = false, low_q = false;
+#pragma unroll
+                for (int k = 0; k < LQW; k++) {
+                    const uint32_t w = qw[r * LQW + k];
+                    has_n |= (w & 0x80808080u) != 0u;
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++) low_q |= (uint8_t)(((w >> (8 * bb)) & 0x7Fu) - 33u) < 10u;
+                }
+                const bool homopolymer = ((u ^ (u >> 2)) & adj_mask) == 0u;
+                keep = keep && !(has_n || homopolymer || low_q);
+                keys[j] = ((uint64_t)b << kl.sh_bc) | ((uint64_t)f << kl.sh_feat) | ((uint64_t)lib << kl.sh_libid) |
+                          ((uint64_t)u << kl.sh_umi) | ((fl & CRGPU_FLAG_NONTXOMIC) ? 1ull : 0ull);
+                if (keep) mask |= 1u << j;
+                if (HIST && keep)
+                    for (uint32_t p = 0; p < plan.n_passes; p++)
+                        atomicAdd(&s_hist[p * RADIX_MAX + ((uint32_t)(keys[j] >> plan.shift[p]) & plan.mask[p])], 1u);
+            }
+        }
+      }
+        // one reservation per workgroup and chunk; inside a wave the kept keys leave item slot by item slot, so that a store
+        // instruction writes consecutive addresses (thread-major order made 64 separate 100-byte pieces of every store)
+        const unsigned long long o = block_reserve_256((uint32_t)__popc(mask), n_out, lds);
+        unsigned long long wo = __shfl(o, 0);  // the wave's base = the offset of its first lane
+        const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+        for (int j = 0; j < KEY_ITEMS; j++) {
+            const bool k = (mask >> j) & 1u;
+            const unsigned long long m = __ballot(k);
+            if (k) keys_out[wo + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = keys[j];
+            wo += (uint32_t)__popcll(m);
+        }
+    }
+    if (HIST) {
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < plan.n_passes * RADIX_MAX; x += 256)
+            if (s_hist[x]) atomicAdd(&ghist[x], s_hist[x]);
+    }
+    (void)L;
 }
 
 static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *d_keys_out, uint32_t *d_vals_out,
@@ -360,6 +482,40 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         hipLaunchKernelGGL((k_build_keys<LQW, false>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,    \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
                            d_status, d_ticket, recs->d_umi_len)
+        // four reads per lane with 16-byte loads where the layout allows it (see k_build_keys_v4); the 1 - 3 reads behind the
+        // last multiple of four go through the scalar kernel, appended by the same counter
+        const bool aligned16 = ((uintptr_t)recs->d_bc_idx | (uintptr_t)recs->d_umi | (uintptr_t)recs->d_feature |
+                                (uintptr_t)recs->d_umi_qualn) % 16 == 0 && (uintptr_t)recs->d_flags % 4 == 0;
+        const uint32_t lqw = (recs->umi_len & 3u) == 0u ? recs->umi_len / 4u : 0u;
+        if (!d_vals_out && !recs->d_umi_len && lqw >= 1 && lqw <= 4 && aligned16 && recs->n >= 4096 && !getenv("CRGPU_KEYS_SCALAR")) {
+            const uint64_t n4 = recs->n & ~3ull;
+#define CR_BUILD_KEYS_V4(LQW)                                                                                                  \
+    if (d_hist)                                                                                                                \
+        hipLaunchKernelGGL((k_build_keys_v4<LQW, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,      \
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, n4, d_keys_out, d_n, plan, d_hist);              \
+    else                                                                                                                       \
+        hipLaunchKernelGGL((k_build_keys_v4<LQW, false>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,     \
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, n4, d_keys_out, d_n, plan, d_hist)
+            switch (lqw) {
+                case 1: CR_BUILD_KEYS_V4(1); break;
+                case 2: CR_BUILD_KEYS_V4(2); break;
+                case 3: CR_BUILD_KEYS_V4(3); break;
+                default: CR_BUILD_KEYS_V4(4); break;
+            }
+#undef CR_BUILD_KEYS_V4
+            if (n4 < recs->n) {
+                const uint64_t rest = recs->n - n4;
+                const uint8_t *tail_flags = recs->d_flags ? recs->d_flags + n4 : nullptr;
+                if (d_hist)
+                    hipLaunchKernelGGL((k_build_keys<0, true>), dim3(1), dim3(256), 0, ctx->stream, kl, recs->d_bc_idx + n4, recs->d_umi + n4,
+                                       recs->d_umi_qualn + n4 * recs->umi_len, recs->d_feature + n4, tail_flags, rest, d_keys_out,
+                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr);
+                else
+                    hipLaunchKernelGGL((k_build_keys<0, false>), dim3(1), dim3(256), 0, ctx->stream, kl, recs->d_bc_idx + n4, recs->d_umi + n4,
+                                       recs->d_umi_qualn + n4 * recs->umi_len, recs->d_feature + n4, tail_flags, rest, d_keys_out,
+                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr);
+            }
+        } else
         switch (recs->d_umi_len ? 0u : recs->umi_len) {  // per-read lengths: the byte path
             case 4: CR_BUILD_KEYS(1); break;
             case 8: CR_BUILD_KEYS(2); break;
