@@ -6,6 +6,8 @@
 //   crgpu::BarcodeCorrector barcode/src/corrector.rs:14-71         new(whitelist, bc_counts, strategy), correct_barcode
 //   crgpu::DupBuilder       tx_annotation/src/mark_dups.rs:118-169 observe(...), build(...)
 //   crgpu::BarcodeDupMarker tx_annotation/src/mark_dups.rs:171-363 -> UmiCount stream + feature_counts()
+//   crgpu::FeatureExtractor cr_types/src/reference/feature_extraction.rs:176-470  new(feature defs, feat_dist), match_read,
+//                           compile_pattern
 //   crgpu::BarcodeIndex     cr_types/src/barcode_index.rs:14-53
 //   crgpu::CountMatrix      cr_h5/src/count_matrix.rs:382-448, cr_lib/src/stages/write_matrix_market.rs:80-122
 //
@@ -13,6 +15,7 @@
 // computes on the CPU: every result comes from libcrgpu, and construction fails without a gfx950 device.
 #pragma once
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 #include <map>
@@ -282,6 +285,124 @@ class DupBuilder {
     uint32_t n_features_, umi_len_;
     std::vector<uint32_t> bc_, umi_, feature_;
     std::vector<uint8_t> qualn_, flags_;
+};
+
+/// FeatureDef (cr_types/src/reference/feature_reference.rs): the columns FeatureExtractor reads.
+struct FeatureDef {
+    uint32_t index;        // position in the feature reference (and in feat_dist)
+    std::string pattern;   // "5PNNNNNNNNNN(BC)", "^(BC)", "(BC)GTTTAAG...", bare "(BC)"
+    std::string sequence;  // A/C/G/T
+    int read;              // WhichRead: 0 = R1, 1 = R2
+};
+
+/// FeatureData (feature_extraction.rs:163-173) of one read: ids as feature indices, barcode / qual as a span of the read.
+struct FeatureData {
+    std::vector<uint32_t> ids;        // one id when the read is counted; its value is ids[0] (more ids: only the count is kept)
+    uint32_t n_ids = 0;
+    int read = 0;
+    uint32_t start = 0, len = 0;
+    bool corrected = false;           // corrected_barcode is Some
+};
+
+/// FeatureExtractor of ONE feature type (match_read skips the definitions of other types, :376-378): new() compiles the
+/// patterns (errors as the reference's: invalid pattern / sequence, duplicate definition), match_read runs on the GPU.
+class FeatureExtractor {
+   public:
+    FeatureExtractor(Context &ctx, int slot, const std::vector<FeatureDef> &defs, const std::vector<double> *feat_dist = nullptr)
+        : ctx_(ctx), slot_(slot) {
+        std::vector<crgpu_feature_def> d(defs.size());
+        for (size_t k = 0; k < defs.size(); k++)
+            d[k] = crgpu_feature_def{defs[k].pattern.c_str(), defs[k].sequence.c_str(), defs[k].index, (uint32_t)defs[k].read};
+        ctx_.check(crgpu_set_feature_extractor(ctx_.get(), slot_, d.data(), (uint32_t)d.size(), feat_dist ? feat_dist->data() : nullptr,
+                                               feat_dist ? (uint32_t)feat_dist->size() : 0u));
+    }
+    /// compile_pattern (:307-343): the regular expression as text; throws for a pattern the reference rejects
+    static std::string compile_pattern(const std::string &pattern, uint32_t length) {
+        char buf[4096];
+        const int rc = crgpu_compile_feature_pattern(pattern.c_str(), length, buf, sizeof(buf));
+        if (rc != CRGPU_OK) throw Error(rc, "Invalid pattern: '" + pattern + "'");
+        return buf;
+    }
+    /// regex_str of every compiled pattern (tethered ones as compile_pattern gives them, bare groups as compile_bare_patterns)
+    std::vector<std::string> regexes() const {
+        uint32_t n = 0;
+        ctx_.check(crgpu_feature_extractor_regex(ctx_.get(), slot_, 0, nullptr, 0, &n));
+        std::vector<std::string> out;
+        std::vector<char> buf(1 << 20);
+        for (uint32_t p = 0; p < n; p++) {
+            ctx_.check(crgpu_feature_extractor_regex(ctx_.get(), slot_, p, buf.data(), buf.size(), nullptr));
+            out.emplace_back(buf.data());
+        }
+        return out;
+    }
+    /// match_read (:358-441) for a batch of read pairs (either read may be absent: empty vectors); nullopt = None
+    std::vector<std::optional<FeatureData>> match_reads(const std::vector<std::string> &r1_seq, const std::vector<std::string> &r1_qual,
+                                                        const std::vector<std::string> &r2_seq,
+                                                        const std::vector<std::string> &r2_qual) const {
+        const size_t n = r1_seq.empty() ? r2_seq.size() : r1_seq.size();
+        Rows a = upload(r1_seq, r1_qual), b = upload(r2_seq, r2_qual);
+        DevBuf f(ctx_, n * 4), ni(ctx_, n * 4), cap(ctx_, n * 4);
+        ctx_.check(crgpu_extract_features_dev(ctx_.get(), slot_, a.seq.u8(), a.qual.u8(), a.len.u32(), a.stride, b.seq.u8(), b.qual.u8(),
+                                              b.len.u32(), b.stride, n, f.u32(), ni.u32(), cap.u32()));
+        std::vector<uint32_t> hf(n), hn(n), hc(n);
+        ctx_.check(crgpu_memcpy_d2h(ctx_.get(), hf.data(), f.p, n * 4));
+        ctx_.check(crgpu_memcpy_d2h(ctx_.get(), hn.data(), ni.p, n * 4));
+        ctx_.check(crgpu_memcpy_d2h(ctx_.get(), hc.data(), cap.p, n * 4));
+        std::vector<std::optional<FeatureData>> out(n);
+        for (size_t i = 0; i < n; i++) {
+            if (hc[i] == CRGPU_NO_CAPTURE) continue;
+            FeatureData d;
+            d.corrected = (hc[i] >> 31) != 0;
+            d.read = (int)((hc[i] >> 30) & 1u);
+            d.start = (hc[i] >> 8) & 0x3FFFFFu;
+            d.len = hc[i] & 0xFFu;
+            d.n_ids = hn[i];
+            if (hn[i] == 1) d.ids.push_back(hf[i]);
+            out[i] = d;
+        }
+        return out;
+    }
+
+   private:
+    struct DevBuf {
+        Context &c;
+        void *p = nullptr;
+        DevBuf(Context &ctx, size_t bytes) : c(ctx) {
+            if (bytes) c.check(crgpu_malloc(c.get(), &p, bytes));
+        }
+        ~DevBuf() {
+            if (p) crgpu_free(c.get(), p);
+        }
+        DevBuf(const DevBuf &) = delete;
+        DevBuf(DevBuf &&o) noexcept : c(o.c), p(o.p) { o.p = nullptr; }
+        uint8_t *u8() const { return (uint8_t *)p; }
+        uint32_t *u32() const { return (uint32_t *)p; }
+    };
+    struct Rows {
+        DevBuf seq, qual, len;
+        uint32_t stride;
+    };
+    Rows upload(const std::vector<std::string> &seq, const std::vector<std::string> &qual) const {
+        uint32_t stride = 0;
+        for (const auto &s : seq) stride = s.size() > stride ? (uint32_t)s.size() : stride;
+        stride = (stride + 3u) & ~3u;
+        const size_t n = seq.size();
+        Rows r{DevBuf(ctx_, n * stride), DevBuf(ctx_, n * stride), DevBuf(ctx_, n * 4), stride};
+        if (n == 0) return r;
+        std::vector<uint8_t> s(n * stride, 0), q(n * stride, 0);
+        std::vector<uint32_t> l(n);
+        for (size_t i = 0; i < n; i++) {
+            std::copy(seq[i].begin(), seq[i].end(), s.begin() + i * stride);
+            std::copy(qual[i].begin(), qual[i].end(), q.begin() + i * stride);
+            l[i] = (uint32_t)seq[i].size();
+        }
+        ctx_.check(crgpu_memcpy_h2d(ctx_.get(), r.seq.p, s.data(), s.size()));
+        ctx_.check(crgpu_memcpy_h2d(ctx_.get(), r.qual.p, q.data(), q.size()));
+        ctx_.check(crgpu_memcpy_h2d(ctx_.get(), r.len.p, l.data(), n * 4));
+        return r;
+    }
+    Context &ctx_;
+    int slot_;
 };
 
 /// CountMatrix: the arrays write_matrix_h5 stores (count_matrix.rs:382-448) + write_matrix_mtx.

@@ -1,6 +1,8 @@
 // C++ host-mirror tests (include/crgpu.hpp): the reference's own unit tests for this path, written against
 // the mirrored interface, run on the GPU through the C ABI.
 //   barcode/src/corrector.rs:196-341   test_barcode_correction, ..._no_valid_counts, prop_test_n_in_barcode
+//   cr_types/src/reference/feature_extraction.rs:585-635,638-706,737-827   test_compile_pattern, test_correct_bare_feature
+//                                            (with its multi-capture read ACCTTTT), test_correct_feature
 //   tx_annotation/src/mark_dups.rs:371-392   test_correct_umis (same count structure; UMIs changed so that none is
 //                                            a homopolymer, which UmiInfo::new would reject before DupBuilder)
 // Build: g++ -std=c++17 -Iinclude tests/cpp/test_host_mirror.cpp -Lcellranger_amd -lcrgpu   (see tests/test_gpu_cpp_host.py)
@@ -136,8 +138,93 @@ static void test_correct_umis_through_dup_builder() {
     }
 }
 
+// compute_feature_dist (cr_types/src/reference/feature_checker.rs:8-50) for features of one type
+static std::vector<double> feature_dist(const std::vector<int64_t> &counts, const std::vector<int> &types) {
+    std::vector<double> d(counts.size(), 0.0);
+    for (size_t i = 0; i < counts.size(); i++) {
+        int64_t sum = 0;
+        for (size_t j = 0; j < counts.size(); j++)
+            if (types[j] == types[i]) sum += counts[j];
+        d[i] = sum > 0 ? (double)counts[i] / (double)sum : 0.0;
+    }
+    return d;
+}
+
+// the reference's helper (:490-524): the read IS the sequence, on R1 and R2; the answer is FeatureData::corrected_barcode
+static std::optional<std::string> correct_feature_barcode(const crgpu::FeatureExtractor &fext, const std::vector<std::string> &feats,
+                                                          const std::string &seq, const std::string &qual) {
+    const auto r = fext.match_reads({seq}, {qual}, {seq}, {qual});
+    if (!r[0].has_value() || !r[0]->corrected || r[0]->ids.size() != 1) return std::nullopt;
+    return feats[r[0]->ids[0]];
+}
+
+static void test_compile_pattern() {
+    using FE = crgpu::FeatureExtractor;
+    CHECK(FE::compile_pattern("AGTCN(BC)TTT", 5) == "AGTC.(.{5,5})TTT");
+    CHECK(FE::compile_pattern("5PAGTCN(BC)TTT", 5) == "^AGTC.(.{5,5})TTT");
+    CHECK(FE::compile_pattern("5PAGTCN(BC)TTT-3p", 5) == "^AGTC.(.{5,5})TTT$");
+    CHECK(FE::compile_pattern("5P-AGTCN(BC)TTT3p", 5) == "^AGTC.(.{5,5})TTT$");
+    CHECK(FE::compile_pattern("^AGTCN(BC)TTT$", 5) == "^AGTC.(.{5,5})TTT$");
+    for (const char *bad : {"^AGTCN(BC)TTT3$", "5PAGTCN(BCTTT", "5PAGTCNTTT", "5PAGT(BC)CNTQTT", "3PAGT(BC)CNTATT", "AGT(BC)CNTATT5P",
+                            "AGT(BC)CNTATT^"}) {
+        bool threw = false;
+        try {
+            (void)FE::compile_pattern(bad, 5);
+        } catch (const crgpu::Error &) {
+            threw = true;
+        }
+        CHECK(threw);
+    }
+    crgpu::Context ctx(0);
+    FE bare(ctx, 0, {{0, "(BC)", "ACGT", 0}});
+    CHECK(bare.regexes() == std::vector<std::string>{"(.CGT|A.GT|AC.T|ACG.)"});
+}
+
+static void test_correct_bare_feature() {
+    crgpu::Context ctx(0);
+    const std::vector<std::string> feats{"ACGT", "ACCT", "TTTT"};
+    const std::vector<double> fdist = feature_dist({1, 10, 10}, {0, 0, 0});
+    crgpu::FeatureExtractor fext(ctx, 0, {{0, "(BC)", "ACGT", 0}, {1, "(BC)", "ACCT", 0}, {2, "(BC)", "TTTT", 0}}, &fdist);
+    // matches two patterns, but cannot choose b/c of 97.5% threshold
+    CHECK(!correct_feature_barcode(fext, feats, "ACTT", "IIII").has_value());
+    // also _perfectly_ matches two patterns, but still no dice
+    CHECK(!correct_feature_barcode(fext, feats, "ACCTTTT", "IIIIIII").has_value());
+    CHECK(correct_feature_barcode(fext, feats, "ACGT", "IIII") == std::optional<std::string>("ACGT"));
+    CHECK(correct_feature_barcode(fext, feats, "ACCT", "IIII") == std::optional<std::string>("ACCT"));
+    CHECK(correct_feature_barcode(fext, feats, "TTTT", "IIII") == std::optional<std::string>("TTTT"));
+    CHECK(correct_feature_barcode(fext, feats, "TTTA", "IIII") == std::optional<std::string>("TTTT"));
+}
+
+static void test_correct_feature() {
+    crgpu::Context ctx(0);
+    const std::vector<std::string> feats{"AAAA", "CCCC", "GGGG", "TTTT", "TTTA", "AAAT", "AATA", "ATAA", "TAAA"};
+    const std::vector<int> types{0, 0, 0, 1, 1, 2, 2, 2, 2};  // Antibody, CRISPR, Custom
+    const std::vector<double> fdist = feature_dist({0, 10, 1, 10, 10, 10, 10, 10, 10}, types);
+    std::vector<std::vector<crgpu::FeatureDef>> by_type(3);
+    for (uint32_t i = 0; i < feats.size(); i++) by_type[types[i]].push_back({i, "^(BC)", feats[i], 0});
+    crgpu::FeatureExtractor antibody(ctx, 0, by_type[0], &fdist), crispr(ctx, 1, by_type[1], &fdist), custom(ctx, 2, by_type[2], &fdist);
+    CHECK(!correct_feature_barcode(antibody, feats, "AAAT", "IIII").has_value());
+    CHECK(correct_feature_barcode(antibody, feats, "CGCC", "IIII") == std::optional<std::string>("CCCC"));
+    CHECK(!correct_feature_barcode(antibody, feats, "TTTA", "IIII").has_value());
+    CHECK(!correct_feature_barcode(crispr, feats, "TTTC", "IIII").has_value());
+    CHECK(correct_feature_barcode(custom, feats, "AAAA", "III!") == std::optional<std::string>("AAAT"));
+    CHECK(correct_feature_barcode(custom, feats, "AAAA", "I!II") == std::optional<std::string>("ATAA"));
+    CHECK(!correct_feature_barcode(custom, feats, "AAAA", "IIII").has_value());
+    // two definitions with the same read, pattern and sequence (feature_extraction.rs:152-163)
+    bool threw = false;
+    try {
+        crgpu::FeatureExtractor dup(ctx, 3, {{0, "^(BC)", "AAAA", 0}, {1, "^(BC)", "AAAA", 0}});
+    } catch (const crgpu::Error &) {
+        threw = true;
+    }
+    CHECK(threw);
+}
+
 int main() {
     try {
+        test_compile_pattern();
+        test_correct_bare_feature();
+        test_correct_feature();
         test_barcode_correction();
         test_barcode_correction_no_valid_counts();
         prop_test_n_in_barcode();
