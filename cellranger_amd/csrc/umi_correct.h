@@ -232,31 +232,48 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             s_halo_head = hh ? 1u : 0u;
         }
         __syncthreads();
-        if (tid < UC_BLOCKS) {
-            int cs = -1;
-            for (int b = 0; b < (int)tid; b++) {
-                const unsigned long long m = s_heads[b];
-                if (m) cs = b * 64 + 63 - __clzll((long long)m);
+        if (tid < 64) {
+            // one wave, lane b = block b of 64 keys: the last segment head before each block and the first one behind it
+            // (prefix maximum / suffix minimum over the blocks by shuffles -- sixteen lanes looping over sixteen masks
+            // held every tile's other 240 threads at the barrier for a couple of microseconds), and the tile's first / last
+            // head for k_correct_umis_edges
+            static_assert(UC_BLOCKS <= 64, "one lane per block");
+            const unsigned long long m = tid < UC_BLOCKS ? s_heads[tid] : 0ull;
+            const int last = m ? (int)(tid * 64u + 63u - (uint32_t)__clzll((long long)m)) : -1;
+            const int first = m ? (int)(tid * 64u + (uint32_t)__ffsll((long long)m) - 1u) : 0x7FFFFFFF;
+            int pm = last, sm = first;
+#pragma unroll
+            for (int d = 1; d < UC_BLOCKS; d <<= 1) {
+                const int y = __shfl_up(pm, d), z = __shfl_down(sm, d);
+                if ((int)tid >= d) pm = pm > y ? pm : y;
+                if ((int)tid + d < (int)UC_BLOCKS) sm = sm < z ? sm : z;
             }
-            s_carry_start[tid] = cs;
-            int ce = s_halo_head ? (int)UC_TILE : 0x7FFFFFFF;
-            for (int b = UC_BLOCKS - 1; b > (int)tid; b--) {
-                const unsigned long long m = s_heads[b];
-                if (m) ce = b * 64 + (__ffsll((long long)m) - 1);
+            int cs = __shfl_up(pm, 1), ce = __shfl_down(sm, 1);
+            if (tid == 0) cs = -1;
+            const int behind = s_halo_head ? (int)UC_TILE : 0x7FFFFFFF;
+            if (tid + 1 >= UC_BLOCKS) ce = 0x7FFFFFFF;
+            ce = ce < behind ? ce : behind;
+            if (tid < UC_BLOCKS) {
+                s_carry_start[tid] = cs;
+                s_carry_end[tid] = ce;
             }
-            s_carry_end[tid] = ce;
-        } else if (tid == 64) {
-            // first / last segment head of the tile (positions < tn) for k_correct_umis_edges
-            uint32_t first = UC_NOHEAD, last = UC_NOHEAD;
-            for (uint32_t b = 0; b < UC_BLOCKS && b * 64u < tn; b++) {
-                unsigned long long m = s_heads[b];
-                if (tn - b * 64u < 64u) m &= (1ull << (tn - b * 64u)) - 1ull;  // drop the padding head at tn
-                if (!m) continue;
-                if (first == UC_NOHEAD) first = b * 64u + (uint32_t)(__ffsll((long long)m) - 1);
-                last = b * 64u + 63u - (uint32_t)__clzll((long long)m);
+            // heads at positions < tn only (the padding head at tn closes the last segment but is no key)
+            unsigned long long mk = m;
+            if (tid * 64u >= tn) mk = 0ull;
+            else if (tn - tid * 64u < 64u) mk &= (1ull << (tn - tid * 64u)) - 1ull;
+            uint32_t tf = mk ? tid * 64u + (uint32_t)__ffsll((long long)mk) - 1u : UC_NOHEAD;   // UC_NOHEAD is the maximum
+            int tl = mk ? (int)(tid * 64u + 63u - (uint32_t)__clzll((long long)mk)) : -1;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t y = __shfl_xor(tf, d);
+                const int z = __shfl_xor(tl, d);
+                tf = tf < y ? tf : y;
+                tl = tl > z ? tl : z;
             }
-            tile_first[tile] = first;
-            tile_last[tile] = last;
+            if (tid == 0) {
+                tile_first[tile] = tf;
+                tile_last[tile] = tl >= 0 ? (uint32_t)tl : UC_NOHEAD;
+            }
         }
         __syncthreads();
         // ---- segment bounds of every key; members of long in-tile segments enter the hash set ----
