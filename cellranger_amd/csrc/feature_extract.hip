@@ -585,6 +585,7 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
     CR_REQUIRE(ctx, !X.uses_read[1] || (d_r2_seq && d_r2_qual && r2_stride), CRGPU_EINVAL,
                "the extractor holds R2 patterns but no R2 rows were given");
     CR_REQUIRE(ctx, r1_stride < (1u << 22) && r2_stride < (1u << 22), CRGPU_ERANGE, "rows longer than 4 Mi bases");
+    cr_invalidate(ctx);  // caller buffers are written: by-products of earlier calls are not trusted any more
     double pe[34];
     for (int q = 0; q < 34; q++) pe[q] = std::pow(10.0, -(double)q / 10.0);  // host libm as in :45
     double *d_pe = (double *)(ctx->d_scalars + 128);
