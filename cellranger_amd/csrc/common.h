@@ -255,7 +255,9 @@ void cr_drop_miss_records(crgpu_ctx *ctx);
 // sort.hip: the plan radix_sort would use for 64-bit keys on bits [lo_bit, hi_bit); false = onesweep does not apply
 bool cr_sweep_plan(uint32_t lo_bit, uint32_t hi_bit, SweepPlan *plan, uint32_t *widths);
 // low bits of a molecule key of total_bits that the radix passes leave to the finishing pass (0: none)
-uint32_t cr_sort_low_bits(uint32_t total_bits);
+uint32_t cr_sort_low_bits(uint32_t total_bits, uint32_t umi_bits);
+bool cr_sort_finish_experiment();  // CRGPU_SORT_FINISH=1: the 16-bit finishing pass of round 2 instead of k_order_runs
+int cr_order_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel): the attribute is per device
 static inline void cr_allow_lds(crgpu_ctx *ctx, const void *kernel, size_t bytes) {
     if (ctx->lds_attr_done.insert(kernel).second)

@@ -452,7 +452,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         uint32_t widths[OS_MAX_PASSES];
         memset(&plan, 0, sizeof(plan));
         uint32_t *d_hist = nullptr;
-        if (!d_vals_out && ctx->trust_buffers && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(cr_sort_low_bits(ctx->layout.total_bits()), ctx->layout.total_bits(), &plan, widths)) {
+        if (!d_vals_out && ctx->trust_buffers && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(cr_sort_low_bits(ctx->layout.total_bits(), ctx->layout.bits_umi), ctx->layout.total_bits(), &plan, widths)) {
             if (!gh.d_hist) CR_TRY(cr_pool_alloc(ctx, (void **)&gh.d_hist, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t)));
             d_hist = gh.d_hist;
             CR_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t), ctx->stream));
@@ -1724,8 +1724,12 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     bool emitted = false;
     if (low_left) {
         bool fell_back = false;
-        CR_TRY(cr_finish_emit(ctx, keys_rw, vals_rw, n_keys, low_left, ukey, upos, &nd, &fell_back));
-        emitted = !fell_back;
+        if (cr_sort_finish_experiment()) {
+            CR_TRY(cr_finish_emit(ctx, keys_rw, vals_rw, n_keys, low_left, ukey, upos, &nd, &fell_back));
+            emitted = !fell_back;
+        } else {
+            CR_TRY(cr_order_runs(ctx, keys_rw, vals_rw, n_keys, low_left, &fell_back));  // then the run lengths as usual
+        }
         if (fell_back) {
             // a run of equal top bits too long for the fused pass: sort the buffer (the same multiset) on all bits
             ctx->sort_refinished++;

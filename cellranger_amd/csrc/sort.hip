@@ -648,16 +648,44 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
 // runs of 8 to 64 (the top genes of every cell: Zipf x log-normal cell sizes), their tiles take ten times as long as the
 // others, and under ticket order every later tile waits in its look-back for the slow tile's count with all workgroup
 // slots taken.  profiles/r02_finish_pass_ab.txt.
-uint32_t cr_sort_low_bits(uint32_t total_bits) {
+// How many low key bits the radix passes leave alone (0: none; the default).
+//   CRGPU_SORT_FINISH=2     the fewest low bits (at most 8) whose omission saves a whole pass, provided at least 16 UMI bits
+//                           stay above the cut: keys that agree on everything above it are then rare and few (the reads of one
+//                           UMI whose UmiType bits differ; UMIs of one (barcode, feature) that share their leading bases), and
+//                           k_order_runs puts those short runs in order -- 61 bits: 6 passes + 7 bits, 64 bits: 7 passes + 1 bit.
+//                           Measured at 1 B records: the passes 25.9 -> 22.8 ms, k_order_runs 3.7 ms (8.1 with one lane walking
+//                           every run through memory, 5.5 with in-register odd-even sorting of the runs inside a wave, 3.7 with
+//                           waves 48 keys apart so that short runs never leave their wave): +0.6 ms, so it is not the default;
+//                           fused into the run-length count (which reads the keys anyway) it would be -1.5 ms
+//   CRGPU_SORT_FINISH=1     the earlier experiment: up to 16 low bits, finished by k_finish_runs / k_finish_emit (slower still)
+uint32_t cr_sort_low_bits(uint32_t total_bits, uint32_t umi_bits) {
     const char *e = getenv("CRGPU_SORT_FINISH");
-    const bool on = e && atoi(e) == 1;
-    if (!on || !onesweep_enabled() || total_bits <= 27) return 0;
-    const uint32_t p = (total_bits - 16 + 8) / 9;      // passes of 9 bits for the top part
-    if (9 * p >= total_bits) return 0;
-    const uint32_t low = total_bits - 9 * p;          // <= 16 by construction
-    // the classic plan for comparison: only worth it when it saves at least one pass
+    if (!onesweep_enabled() || total_bits <= 27) return 0;
+    if (!e || atoi(e) == 0) return 0;
     const uint32_t p8 = (total_bits + 7) / 8, p9 = (total_bits + 8) / 9;
-    return p < (p9 < p8 ? p9 : p8) ? low : 0;
+    const uint32_t full = p9 < p8 ? p9 : p8;
+    if (e && atoi(e) == 1) {
+        if (const char *lo = getenv("CRGPU_SORT_FINISH_LOW")) {  // experiment: exactly this many low bits
+            const uint32_t low = (uint32_t)atoi(lo);
+            return low >= 1 && low <= 16 && low < total_bits ? low : 0;
+        }
+        const uint32_t p = (total_bits - 16 + 8) / 9;      // passes of 9 bits for the top part
+        if (9 * p >= total_bits) return 0;
+        const uint32_t low = total_bits - 9 * p;          // <= 16 by construction
+        return p < full ? low : 0;
+    }
+    for (uint32_t low = 1; low <= 8 && low < total_bits; low++) {
+        const uint32_t top = total_bits - low;
+        const uint32_t q8 = (top + 7) / 8, q9 = (top + 8) / 9;
+        if ((q9 < q8 ? q9 : q8) >= full) continue;               // saves nothing yet
+        // bit 0 is the UmiType bit, the UMI sits right above it: low - 1 of its bits fall below the cut
+        return umi_bits >= 16u + (low - 1u) ? low : 0u;
+    }
+    return 0;
+}
+bool cr_sort_finish_experiment() {
+    const char *e = getenv("CRGPU_SORT_FINISH");
+    return e && atoi(e) == 1;
 }
 
 bool cr_sweep_plan(uint32_t lo_bit, uint32_t hi_bit, SweepPlan *plan, uint32_t *widths) {
@@ -782,6 +810,179 @@ __global__ __launch_bounds__(256) void k_finish_runs(uint64_t *__restrict__ keys
     }
 }
 
+// ---- ordering the short runs that a sort on the top bits leaves ------------------------------------------------------------
+// After passes on the bits above `low`, keys that agree on those bits sit next to each other in arrival order.  With the
+// cut of cr_sort_low_bits such runs are mostly single keys or copies of ONE key (the reads of a molecule); what needs work
+// are the reads of one UMI whose UmiType bits differ and the rare UMIs of a (barcode, feature) that share their leading bases.
+// One streaming pass: the lane that holds the first key of a run (neighbours from the lanes next to it, memory only at the
+// wave's edges) owns the run: two keys are compared and swapped in registers, longer runs (rare) are insertion-sorted in
+// place through memory, long disordered ones by an in-place bucket permutation on the low bits; a run of more than OR_MAX
+// keys raises *bad and the caller sorts on all bits instead.  Rewriting a run never changes the bits above the cut, which is
+// all a neighbouring lane looks at.
+#define OR_STEP 48u     // keys between the waves of k_order_runs (64 keys each)
+#define OR_CAP 32u      // runs up to this length: insertion sort
+#define OR_MAX 65536u   // longer runs than this are not scanned by one lane: the caller sorts on all bits
+// one lane puts the run [i, e) in order through memory: e found by scanning, nothing to do when it is already ordered
+template <bool HAS_VALS>
+__device__ void or_run_through_memory(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low, uint64_t i,
+                                      uint32_t *__restrict__ bad) {
+    const uint64_t first = keys[i], top = first >> low;
+    uint64_t e = i + 1, prev = first;
+    bool disorder = false;
+    while (e < n && e - i <= OR_MAX) {
+        const uint64_t k = keys[e];
+        if ((k >> low) != top) break;
+        disorder |= k < prev;
+        prev = k;
+        e++;
+    }
+    if (e - i > OR_MAX) {
+        atomicOr(bad, 1u);
+        return;
+    }
+    if (!disorder) return;
+    const uint64_t len = e - i;
+    if (len <= OR_CAP) {  // insertion sort in place (only this lane touches the run)
+        for (uint64_t a = i + 1; a < e; a++) {
+            const uint64_t k = keys[a];
+            const uint32_t v = HAS_VALS ? vals[a] : 0u;
+            uint64_t b = a;
+            while (b > i && keys[b - 1] > k) {
+                keys[b] = keys[b - 1];
+                if (HAS_VALS) vals[b] = vals[b - 1];
+                b--;
+            }
+            if (b != a) {
+                keys[b] = k;
+                if (HAS_VALS) vals[b] = v;
+            }
+        }
+        return;
+    }
+    // a long run that mixes low bits (many reads of one UMI with both UmiTypes, ...): in-place bucket permutation on the
+    // low bits (American flag sort, at most 256 buckets)
+    uint32_t cnt[256], nxt[256];
+    const uint32_t nb = 1u << low, dm = nb - 1u;
+    for (uint32_t d = 0; d < nb; d++) cnt[d] = 0;
+    for (uint64_t a = i; a < e; a++) cnt[(uint32_t)keys[a] & dm]++;
+    uint32_t acc = 0;
+    for (uint32_t d = 0; d < nb; d++) {
+        nxt[d] = acc;
+        acc += cnt[d];
+        cnt[d] = acc;  // end of bucket d
+    }
+    for (uint32_t d = 0; d < nb; d++) {
+        while (nxt[d] < cnt[d]) {
+            const uint64_t k = keys[i + nxt[d]];
+            const uint32_t kd = (uint32_t)k & dm;
+            if (kd == d) {
+                nxt[d]++;
+            } else {
+                const uint64_t t = i + nxt[kd];
+                const uint64_t o = keys[t];
+                keys[t] = k;
+                keys[i + nxt[d]] = o;
+                if (HAS_VALS) {
+                    const uint32_t va = vals[i + nxt[d]], vb = vals[t];
+                    vals[t] = va;
+                    vals[i + nxt[d]] = vb;
+                }
+                nxt[kd]++;
+            }
+        }
+    }
+}
+
+template <bool HAS_VALS>
+__global__ __launch_bounds__(256) void k_order_runs(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low,
+                                                    uint32_t *__restrict__ bad) {
+    // A wave looks at 64 consecutive keys but the waves are only OR_STEP keys apart: a wave owns the runs that START in its
+    // first OR_STEP lanes, so a run of up to 64 - OR_STEP + 1 keys always ends inside the wave that owns it (a run that
+    // leaves its wave costs one lane a serial walk through memory while the other 63 wait: with waves 64 apart that was
+    // half of all waves and 4 of the pass's 5.5 ms).
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_waves = (n + OR_STEP - 1) / OR_STEP;
+    const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gw < n_waves; gw += wave_stride) {
+        const uint64_t i = gw * OR_STEP + lane;
+        const bool in = i < n;
+        const uint64_t ic = in ? i : n - 1;
+        uint64_t key = keys[ic];
+        uint32_t val = HAS_VALS ? vals[ic] : 0u;
+        const uint64_t key0 = key;
+        const uint32_t val0 = val;
+        uint64_t left = __shfl_up(key, 1);
+        if (lane == 0) left = ic > 0 ? keys[ic - 1] : ~key;
+        uint64_t behind = ~key;  // the key behind the wave (lane 63 only)
+        if (lane == 63 && ic + 1 < n) behind = keys[ic + 1];
+        const uint64_t top = key >> low;
+        const bool start = in && (i == 0 || (left >> low) != top);
+        const unsigned long long starts = __ballot(start);
+        const unsigned long long upto = ~0ull >> (63u - lane);  // lanes 0 .. lane
+        const bool has_head = (starts & upto) != 0ull;          // else: part of a run that began before the wave
+        const uint32_t rs = has_head ? 63u - (uint32_t)__clzll((long long)(starts & upto)) : 0u;
+        const unsigned long long above = lane < 63u ? starts >> (lane + 1u) : 0ull;
+        const uint32_t n_in = (uint32_t)__popcll(__ballot(in));  // lanes behind the last key hold a copy of it: not part of any run
+        uint32_t re = above ? lane + 1u + (uint32_t)__ffsll((long long)above) - 1u : 64u;  // exclusive
+        const bool to_wave_end = re == 64u;
+        re = re < n_in ? re : n_in;
+        // the wave's last run goes on behind the wave?  (also: keys behind n do not exist)
+        const bool last_goes_on = __shfl((behind >> low) == top && in, 63);
+        const bool owned = in && has_head && rs < OR_STEP;  // runs that start in the last lanes belong to the next wave
+        const bool closed = owned && !(to_wave_end && last_goes_on);
+        // a run that starts here and leaves the wave: its first lane does it through memory
+        if (start && owned && to_wave_end && last_goes_on) or_run_through_memory<HAS_VALS>(keys, vals, n, low, i, bad);
+        // closed runs with a descent somewhere: odd-even transposition across the lanes, in registers
+        const unsigned long long desc = __ballot(closed && lane > rs && key < left);
+        const unsigned long long mine = (re >= 64u ? ~0ull : ((1ull << re) - 1ull)) & ~((1ull << rs) - 1ull);  // lanes rs .. re - 1
+        const bool need = closed && (desc & mine) != 0ull;
+        uint32_t len = need ? re - rs : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(len, d);
+            len = o > len ? o : len;
+        }
+        for (uint32_t t = 0; t < len; t++) {  // uniform: the longest run of the wave that needs work
+            const bool low_side = ((lane - rs) & 1u) == (t & 1u);
+            const uint32_t partner = low_side ? lane + 1u : lane - 1u;
+            const bool ok = need && (low_side ? partner < re : lane > rs);
+            const uint64_t pk = __shfl(key, (int)(partner & 63u));
+            const uint32_t pv = HAS_VALS ? __shfl(val, (int)(partner & 63u)) : 0u;
+            if (ok) {
+                const bool take = low_side ? pk < key : pk > key;  // the lower lane keeps the smaller key
+                if (take) {
+                    key = pk;
+                    val = pv;
+                }
+            }
+        }
+        if (need && (key != key0 || (HAS_VALS && val != val0))) {  // an equal key may have arrived with another read's ordinal
+            keys[i] = key;
+            if (HAS_VALS) vals[i] = val;
+        }
+    }
+}
+
+int cr_order_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
+    *fell_back = false;
+    if (n < 2 || low_bits == 0) return CRGPU_OK;
+    uint32_t *d_flag = ctx->d_scalars + 52;
+    {
+        CrTimer t(ctx, CRGPU_T_SORT_HIST, n);  // booked beside the histogram slot: "sort, not a scatter pass"
+        CR_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(uint32_t), ctx->stream));
+        const dim3 grid(cr_grid((n + OR_STEP - 1) / OR_STEP * 64u, 256, 256u * 16u));
+        if (d_vals)
+            hipLaunchKernelGGL(k_order_runs<true>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits, d_flag);
+        else
+            hipLaunchKernelGGL(k_order_runs<false>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits, d_flag);
+        CR_HIP(ctx, hipGetLastError());
+    }
+    uint32_t flag = 0;
+    CR_TRY(crgpu_memcpy_d2h(ctx, &flag, d_flag, sizeof(flag)));
+    *fell_back = flag != 0;
+    return CRGPU_OK;
+}
+
 static int finish_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
     *fell_back = false;
     uint32_t *d_flag = ctx->d_scalars + 52;
@@ -828,7 +1029,8 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
         SweepPlan plan;
         uint32_t widths[OS_MAX_PASSES];
         // the passes sort on the top bits only when that saves one; k_finish_runs orders the `low` bits afterwards
-        const uint32_t low = lo_bit == 0 ? cr_sort_low_bits(hi_bit) : 0u;
+        const uint32_t low = (lo_bit == 0 && ctx->layout.set && hi_bit == ctx->layout.total_bits())
+                                 ? cr_sort_low_bits(hi_bit, ctx->layout.bits_umi) : 0u;
         const bool sweep = cr_sweep_plan(lo_bit + low, hi_bit, &plan, widths);
         KeyHistograms &gh = ctx->ghist;
         const bool have_hist = sweep && gh.valid && gh.d_keys == (const uint64_t *)d_keys && gh.n == n &&
@@ -847,8 +1049,12 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
                 return CRGPU_OK;
             }
             bool fell_back = false;
-            CR_TRY(finish_runs(ctx, *result_in_tmp ? k1 : k0, d_vals ? (*result_in_tmp ? d_vals_tmp : d_vals) : nullptr, n, low,
-                               &fell_back));
+            if (cr_sort_finish_experiment())
+                CR_TRY(finish_runs(ctx, *result_in_tmp ? k1 : k0, d_vals ? (*result_in_tmp ? d_vals_tmp : d_vals) : nullptr, n, low,
+                                   &fell_back));
+            else
+                CR_TRY(cr_order_runs(ctx, *result_in_tmp ? k1 : k0, d_vals ? (*result_in_tmp ? d_vals_tmp : d_vals) : nullptr, n, low,
+                                     &fell_back));
             if (!fell_back) return CRGPU_OK;
             // a run of equal top bits too long for the finishing pass (it may have moved keys inside other runs: the
             // buffer still holds every key): sort it again on all bits

@@ -299,11 +299,18 @@ def test_barcode_summary_csv(tmp_path):
     assert int(rows["reads"].sum()) == int((dev["idx"].to_host() != E.MISS).sum())
 
 
-def test_clustered_umis_and_long_runs_of_near_identical_keys():
+@pytest.mark.parametrize("big_run,top_bits_sort", [(50_000, False), (50_000, True), (90_000, True)])
+def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, top_bits_sort, monkeypatch):
     """UMIs that differ only in their last bases (three 8-base prefixes), UmiTypes mixed inside every UMI, and keys that
     agree in everything but the last 2.5 bases of the UMI in runs of 2..30, of 100 and of 50 000 reads: Hamming-1
-    neighbourhoods are dense, counts tie, and one (barcode, feature) segment holds most of the reads."""
+    neighbourhoods are dense, counts tie, and one (barcode, feature) segment holds most of the reads.
+    top_bits_sort (CRGPU_SORT_FINISH=2): the sort leaves the lowest key bits to k_order_runs -- runs inside a wave by an
+    odd-even transposition in registers, longer ones through memory (insertion up to 32 keys, in-place bucket permutation up
+    to 65 536), and a run of 90 000 keys makes it hand the job back to a sort on all bits (CRGPU_STAT_SORT_REFINISHED)."""
     import gpu_helpers as G
+
+    if top_bits_sort:
+        monkeypatch.setenv("CRGPU_SORT_FINISH", "2")
     from cellranger_amd import synth as S
     from cellranger_amd._lib import FLAG_NONTXOMIC
 
@@ -318,18 +325,19 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys():
     r["umi"] = ((prefix[rng.integers(0, 3, n)] << np.uint32(8)) | rng.integers(0, 256, n, dtype=np.uint32)).astype(np.uint32)
     # one run of 50 000 reads: same barcode, feature and first 9.5 bases; 20 runs of 100 reads
     assert not (r["flags"][0] & 0x10) and not (r["cb_qualn"][0] & 0x80).any()
-    r["cb"][:50_000], r["feature"][:50_000] = r["cb"][0], 7
-    r["cb_qualn"][:50_000] = r["cb_qualn"][0]
-    r["umi"][:50_000] = (r["umi"][0] & ~np.uint32(31)) | rng.integers(0, 32, 50_000, dtype=np.uint32)
+    r["cb"][:big_run], r["feature"][:big_run] = r["cb"][0], 7
+    r["cb_qualn"][:big_run] = r["cb_qualn"][0]
+    r["umi"][:big_run] = (r["umi"][0] & ~np.uint32(31)) | rng.integers(0, 32, big_run, dtype=np.uint32)
     for g in range(20):
-        s = 50_000 + 100 * g
+        s = big_run + 100 * g
         r["cb"][s:s + 100], r["feature"][s:s + 100] = r["cb"][s], g
         r["cb_qualn"][s:s + 100] = r["cb_qualn"][s]
         r["umi"][s:s + 100] = (r["umi"][s] & ~np.uint32(31)) | rng.integers(0, 32, 100, dtype=np.uint32)
-    r["flags"][:52_000] = r["flags"][0] & 0x0F     # the planted runs copy a barcode without N
+    r["flags"][:big_run + 2_000] = r["flags"][0] & 0x0F     # the planted runs copy a barcode without N
     r["flags"] = (r["flags"] | np.where(rng.random(n) < 0.4, FLAG_NONTXOMIC, 0)).astype(np.uint8)
     res, m = _compare_with_oracle(c, w, r, n, 40)
     assert m.nnz > 1000
+    assert (c.stat(1) > 0) == (top_bits_sort and big_run > 65_536)   # CRGPU_STAT_SORT_REFINISHED
     c.close()
 
 
