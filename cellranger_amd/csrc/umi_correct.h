@@ -37,6 +37,9 @@
 #define UC_ITEMS 4
 #endif
 #define UC_TILE (256 * UC_ITEMS)
+#ifndef UC_MIN_WG
+#define UC_MIN_WG 1   // second launch-bounds argument: workgroups per CU the register allocation has to allow
+#endif
 #define UC_BLOCKS (UC_TILE / 64)
 #ifndef UC_SMALL
 #define UC_SMALL 32
@@ -181,7 +184,7 @@ __device__ __forceinline__ uint32_t best_neighbour_lds(const uint32_t *s_umi, co
     return best.pos;
 }
 
-__global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const uint64_t *__restrict__ ukey,
+__global__ __launch_bounds__(256, UC_MIN_WG) void k_correct_umis_tiled(const KL kl, const uint64_t *__restrict__ ukey,
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
                                                             uint64_t n_keys, uint32_t *__restrict__ tile_first,
                                                             uint32_t *__restrict__ tile_last, uint32_t *__restrict__ corr,
@@ -189,7 +192,6 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
     __shared__ uint32_t s_umi[UC_TILE];
     __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
     __shared__ uint16_t s_start[UC_TILE];  // segment start inside the tile, UC_OPEN = not fully inside the tile
-    __shared__ uint16_t s_end[UC_TILE];    // exclusive end
     __shared__ __attribute__((aligned(16))) uint32_t s_hash[UC_BUCKETS * 8];
     __shared__ unsigned long long s_heads[UC_BLOCKS];  // bit l of entry b: position 64*b+l starts a segment
     __shared__ int s_carry_start[UC_BLOCKS];           // last segment start in blocks < b, or -1
@@ -290,7 +292,6 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
             const int end = gt ? (int)(p + (uint32_t)__ffsll((long long)gt)) : s_carry_end[b];
             const bool closed = start >= 0 && end <= (int)UC_TILE;
             s_start[p] = closed ? (uint16_t)start : (uint16_t)UC_OPEN;
-            s_end[p] = closed ? (uint16_t)end : (uint16_t)UC_OPEN;
             if (closed && end - start > UC_SMALL && !(s_cnt[p] & UC_NOCORR)) {
                 uc_insert<UC_BUCKETS, UC_POSBITS>(s_hash, (uint32_t)start, s_umi[p] & sp.lo_mask, p);
                 inserted = true;
@@ -303,8 +304,12 @@ __global__ __launch_bounds__(256) void k_correct_umis_tiled(const KL kl, const u
         for (int r = 0; r < UC_ITEMS; r++) {
             const uint32_t p = (uint32_t)r * 256u + tid;
             if (p >= tn) continue;
-            const uint32_t s = s_start[p], e = s_end[p];
+            const uint32_t s = s_start[p];
             if (s == UC_OPEN) continue;
+            // the (exclusive) end again from the head masks: two LDS words instead of a 2 KB array (the sixth workgroup per CU)
+            const uint32_t eb = p >> 6;
+            const unsigned long long gt = lane < 63u ? (s_heads[eb] >> (lane + 1u)) : 0ull;
+            const uint32_t e = gt ? p + (uint32_t)__ffsll((long long)gt) : (uint32_t)s_carry_end[eb];
             const uint64_t k = t0 + p;
             const uint32_t cw = s_cnt[p];
             const uint32_t my_cnt = cw & ~UC_NOCORR;
