@@ -1504,12 +1504,16 @@ __global__ __launch_bounds__(256) void k_correct_records(const WlViewSet vs, con
                                                          const uint32_t *__restrict__ rec_key, const uint8_t *__restrict__ rec_fl,
                                                          const uint32_t *__restrict__ rec_count, uint32_t rec_cap,
                                                          uint32_t rec_regions, const K2Params P,
-                                                         const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rank_out) {
+                                                         const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rank_out,
+                                                         uint32_t parts) {
     if (rec_count[rec_regions] != 0u) return;
-    for (uint32_t r = blockIdx.x; r < rec_regions; r += gridDim.x) {
+    // work items = (region, part): `parts` workgroups share a region's records (gridDim.x is a multiple of parts)
+    for (uint32_t w = blockIdx.x; w < rec_regions * parts; w += gridDim.x) {
+        const uint32_t r = w / parts, part = w % parts;
         const uint32_t cnt = rec_count[r];
         const uint32_t base = rank_out ? rec_off[r] : 0u;
-        for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
+        const uint32_t p_lo = (uint32_t)((uint64_t)cnt * part / parts), p_hi = (uint32_t)((uint64_t)cnt * (part + 1u) / parts);
+        for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += 256) {
             const uint64_t o = (uint64_t)r * rec_cap + p;
             uint32_t *sink = rank_out ? rank_out + base + p : nullptr;
             if (sink) *sink = CRGPU_MISS;
@@ -1622,8 +1626,16 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
             staged = false;  // not fatal: atomics as before
         }
         if (staged) hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, rec.d_count, rec.regions, d_off);
-        hipLaunchKernelGGL(k_correct_records, dim3(2048), dim3(256), 0, ctx->stream, vs, rec.d_i, rec.d_key, rec.d_fl, rec.d_count,
-                           rec.cap, rec.regions, P, d_off, d_rank);
+        // one workgroup per region (the regions are K1's waves: 4096): with 2048 workgroups taking two regions each, the 256
+        // that do not fit beside the 1792 resident ones ran almost alone at the end (K2 3.24 -> 2.87 ms per 500 M reads)
+        uint32_t k2_parts = 4;  // four workgroups per region: 2.88 -> 2.74 ms per 500 M reads on top of the one-per-region gain
+        if (const char *g = getenv("CRGPU_K2_PARTS")) k2_parts = (uint32_t)atoi(g);  // A/B
+        if (k2_parts < 1 || k2_parts > 16) k2_parts = 1;
+        uint32_t k2_grid = rec.regions * k2_parts;
+        if (const char *g = getenv("CRGPU_K2_GRID")) k2_grid = (uint32_t)atoi(g) / k2_parts * k2_parts;  // A/B
+        if (k2_grid < k2_parts) k2_grid = k2_parts;
+        hipLaunchKernelGGL(k_correct_records, dim3(k2_grid), dim3(256), 0, ctx->stream, vs, rec.d_i, rec.d_key, rec.d_fl, rec.d_count,
+                           rec.cap, rec.regions, P, d_off, d_rank, k2_parts);
         int rc = CRGPU_OK;
         if (hipGetLastError() != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "crgpu_correct: launch failed");
         uint32_t total = 0;
