@@ -452,7 +452,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         uint32_t widths[OS_MAX_PASSES];
         memset(&plan, 0, sizeof(plan));
         uint32_t *d_hist = nullptr;
-        if (!d_vals_out && ctx->trust_buffers && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(cr_sort_low_bits(ctx->layout.total_bits(), ctx->layout.bits_umi), ctx->layout.total_bits(), &plan, widths)) {
+        if (ctx->trust_buffers && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(cr_sort_low_bits(ctx->layout.total_bits(), ctx->layout.bits_umi), ctx->layout.total_bits(), &plan, widths)) {
             if (!gh.d_hist) CR_TRY(cr_pool_alloc(ctx, (void **)&gh.d_hist, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t)));
             d_hist = gh.d_hist;
             CR_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t), ctx->stream));
@@ -473,7 +473,11 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
             CR_HIP(ctx, hipMemsetAsync(d_ticket, 0, sizeof(uint32_t), ctx->stream));
         }
 #define CR_BUILD_KEYS(LQW)                                                                                                  \
-    if (d_vals_out)                                                                                                         \
+    if (d_vals_out && d_hist)                                                                                               \
+        hipLaunchKernelGGL((k_build_keys<LQW, true, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, \
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
+                           d_status, d_ticket, recs->d_umi_len);                                                            \
+    else if (d_vals_out)                                                                                                    \
         hipLaunchKernelGGL((k_build_keys<LQW, false, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
                            d_status, d_ticket, recs->d_umi_len);                                                            \

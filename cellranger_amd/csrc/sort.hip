@@ -1039,7 +1039,8 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
         if (sweep) {
             uint64_t *k0 = (uint64_t *)d_keys, *k1 = (uint64_t *)d_tmp;
             if (d_vals)
-                CR_TRY(onesweep_sort_u64<true>(ctx, k0, k1, d_vals, d_vals_tmp, n, plan, widths, result_in_tmp, nullptr));
+                CR_TRY(onesweep_sort_u64<true>(ctx, k0, k1, d_vals, d_vals_tmp, n, plan, widths, result_in_tmp,
+                                               have_hist ? gh.d_hist : nullptr));
             else
                 CR_TRY(onesweep_sort_u64<false>(ctx, k0, k1, nullptr, nullptr, n, plan, widths, result_in_tmp,
                                                 have_hist ? gh.d_hist : nullptr));
