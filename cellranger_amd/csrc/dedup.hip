@@ -1466,12 +1466,20 @@ struct __attribute__((aligned(4))) DupRec {
     uint32_t umi, read_count, flags;
 };
 
+// PACK8 (UMIs of at most 12 bases): the record is 8 bytes -- (flags << 24 | UMI) and the read count -- one aligned 8-byte store
+// per read instead of a 12-byte one that may straddle two sectors
+struct __attribute__((aligned(8))) DupRec8 {
+    uint32_t umi_flags, read_count;
+};
+template <bool PACK8>
 __global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ vals,
                                                   const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
                                                   const uint32_t *__restrict__ corr, const uint32_t *__restrict__ inc_all,
                                                   const uint16_t *__restrict__ st, const uint32_t *__restrict__ minidx,
-                                                  const uint32_t *__restrict__ rep_read, DupRec *__restrict__ packed,
+                                                  const uint32_t *__restrict__ rep_read, void *__restrict__ packed_v,
                                                   const TargetFilter tf) {
+    DupRec *__restrict__ packed = reinterpret_cast<DupRec *>(packed_v);
+    DupRec8 *__restrict__ packed8 = reinterpret_cast<DupRec8 *>(packed_v);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
         const uint32_t b = upos[k], e = k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys;
@@ -1494,20 +1502,36 @@ __global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *_
             const uint32_t r = vals[i];
             // one 12-byte store per read: the position of a read in sorted order has nothing to do with its ordinal,
             // and three separate scattered stores cost three partial-line writes per read (38 GB per 200 M reads)
-            packed[r] = DupRec{umi, read_count, (uint32_t)(base | ((!lowK && !filt && r == rep) ? CRGPU_DUP_UMI_COUNT : 0))};
+            const uint32_t fl = (uint32_t)(base | ((!lowK && !filt && r == rep) ? CRGPU_DUP_UMI_COUNT : 0));
+            if (PACK8)
+                packed8[r] = DupRec8{(fl << 24) | umi, read_count};
+            else
+                packed[r] = DupRec{umi, read_count, fl};
         }
     }
 }
 
 // the packed records -> the three output arrays of the ABI, streaming
-__global__ __launch_bounds__(256) void k_unpack_dupinfo(const DupRec *__restrict__ packed, uint64_t n, uint32_t *__restrict__ out_umi,
+template <bool PACK8>
+__global__ __launch_bounds__(256) void k_unpack_dupinfo(const void *__restrict__ packed_v, uint64_t n, uint32_t *__restrict__ out_umi,
                                                         uint32_t *__restrict__ out_cnt, uint8_t *__restrict__ out_flags) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
-        const DupRec d = packed[r];
-        if (out_umi) out_umi[r] = d.umi;
-        if (out_cnt) out_cnt[r] = d.read_count;
-        if (out_flags) out_flags[r] = (uint8_t)d.flags;
+        uint32_t umi, cnt, fl;
+        if (PACK8) {
+            const DupRec8 d = reinterpret_cast<const DupRec8 *>(packed_v)[r];
+            umi = d.umi_flags & 0xFFFFFFu;
+            fl = d.umi_flags >> 24;
+            cnt = d.read_count;
+        } else {
+            const DupRec d = reinterpret_cast<const DupRec *>(packed_v)[r];
+            umi = d.umi;
+            cnt = d.read_count;
+            fl = d.flags;
+        }
+        if (out_umi) out_umi[r] = umi;
+        if (out_cnt) out_cnt[r] = cnt;
+        if (out_flags) out_flags[r] = (uint8_t)fl;
     }
 }
 
@@ -1958,11 +1982,22 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
                 CR_HIP(ctx, hipMemsetAsync(packed_b.p, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
             }
             DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
-            hipLaunchKernelGGL(k_per_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys, corr,
-                               inc_all, st, minidx, rep_b.as<uint32_t>(), packed, tf);
-            if (!pr.packed_out)
-                hipLaunchKernelGGL(k_unpack_dupinfo, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream, packed, pr.n_reads,
-                                   pr.out_umi, pr.out_cnt, pr.out_flags);
+            // our own temporary may use the 8-byte layout (the block was sized and zeroed for 12-byte records: enough)
+            const bool pack8 = !pr.packed_out && kl.bits_umi <= 24u && !getenv("CRGPU_DUPINFO_PACK12");
+            if (pack8)
+                hipLaunchKernelGGL(k_per_read<true>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
+                                   corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
+            else
+                hipLaunchKernelGGL(k_per_read<false>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
+                                   corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
+            if (!pr.packed_out) {
+                if (pack8)
+                    hipLaunchKernelGGL(k_unpack_dupinfo<true>, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream,
+                                       (const void *)packed, pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
+                else
+                    hipLaunchKernelGGL(k_unpack_dupinfo<false>, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream,
+                                       (const void *)packed, pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
+            }
             CR_HIP(ctx, hipGetLastError());
         }
     }
