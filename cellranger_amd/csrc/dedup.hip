@@ -1977,13 +1977,14 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         }
         if (direct) {
             DevBuf packed_b;
+            // our own temporary may use the 8-byte layout
+            const bool pack8 = !pr.packed_out && kl.bits_umi <= 24u && !getenv("CRGPU_DUPINFO_PACK12");
             if (!pr.packed_out) {
-                CR_TRY(dmalloc(ctx, packed_b, pr.n_reads * sizeof(DupRec)));
-                CR_HIP(ctx, hipMemsetAsync(packed_b.p, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
+                const uint64_t bytes = pr.n_reads * (pack8 ? sizeof(DupRec8) : sizeof(DupRec));
+                CR_TRY(dmalloc(ctx, packed_b, bytes));
+                CR_HIP(ctx, hipMemsetAsync(packed_b.p, 0, bytes, ctx->stream));
             }
             DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
-            // our own temporary may use the 8-byte layout (the block was sized and zeroed for 12-byte records: enough)
-            const bool pack8 = !pr.packed_out && kl.bits_umi <= 24u && !getenv("CRGPU_DUPINFO_PACK12");
             if (pack8)
                 hipLaunchKernelGGL(k_per_read<true>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
                                    corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
