@@ -49,6 +49,9 @@
 #define SORT_WAVES (SORT_BLOCK / 64)
 #define RADIX_BITS 8
 #define RADIX 256
+#ifndef SORT_LB
+#define SORT_LB 8  // predecessor statuses read per round trip of the onesweep look-back
+#endif
 #ifndef SORT_MAX_BLOCKS
 #define SORT_MAX_BLOCKS 1024
 #endif
@@ -204,6 +207,26 @@ __global__ __launch_bounds__(256) void k_scan_digits(uint32_t *__restrict__ bloc
 // flag in the top two bits (1 = this chunk's count, 2 = inclusive prefix up to this chunk), published with
 // agent-scope atomic stores.  A chunk publishes its counts before it starts waiting, and waits only on lower
 // tickets, so the chain always makes progress.
+// -DSORT_PHASE_TIMING: thread 0 of every workgroup adds the shader-clock ticks of each phase of a chunk to g_sort_phase
+// (attribution builds only, scripts/sort_phases.py; crgpu_debug_sort_phases reads and clears the counters)
+#ifdef SORT_PHASE_TIMING
+__device__ unsigned long long g_sort_phase[16];
+#define SORT_PH(i)                                                          \
+    do {                                                                    \
+        if (tid == 0) {                                                     \
+            const unsigned long long t_ = __builtin_readcyclecounter();     \
+            atomicAdd(&g_sort_phase[i], t_ - ph_t);                         \
+            ph_t = t_;                                                      \
+        }                                                                   \
+    } while (0)
+extern "C" int crgpu_debug_sort_phases(unsigned long long *out16) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sort_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sort_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#else
+#define SORT_PH(i) ((void)0)
+#endif
 #define OS_AGG (1ull << 62)
 #define OS_INC (2ull << 62)
 #define OS_VAL ((1ull << 62) - 1ull)
@@ -245,6 +268,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
     const uint64_t hi = ONESWEEP ? n : (lo + tile < n ? lo + tile : n);
     const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
 
+#ifdef SORT_PHASE_TIMING
+    unsigned long long ph_t = __builtin_readcyclecounter();
+#endif
     for (uint64_t chunk = lo;; chunk += CHUNK) {
         uint64_t cidx = 0;
         if (ONESWEEP) {
@@ -276,8 +302,10 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         } else if (chunk >= hi) {
             break;
         }
+        SORT_PH(0);  // ticket
         for (uint32_t x = tid; x < SORT_WAVES * RADIX_T; x += SORT_BLOCK) (&wcount[0][0])[x] = 0;
         __syncthreads();
+        SORT_PH(1);  // counters cleared
 
         K key[ITEMS];
         uint32_t val[ITEMS];
@@ -292,6 +320,10 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                 key[it] = SORT_LOAD_IN(&kin[it * 64]);
                 if (HAS_VALS) val[it] = vin[it * 64];
             }
+#ifdef SORT_PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SORT_PH(2);  // keys arrived
+#endif
 #pragma unroll
             for (int it = 0; it < ITEMS; it++) {
                 const uint32_t d = dig(key[it], HAS_VALS ? val[it] : 0u);
@@ -311,7 +343,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                 dr[it] = (d << 16) | wave_multisplit_rank<BITS, false>(d, ok, wcount[wave]);
             }
         }
+        SORT_PH(3);  // own wave ranked
         __syncthreads();
+        SORT_PH(4);  // all waves ranked
         // one thread per digit: chunk-local start of the digit (exclusive scan over digits), per-wave
         // starts inside it, and the shift from LDS position to global position
         uint32_t tot = 0, run0 = 0;
@@ -333,6 +367,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             }
         }
         __syncthreads();
+        SORT_PH(5);  // digit scan
 #pragma unroll
         for (int it = 0; it < ITEMS; it++) {
             if (chunk_n == CHUNK || wave_off + it * 64 < chunk_n) {
@@ -341,6 +376,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                 if (HAS_VALS) svals[p] = val[it];
             }
         }
+        SORT_PH(6);  // LDS scatter issued
         // global start of every digit's run.  ONESWEEP: the look-back comes as late as possible (after the LDS
         // scatter above) so that the predecessors have had time to publish
         if (tid < RADIX_T) {
@@ -369,23 +405,22 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                         }
                         return sv;
                     };
-                    // steady state: the predecessor already has its inclusive prefix (one load).  Otherwise (start
-                    // of a pass, when all resident chunks begin together) walk back eight chunks per round trip
-                    uint64_t p = cidx - 1;
-                    unsigned long long sv = wait_for(p, __hip_atomic_load(&status[p * RADIX_T + tid], __ATOMIC_RELAXED,
-                                                                          __HIP_MEMORY_SCOPE_AGENT));
-                    excl = sv & OS_VAL;
-                    bool done = (sv >> 62) == 2ull;
+                    // SORT_LB statuses per round trip (the loads of a round are independent).  Wider rounds are SLOWER: 16 per
+                    // round +1.0 ms, 32 per round +3.1 ms for the seven passes over 796 M keys (profiles/r02_sort_phases.txt)
+                    // -- every status word read crosses the fabric (other XCDs wrote it), and a round of 32 reads as many
+                    // bytes as the chunk's own keys.
+                    uint64_t p = cidx;  // chunks [0, p) are still to be added; chunk 0 always carries an inclusive prefix
+                    bool done = false;
                     while (!done) {
-                        const uint32_t nb = p < 8 ? (uint32_t)p : 8u;  // p > 0: chunk 0 always carries an inclusive prefix
-                        unsigned long long v[8];
+                        const uint32_t nb = p < SORT_LB ? (uint32_t)p : (uint32_t)SORT_LB;
+                        unsigned long long v[SORT_LB];
 #pragma unroll
-                        for (uint32_t j = 0; j < 8; j++)
+                        for (uint32_t j = 0; j < SORT_LB; j++)
                             v[j] = j < nb ? __hip_atomic_load(&status[(p - 1 - j) * RADIX_T + tid], __ATOMIC_RELAXED,
                                                               __HIP_MEMORY_SCOPE_AGENT)
                                           : 0ull;
 #pragma unroll
-                        for (uint32_t j = 0; j < 8; j++) {
+                        for (uint32_t j = 0; j < SORT_LB; j++) {
                             if (done || j >= nb) continue;
                             const unsigned long long x = wait_for(p - 1 - j, v[j]);
                             excl += x & OS_VAL;
@@ -403,7 +438,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             }
             gdelta[tid] = g - run0;
         }
+        SORT_PH(7);  // look-back of thread 0
         __syncthreads();
+        SORT_PH(8);  // look-back of all digits
         if (ONESWEEP && *s_abort) break;  // uniform: nothing of this chunk is written, the pass is redone
         for (uint32_t p = tid; p < chunk_n; p += SORT_BLOCK) {
             const K k = skeys[p];
@@ -411,7 +448,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             SORT_STORE_OUT(k, &keys_out[pos]);
             if (HAS_VALS) vals_out[pos] = svals[p];
         }
+        SORT_PH(9);  // copy-out issued
         __syncthreads();
+        SORT_PH(10);  // everybody's copy-out issued
     }
 }
 
