@@ -126,6 +126,10 @@ struct CrComm;  // comm.hip: RCCL communicator or in-process group of this conte
 struct crgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // second in-order stream + fork / join events: the count stage runs the search for low-support candidates beside the
+    // UMI correction (dedup.hip, CrFork); created with the context, idle otherwise
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     std::recursive_mutex mu;  // every entry point holds it (CR_ENTER): calls of several host threads are serialised
     int n_ranks = 1, rank = 0;
@@ -271,6 +275,7 @@ int cr_pool_alloc(crgpu_ctx *ctx, void **out, uint64_t bytes);
 void cr_pool_free(crgpu_ctx *ctx, void *p);
 void cr_pool_release_all(crgpu_ctx *ctx);  // hipFree every cached block (destroy / memory pressure)
 
+hipEvent_t cr_take_event(crgpu_ctx *ctx);  // an event of the ledger's pool (ctx.hip)
 // timing scope: records a HIP event pair around the launches of one family when enabled
 struct CrTimer {
     crgpu_ctx *ctx;

@@ -62,6 +62,13 @@ extern "C" int crgpu_create(crgpu_ctx **out, int device_id, int n_ranks, int ran
         delete ctx;
         return cr_fail(nullptr, CRGPU_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();  // the count stage then stays on the one stream
+        if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+        ctx->stream2 = nullptr;
+    }
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) ctx->pool_budget = (uint64_t)total_b / 2;
@@ -185,6 +192,9 @@ extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
         hipEventDestroy(s.stop);
     }
     for (auto ev : ctx->event_pool) hipEventDestroy(ev);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
@@ -344,7 +354,7 @@ void cr_pool_release_all(crgpu_ctx *ctx) {
 
 // ---- timing ------------------------------------------------------------------------------------
 
-static hipEvent_t take_event(crgpu_ctx *ctx) {
+hipEvent_t cr_take_event(crgpu_ctx *ctx) {
     if (!ctx->event_pool.empty()) {
         hipEvent_t e = ctx->event_pool.back();
         ctx->event_pool.pop_back();
@@ -357,8 +367,8 @@ static hipEvent_t take_event(crgpu_ctx *ctx) {
 
 CrTimer::CrTimer(crgpu_ctx *c, int s, uint64_t u) : ctx(c), slot(s), units(u) {
     if (!ctx->timing) return;
-    start = take_event(ctx);
-    stop = take_event(ctx);
+    start = cr_take_event(ctx);
+    stop = cr_take_event(ctx);
     hipEventRecord(start, ctx->stream);
 }
 

@@ -1706,6 +1706,63 @@ struct PerRead {
     struct DupRec *packed_out = nullptr;  // non-NULL: leave the packed 12-byte records here (n_reads entries), no unpacking
 };
 
+// Two branches of the count stage that only read the distinct keys run side by side: the UMI correction stays on the
+// context's stream, the search for low-support candidates (filter, compaction, hash sort) goes to the second one.  Between
+// side() and join() every launch, scratch read-back and timer that goes through ctx->stream lands on the second stream; the
+// ledger books the whole region as ONE span on the main stream (inner timers are off: overlapping spans would count the
+// shared time twice).  Temporaries of both branches must stay alive until join(): the pool hands a freed block to the next
+// caller at once, which is only safe on one in-order stream.  CRGPU_DEDUP_OVERLAP=0 keeps everything on one stream.
+struct CrFork {
+    crgpu_ctx *ctx;
+    hipStream_t main = nullptr;
+    bool on_side = false, was_timing = false;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    explicit CrFork(crgpu_ctx *c) : ctx(c) {}
+    // CRGPU_DEDUP_OVERLAP: 0 = never, 2 = for every input (tests), otherwise from 2^20 distinct keys on
+    static bool enabled(const crgpu_ctx *c, uint64_t nd) {
+        const char *e = getenv("CRGPU_DEDUP_OVERLAP");
+        if (!c->stream2 || (e && e[0] == '0')) return false;
+        return (e && e[0] == '2') ? nd > 0 : nd >= (1u << 20);
+    }
+    // call after the main branch has been enqueued; start_of_region = the event recorded before it
+    int side(hipEvent_t start_of_region) {
+        main = ctx->stream;
+        was_timing = ctx->timing;
+        t0 = start_of_region;
+        if (hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0) != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "hipStreamWaitEvent failed");
+        ctx->stream = ctx->stream2;
+        ctx->timing = false;
+        on_side = true;
+        return CRGPU_OK;
+    }
+    int join() {
+        if (!on_side) return CRGPU_OK;
+        on_side = false;
+        hipError_t e = hipEventRecord(ctx->ev_join, ctx->stream2);
+        ctx->stream = main;
+        ctx->timing = was_timing;
+        if (e == hipSuccess) e = hipStreamWaitEvent(main, ctx->ev_join, 0);
+        if (e != hipSuccess) return cr_fail(ctx, CRGPU_EHIP, "joining the second stream failed: %s", hipGetErrorString(e));
+        if (t0) {
+            hipEventRecord(t1, main);
+            ctx->spans.push_back({CRGPU_T_DEDUP, t0, t1, 0});
+            t0 = t1 = nullptr;
+        }
+        return CRGPU_OK;
+    }
+    ~CrFork() {  // error path: nothing of the side branch may outlive the call
+        if (on_side) {
+            (void)hipStreamSynchronize(ctx->stream2);
+            ctx->stream = main;
+            ctx->timing = was_timing;
+        }
+        if (t0) {
+            ctx->event_pool.push_back(t0);
+            ctx->event_pool.push_back(t1);
+        }
+    }
+};
+
 static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_keys, crgpu_counts **out, PerRead pr) {
     if (!ctx || !out) return CRGPU_EINVAL;
     *out = nullptr;
@@ -1798,14 +1855,32 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     CR_TRY(dmalloc(ctx, st_b, st_bytes));
     uint32_t *corr = corr_b.as<uint32_t>(), *inc_all = incall_b.as<uint32_t>(), *minidx = minidx_b.as<uint32_t>();
     uint16_t *st = st_b.as<uint16_t>();
+    // the candidate search of step 4 needs nothing of step 3: it runs beside it on the second stream (CrFork)
+    const bool overlap = CrFork::enabled(ctx, nd);
+    CrFork fork(ctx);
+    DevBuf heads_b, giant_b, best_b;  // step 3's temporaries, alive until the branches have joined
+    if (overlap) {
+        CR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        if (ctx->timing) {
+            fork.t0 = cr_take_event(ctx);
+            fork.t1 = cr_take_event(ctx);
+            CR_HIP(ctx, hipEventRecord(fork.t0, ctx->stream));
+        }
+    }
     {
+        const bool timing_was = ctx->timing;
+        if (overlap) ctx->timing = false;  // one span for the whole region (CrFork::join)
+        struct TimingBack {
+            crgpu_ctx *c;
+            bool v;
+            ~TimingBack() { c->timing = v; }
+        } timing_back{ctx, timing_was};
         CrTimer t(ctx, CRGPU_T_DEDUP);
         CR_HIP(ctx, hipMemsetAsync(inc_all, 0, nd * sizeof(uint32_t), ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(st, 0, st_bytes, ctx->stream));
         CR_HIP(ctx, hipMemsetAsync(minidx, 0xFF, nd * sizeof(uint32_t), ctx->stream));
         const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
-        DevBuf heads_b;  // per tile: first / last segment head
-        CR_TRY(dmalloc(ctx, heads_b, 2 * n_tiles * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, heads_b, 2 * n_tiles * sizeof(uint32_t)));  // per tile: first / last segment head
         uint32_t *tile_first = heads_b.as<uint32_t>(), *tile_last = tile_first + n_tiles;
 #ifndef UC_GRID_WG
 #define UC_GRID_WG 5u  // workgroups per CU: what LDS and registers allow (4 left a fifth of the CU idle: 4.39 -> 3.67 ms; 6 with 80 VGPRs: 4.2)
@@ -1818,7 +1893,6 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             cr_allow_lds(ctx, (const void *)k_correct_umis_edges<false>, lds_large);
             cr_allow_lds(ctx, (const void *)k_giant_probe, lds_large);
             // work list of the segments with more than UE_CAP keys: one item per chunk of UE_CAP keys
-            DevBuf giant_b, best_b;
             const uint64_t max_items = nd / (UE_CAP / 2) + 16;
             CR_TRY(dmalloc(ctx, giant_b, max_items * sizeof(GiantItem) + 16));
             CR_TRY(dmalloc(ctx, best_b, nd * sizeof(unsigned long long)));
@@ -1853,6 +1927,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CR_TRY(dmalloc(ctx, v_b, nd * sizeof(uint32_t)));
         const uint32_t vbits = cr_ceil_log2(nd ? nd : 1);  // bits the distinct-key index needs inside the payload
         uint32_t n_cand32 = 0;
+        if (overlap) CR_TRY(fork.side(fork.t0));  // from here to join(): ctx->stream is the second stream
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
             const uint64_t n_ftiles = (nd + LF_TILE - 1) / LF_TILE;
@@ -1871,6 +1946,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             bool s_in_tmp = false;
             CR_TRY(cr_radix_sort_u32(ctx, h_b.as<uint32_t>(), ht_b.as<uint32_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(), n_cand,
                                      0, LS_HASH_BITS, &s_in_tmp));
+            CR_TRY(fork.join());  // k_low_support compares the phase-1 counts: it needs both branches
             {
                 CrTimer t(ctx, CRGPU_T_DEDUP);
                 hipLaunchKernelGGL(k_low_support, dim3(cr_grid(n_cand, 256)), dim3(256), 0, ctx->stream, kl,
@@ -1879,6 +1955,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
                 CR_HIP(ctx, hipGetLastError());
             }
         }
+        CR_TRY(fork.join());  // (no candidates: nothing was joined above)
     }
 
     // 5. molecules = distinct keys some read lands on and that are not low support; with them, in the same two launches,
