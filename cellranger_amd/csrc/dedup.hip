@@ -1735,6 +1735,10 @@ struct CrFork {
         on_side = true;
         return CRGPU_OK;
     }
+    // back to the main stream for the host code that follows; the side branch stays open (inner timers stay off) until join()
+    void pause() {
+        if (on_side) ctx->stream = main;
+    }
     int join() {
         if (!on_side) return CRGPU_OK;
         on_side = false;
@@ -1958,13 +1962,96 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CR_TRY(fork.join());  // (no candidates: nothing was joined above)
     }
 
+    const TargetFilter tf{ctx->d_on_target, ctx->n_target_features, L.sh_feat(), L.bits_feat, ctx->d_on_target ? ctx->target_min_reads : 0};
+    // 5b. optional per-read DupInfo.  Its scattered stores and the molecule / triplet passes of step 5 and 6 only share
+    //     inputs: with the direct scatter the whole of 5b goes to the second stream and is joined at the end of the call
+    //     (the ledger then books 5b + 5 + 5c + 6 as one span)
+    CrFork fork2(ctx);
+    DevBuf rep_b, packed_b;
+    const bool windowed = getenv("CRGPU_DUPINFO_WINDOWED") != nullptr;
+    if (vals && !windowed && CrFork::enabled(ctx, nd)) {
+        CR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        if (ctx->timing) {
+            fork2.t0 = cr_take_event(ctx);
+            fork2.t1 = cr_take_event(ctx);
+            CR_HIP(ctx, hipEventRecord(fork2.t0, ctx->stream));
+        }
+        CR_TRY(fork2.side(fork2.t0));
+    }
+    if (vals) {
+        CR_TRY(dmalloc(ctx, rep_b, nd * sizeof(uint32_t)));
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
+                           rep_b.as<uint32_t>());
+        // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): zeros
+        if (pr.packed_out) {
+            CR_HIP(ctx, hipMemsetAsync(pr.packed_out, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
+        } else {
+            if (pr.out_umi) CR_HIP(ctx, hipMemsetAsync(pr.out_umi, 0, pr.n_reads * sizeof(uint32_t), ctx->stream));
+            if (pr.out_cnt) CR_HIP(ctx, hipMemsetAsync(pr.out_cnt, 0, pr.n_reads * sizeof(uint32_t), ctx->stream));
+            if (pr.out_flags) CR_HIP(ctx, hipMemsetAsync(pr.out_flags, 0, pr.n_reads, ctx->stream));
+        }
+        // The direct scatter is the default.  CRGPU_DUPINFO_WINDOWED=1 takes the windowed one (k_per_read_sorted): measured at
+        // 1 B records it is SLOWER (dedup family 119-138 ms against 77 ms, profiles/r02_dupinfo_windowed_ab.txt): 512 windows of
+        // 2 M reads are 24 MB of output each, far beyond the 4 MB L2 of an XCD, and the three output arrays take three
+        // scattered stores per read instead of one.  Kept as a tested experiment for windows that fit the L2 (two levels).
+        bool direct = !windowed;
+        if (!direct) {
+            DevBuf prec_b, prec2_b, ord2_b;
+            CR_TRY(dmalloc(ctx, prec_b, n_keys * sizeof(uint64_t)));
+            CR_TRY(dmalloc(ctx, prec2_b, n_keys * sizeof(uint64_t)));
+            CR_TRY(dmalloc(ctx, ord2_b, n_keys * sizeof(uint32_t)));
+            uint32_t *d_over = ctx->d_scalars + 56, over = 0;
+            CR_HIP(ctx, hipMemsetAsync(d_over, 0, sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(k_per_read_sorted, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
+                               corr, inc_all, st, minidx, rep_b.as<uint32_t>(), prec_b.as<uint64_t>(), d_over, tf);
+            CR_HIP(ctx, hipGetLastError());
+            CR_TRY(read_u32(ctx, d_over, &over));
+            if (over) {
+                direct = true;
+            } else {
+                const uint32_t bits = cr_ceil_log2(pr.n_reads ? pr.n_reads : 1);
+                CR_TRY(cr_partition_by_payload(ctx, prec_b.as<uint64_t>(), prec2_b.as<uint64_t>(), vals, ord2_b.as<uint32_t>(), n_keys,
+                                               bits > 9 ? bits - 9 : 0));
+                hipLaunchKernelGGL(k_scatter_records, dim3(cr_grid(n_keys, 256)), dim3(256), 0, ctx->stream, prec2_b.as<uint64_t>(),
+                                   ord2_b.as<uint32_t>(), n_keys, pr.out_umi, pr.out_cnt, pr.out_flags, pr.packed_out);
+                CR_HIP(ctx, hipGetLastError());
+            }
+        }
+        if (direct) {
+            // our own temporary may use the 8-byte layout
+            const bool pack8 = !pr.packed_out && kl.bits_umi <= 24u && !getenv("CRGPU_DUPINFO_PACK12");
+            if (!pr.packed_out) {
+                const uint64_t bytes = pr.n_reads * (pack8 ? sizeof(DupRec8) : sizeof(DupRec));
+                CR_TRY(dmalloc(ctx, packed_b, bytes));
+                CR_HIP(ctx, hipMemsetAsync(packed_b.p, 0, bytes, ctx->stream));
+            }
+            DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
+            if (pack8)
+                hipLaunchKernelGGL(k_per_read<true>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
+                                   corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
+            else
+                hipLaunchKernelGGL(k_per_read<false>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
+                                   corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
+            if (!pr.packed_out) {
+                if (pack8)
+                    hipLaunchKernelGGL(k_unpack_dupinfo<true>, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream,
+                                       (const void *)packed, pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
+                else
+                    hipLaunchKernelGGL(k_unpack_dupinfo<false>, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream,
+                                       (const void *)packed, pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
+            }
+            CR_HIP(ctx, hipGetLastError());
+        }
+    }
+    fork2.pause();  // the rest of the call is enqueued on the main stream again; joined before the return
+
     // 5. molecules = distinct keys some read lands on and that are not low support; with them, in the same two launches,
     //    the (barcode, feature) triplets (6.): CRGPU_MOL_FUSED=0 keeps the separate passes (the A/B path)
     DevBuf mkeys_b, mreads_b, tpos_b;
     CR_TRY(dmalloc(ctx, mkeys_b, nd * sizeof(uint64_t)));
     CR_TRY(dmalloc(ctx, mreads_b, nd * sizeof(uint32_t)));
     uint32_t nm32 = 0, nt32 = 0;
-    const TargetFilter tf{ctx->d_on_target, ctx->n_target_features, L.sh_feat(), L.bits_feat, ctx->d_on_target ? ctx->target_min_reads : 0};
     const char *fused_env = getenv("CRGPU_MOL_FUSED");
     const bool fused = nd > 0 && !(fused_env && fused_env[0] == '0');
     if (fused) {
@@ -2009,76 +2096,6 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     }
     if (!fused) CR_TRY(read_u32(ctx, d_total, &nm32));
     const uint64_t nm = nm32;
-
-    // 5b. optional per-read DupInfo
-    if (vals) {
-        DevBuf rep_b;
-        CR_TRY(dmalloc(ctx, rep_b, nd * sizeof(uint32_t)));
-        CrTimer t(ctx, CRGPU_T_DEDUP);
-        hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
-                           rep_b.as<uint32_t>());
-        // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): zeros
-        if (pr.packed_out) {
-            CR_HIP(ctx, hipMemsetAsync(pr.packed_out, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
-        } else {
-            if (pr.out_umi) CR_HIP(ctx, hipMemsetAsync(pr.out_umi, 0, pr.n_reads * sizeof(uint32_t), ctx->stream));
-            if (pr.out_cnt) CR_HIP(ctx, hipMemsetAsync(pr.out_cnt, 0, pr.n_reads * sizeof(uint32_t), ctx->stream));
-            if (pr.out_flags) CR_HIP(ctx, hipMemsetAsync(pr.out_flags, 0, pr.n_reads, ctx->stream));
-        }
-        // The direct scatter is the default.  CRGPU_DUPINFO_WINDOWED=1 takes the windowed one (k_per_read_sorted): measured at
-        // 1 B records it is SLOWER (dedup family 119-138 ms against 77 ms, profiles/r02_dupinfo_windowed_ab.txt): 512 windows of
-        // 2 M reads are 24 MB of output each, far beyond the 4 MB L2 of an XCD, and the three output arrays take three
-        // scattered stores per read instead of one.  Kept as a tested experiment for windows that fit the L2 (two levels).
-        bool direct = getenv("CRGPU_DUPINFO_WINDOWED") == nullptr;
-        if (!direct) {
-            DevBuf prec_b, prec2_b, ord2_b;
-            CR_TRY(dmalloc(ctx, prec_b, n_keys * sizeof(uint64_t)));
-            CR_TRY(dmalloc(ctx, prec2_b, n_keys * sizeof(uint64_t)));
-            CR_TRY(dmalloc(ctx, ord2_b, n_keys * sizeof(uint32_t)));
-            uint32_t *d_over = ctx->d_scalars + 56, over = 0;
-            CR_HIP(ctx, hipMemsetAsync(d_over, 0, sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(k_per_read_sorted, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
-                               corr, inc_all, st, minidx, rep_b.as<uint32_t>(), prec_b.as<uint64_t>(), d_over, tf);
-            CR_HIP(ctx, hipGetLastError());
-            CR_TRY(read_u32(ctx, d_over, &over));
-            if (over) {
-                direct = true;
-            } else {
-                const uint32_t bits = cr_ceil_log2(pr.n_reads ? pr.n_reads : 1);
-                CR_TRY(cr_partition_by_payload(ctx, prec_b.as<uint64_t>(), prec2_b.as<uint64_t>(), vals, ord2_b.as<uint32_t>(), n_keys,
-                                               bits > 9 ? bits - 9 : 0));
-                hipLaunchKernelGGL(k_scatter_records, dim3(cr_grid(n_keys, 256)), dim3(256), 0, ctx->stream, prec2_b.as<uint64_t>(),
-                                   ord2_b.as<uint32_t>(), n_keys, pr.out_umi, pr.out_cnt, pr.out_flags, pr.packed_out);
-                CR_HIP(ctx, hipGetLastError());
-            }
-        }
-        if (direct) {
-            DevBuf packed_b;
-            // our own temporary may use the 8-byte layout
-            const bool pack8 = !pr.packed_out && kl.bits_umi <= 24u && !getenv("CRGPU_DUPINFO_PACK12");
-            if (!pr.packed_out) {
-                const uint64_t bytes = pr.n_reads * (pack8 ? sizeof(DupRec8) : sizeof(DupRec));
-                CR_TRY(dmalloc(ctx, packed_b, bytes));
-                CR_HIP(ctx, hipMemsetAsync(packed_b.p, 0, bytes, ctx->stream));
-            }
-            DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
-            if (pack8)
-                hipLaunchKernelGGL(k_per_read<true>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
-                                   corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
-            else
-                hipLaunchKernelGGL(k_per_read<false>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
-                                   corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
-            if (!pr.packed_out) {
-                if (pack8)
-                    hipLaunchKernelGGL(k_unpack_dupinfo<true>, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream,
-                                       (const void *)packed, pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
-                else
-                    hipLaunchKernelGGL(k_unpack_dupinfo<false>, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream,
-                                       (const void *)packed, pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
-            }
-            CR_HIP(ctx, hipGetLastError());
-        }
-    }
 
     // 5c. optional: reads with a corrected UMI per (library, barcode) -- the one BarcodeSummary column that cannot be
     //     derived from the molecule table afterwards
@@ -2126,6 +2143,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
                                tpos_b.as<uint32_t>(), nt, nm, res->d_bc, res->d_feature, res->d_count);
         CR_HIP(ctx, hipGetLastError());
     }
+    CR_TRY(fork2.join());
     res->n_triplets = nt;
     res->n_molecules = nm;
     res->d_mkeys = (uint64_t *)mkeys_b.p;
