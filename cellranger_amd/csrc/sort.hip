@@ -15,6 +15,7 @@
 //   k_radix_scatter  stable scatter; each block derives its digit bases from the digit totals
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "block_utils.h"
@@ -233,15 +234,22 @@ extern "C" int crgpu_debug_sort_phases(unsigned long long *out16) {
 #ifndef OS_GROUP
 #define OS_GROUP 8u  // consecutive chunks handed to one XCD
 #endif
-template <typename K, bool HAS_VALS, typename DIG, int BITS, bool ONESWEEP = false>
+// ST32: status words of 32 bits (flag in the top two, counts below 2^30) for sorts of fewer than 2^30 keys -- the look-back
+// reads ~21 predecessor rows per chunk (scripts/sort_phases.py), a third of the bytes of the keys themselves with 64-bit
+// words: 25.8 -> 24.9 ms for the seven passes over 796 M keys.
+template <typename K, bool HAS_VALS, typename DIG, int BITS, bool ONESWEEP = false, bool ST32 = false>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
                                                               uint32_t *__restrict__ vals_out, uint64_t n, uint64_t tile,
                                                               DIG dig, const uint32_t *__restrict__ block_offs,
                                                               const uint32_t *__restrict__ digit_totals,
-                                                              uint32_t n_blocks, unsigned long long *__restrict__ status,
+                                                              uint32_t n_blocks, unsigned long long *__restrict__ status_,
                                                               uint32_t *__restrict__ ticket, uint32_t *__restrict__ abort_word,
                                                               uint32_t pass_tag) {
+    using os_word = typename std::conditional<ST32, uint32_t, unsigned long long>::type;
+    constexpr int OS_FSHIFT = ST32 ? 30 : 62;
+    constexpr os_word W_AGG = (os_word)1 << OS_FSHIFT, W_INC = (os_word)2 << OS_FSHIFT, W_VAL = W_AGG - (os_word)1;
+    os_word *__restrict__ status = reinterpret_cast<os_word *>(status_);
     constexpr int ITEMS = SortCfg<K, HAS_VALS>::ITEMS;
     constexpr uint32_t CHUNK = SortCfg<K, HAS_VALS>::CHUNK;
     constexpr uint32_t RADIX_T = 1u << BITS;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                 for (int w = 0; w < SORT_WAVES; w++) tot += wcount[w][tid];
             // (pass_tag bit 31: test switch CRGPU_SORT_FORCE_ABORT -- chunk 0 never publishes, the chain stalls)
             if (ONESWEEP && tid < RADIX_T && !((pass_tag >> 31) && cidx == 0))  // let the successors go on as early as possible
-                __hip_atomic_store(&status[cidx * RADIX_T + tid], (cidx == 0 ? OS_INC : OS_AGG) | tot, __ATOMIC_RELAXED,
+                __hip_atomic_store(&status[cidx * RADIX_T + tid], (cidx == 0 ? W_INC : W_AGG) | (os_word)tot, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             uint32_t run = block_excl_scan<SORT_BLOCK>(tot, lds, nullptr);  // chunk-local start of digit tid
             run0 = run;
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         if (tid < RADIX_T) {
             uint32_t g;
             if (ONESWEEP) {
-                unsigned long long excl = 0;
+                os_word excl = 0;
                 if (cidx > 0) {
                     // Watchdog: the chain cannot stall as long as every XCD receives workgroups (each of them takes its
                     // XCD's chunks in ascending order).  Should that ever not hold (CU masking, a shared device), a waiter
@@ -390,16 +398,22 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                     // chunks, and the host redoes the sort from this pass on with the classic kernels -- no hung GPU,
                     // no failed call.
                     const uint32_t poll_limit = (pass_tag >> 31) ? (1u << 16) : (1u << 22);  // the forced stall need not take seconds
-                    auto wait_for = [&](uint64_t c, unsigned long long sv) {
+#ifdef SORT_PHASE_TIMING
+                    uint32_t ph_polls = 0, ph_depth = 0;
+#endif
+                    auto wait_for = [&](uint64_t c, os_word sv) {
                         uint32_t polls = 0;
-                        while ((sv >> 62) == 0ull) {
+                        while ((sv >> OS_FSHIFT) == 0) {
                             __builtin_amdgcn_s_sleep(1);
                             sv = __hip_atomic_load(&status[c * RADIX_T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SORT_PHASE_TIMING
+                            ph_polls++;
+#endif
                             if ((++polls & 0xFFFu) == 0u) {
                                 if (polls >= poll_limit) atomicCAS(abort_word, 0u, pass_tag & 0x7FFFFFFFu);
                                 if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                                     *s_abort = 1u;
-                                    return OS_INC;
+                                    return W_INC;
                                 }
                             }
                         }
@@ -413,23 +427,33 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                     bool done = false;
                     while (!done) {
                         const uint32_t nb = p < SORT_LB ? (uint32_t)p : (uint32_t)SORT_LB;
-                        unsigned long long v[SORT_LB];
+                        os_word v[SORT_LB];
 #pragma unroll
                         for (uint32_t j = 0; j < SORT_LB; j++)
                             v[j] = j < nb ? __hip_atomic_load(&status[(p - 1 - j) * RADIX_T + tid], __ATOMIC_RELAXED,
                                                               __HIP_MEMORY_SCOPE_AGENT)
-                                          : 0ull;
+                                          : (os_word)0;
 #pragma unroll
                         for (uint32_t j = 0; j < SORT_LB; j++) {
                             if (done || j >= nb) continue;
-                            const unsigned long long x = wait_for(p - 1 - j, v[j]);
-                            excl += x & OS_VAL;
-                            done = (x >> 62) == 2ull;
+                            const os_word x = wait_for(p - 1 - j, v[j]);
+#ifdef SORT_PHASE_TIMING
+                            ph_depth++;
+#endif
+                            excl += x & W_VAL;
+                            done = (x >> OS_FSHIFT) == 2;
                         }
                         p -= nb;
                     }
-                    __hip_atomic_store(&status[cidx * RADIX_T + tid], OS_INC | (excl + tot), __ATOMIC_RELAXED,
+                    __hip_atomic_store(&status[cidx * RADIX_T + tid], W_INC | (os_word)(excl + tot), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SORT_PHASE_TIMING
+                    if (tid == 0) {  // [11] polls of statuses that were not published yet, [12] predecessors walked, [13] chunks
+                        atomicAdd(&g_sort_phase[11], (unsigned long long)ph_polls);
+                        atomicAdd(&g_sort_phase[12], (unsigned long long)ph_depth);
+                        atomicAdd(&g_sort_phase[13], 1ull);
+                    }
+#endif
                 }
                 g = digit_totals[tid] + (uint32_t)excl;
             } else {
@@ -612,6 +636,8 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     }
     uint64_t *in = d_keys, *out = d_tmp;
     uint32_t *vin = d_vals, *vout = d_vals_tmp;
+    static const bool st64_forced = getenv("CRGPU_SORT_STATUS64") != nullptr;  // A/B and test switch
+    const bool st32 = n < (1ull << 30) && !st64_forced;
     for (uint32_t p = 0; p < plan.n_passes && e == hipSuccess; p++) {
         const bool wide = widths[p] == 9;
         const size_t lds = Cfg::lds_bytes(wide ? 9 : 8);
@@ -619,21 +645,22 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
         RadixDigit dig{plan.shift[p], plan.mask[p]};
         const uint32_t tag = (p + 1u) | ((int)p == force_pass && n_chunks > 1 ? 0x80000000u : 0u);
         CrTimer t(ctx, CRGPU_T_SORT, n);
-        e = hipMemsetAsync(d_status, 0, n_chunks * radix * sizeof(unsigned long long), ctx->stream);
+        e = hipMemsetAsync(d_status, 0, n_chunks * radix * (st32 ? sizeof(uint32_t) : sizeof(unsigned long long)), ctx->stream);
         // one workgroup fits per CU, the rest queue up for tickets.  With per-XCD tickets every XCD must receive
         // workgroups whatever the dispatcher's rotation: always the full grid (idle workgroups leave after one atomic)
         const dim3 grid((unsigned)(n_xcc > 1 || n_chunks > 512 ? 512 : n_chunks));
-        if (wide) {
-            cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 9, true>, lds);
-            hipLaunchKernelGGL((k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 9, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
-                               out, vin, vout, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
-                               (unsigned long long *)d_status, tickets + p * 16 * 32, d_abort, tag);
-        } else {
-            cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 8, true>, lds);
-            hipLaunchKernelGGL((k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, 8, true>), grid, dim3(SORT_BLOCK), lds, ctx->stream, in,
-                               out, vin, vout, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,
-                               (unsigned long long *)d_status, tickets + p * 16 * 32, d_abort, tag);
-        }
+#define OS_LAUNCH(BITS_, ST32_)                                                                                                     \
+    do {                                                                                                                            \
+        cr_allow_lds(ctx, (const void *)k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, BITS_, true, ST32_>, lds);                  \
+        hipLaunchKernelGGL((k_radix_scatter<uint64_t, HAS_VALS, RadixDigit, BITS_, true, ST32_>), grid, dim3(SORT_BLOCK), lds,     \
+                           ctx->stream, in, out, vin, vout, n, 0, dig, nullptr, ghist + p * RADIX_MAX, n_xcc,                       \
+                           (unsigned long long *)d_status, tickets + p * 16 * 32, d_abort, tag);                                    \
+    } while (0)
+        if (wide && st32) OS_LAUNCH(9, true);
+        else if (wide) OS_LAUNCH(9, false);
+        else if (st32) OS_LAUNCH(8, true);
+        else OS_LAUNCH(8, false);
+#undef OS_LAUNCH
         if (e == hipSuccess) e = hipGetLastError();
         uint64_t *t2 = in;
         in = out;

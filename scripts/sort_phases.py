@@ -38,6 +38,10 @@ def main():
         c.synchronize()
         assert lib.crgpu_debug_sort_phases(out) == 0
     v = np.array(list(out), dtype=np.float64)
+    chunks = max(v[13], 1.0)
+    print("look-back of digit 0, per chunk: %.2f polls of unpublished statuses, %.2f predecessors walked (%d chunks)"
+          % (v[11] / chunks, v[12] / chunks, int(v[13])))
+    v = v[:11]
     tot = v.sum()
     print("n_keys %d, ticks per chunk and workgroup summed over all passes: %.3g" % (nk, tot))
     for i, name in enumerate(NAMES):
