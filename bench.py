@@ -240,6 +240,8 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node: the id exchange stays on the loopback interface (the container's hostname need not resolve)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         box = [E.get_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)

@@ -237,6 +237,18 @@ extern "C" int crgpu_debug_sort_phases(unsigned long long *out16) {
 // ST32: status words of 32 bits (flag in the top two, counts below 2^30) for sorts of fewer than 2^30 keys -- the look-back
 // reads ~21 predecessor rows per chunk (scripts/sort_phases.py), a third of the bytes of the keys themselves with 64-bit
 // words: 25.8 -> 24.9 ms for the seven passes over 796 M keys.
+__device__ __forceinline__ uint32_t take_ticket_fn(uint32_t *abort_word, uint32_t *ticket, uint32_t n_xcc) {
+    uint32_t xcc = 0;
+    if (n_xcc > 1) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xFu;
+        if (xcc >= n_xcc) xcc %= n_xcc;
+    }
+    const uint32_t ab = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k = atomicAdd(ticket + xcc * 32u, 1u);
+    const uint32_t c = n_xcc > 1 ? ((k / OS_GROUP) * n_xcc + xcc) * OS_GROUP + (k % OS_GROUP) : k;
+    return ab != 0u ? 0xFFFFFFFFu : c;
+}
 template <typename K, bool HAS_VALS, typename DIG, int BITS, bool ONESWEEP = false, bool ST32 = false>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
@@ -279,6 +291,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
 #ifdef SORT_PHASE_TIMING
     unsigned long long ph_t = __builtin_readcyclecounter();
 #endif
+    bool have_next = false;  // ONESWEEP: *s_chunk already holds the ticket of the chunk to come
     for (uint64_t chunk = lo;; chunk += CHUNK) {
         uint64_t cidx = 0;
         if (ONESWEEP) {
@@ -291,19 +304,17 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             // abort_word (shared by all passes of one sort): 0, or 1 + the pass whose look-back watchdog fired.  Once it is
             // set nobody takes another chunk -- of this pass or of the passes queued behind it -- so the buffers stay as
             // the failed pass found them and the host redoes the sort from that pass on with the classic kernels.
-            if (tid == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                *s_chunk = 0xFFFFFFFFu;
-            } else if (tid == 0) {
-                uint32_t xcc = 0;
-                if (n_blocks > 1) {
-                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                    xcc &= 0xFu;
-                    if (xcc >= n_blocks) xcc %= n_blocks;
-                }
-                const uint32_t k = atomicAdd(ticket + xcc * 32u, 1u);
-                *s_chunk = n_blocks > 1 ? ((k / OS_GROUP) * n_blocks + xcc) * OS_GROUP + (k % OS_GROUP) : k;
+            // (the abort word and the ticket are requested together: two dependent round trips were 6 % of a chunk's time;
+            // a ticket taken after an abort is harmless -- nobody works on it and the redo does not use tickets)
+            // Every chunk but a workgroup's first gets its ticket while the chunk before it is copied out (thread 0 asks before
+            // the copy-out loop and puts the value into *s_chunk behind it): all workgroups shift alike, so nobody waits longer
+            // for a predecessor (24.8 -> 24.2 ms for seven passes over 796 M keys).  Requesting the next chunk's KEYS there as
+            // well, into the registers the LDS scatter has freed, costs 45 % (36 ms; profiles/r02_sort_phases.txt) -- the second
+            // time this was measured: reads issued in front of the copy-out stores hold the stores up.
+            if (!have_next) {
+                if (tid == 0) *s_chunk = take_ticket_fn(abort_word, ticket, n_blocks);
+                __syncthreads();
             }
-            __syncthreads();
             cidx = *s_chunk;
             if (cidx >= n_chunks) break;  // uniform
             chunk = cidx * CHUNK;
@@ -466,12 +477,18 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
         __syncthreads();
         SORT_PH(8);  // look-back of all digits
         if (ONESWEEP && *s_abort) break;  // uniform: nothing of this chunk is written, the pass is redone
+        // the next ticket travels during the copy-out (everybody read this chunk's ticket at the top of the loop)
+        uint32_t next_ticket = 0;
+        if (ONESWEEP && tid == 0) next_ticket = take_ticket_fn(abort_word, ticket, n_blocks);
         for (uint32_t p = tid; p < chunk_n; p += SORT_BLOCK) {
             const K k = skeys[p];
             const uint32_t pos = p + gdelta[dig(k, HAS_VALS ? svals[p] : 0u)];
             SORT_STORE_OUT(k, &keys_out[pos]);
             if (HAS_VALS) vals_out[pos] = svals[p];
         }
+        if (ONESWEEP && tid == 0) *s_chunk = next_ticket;
+        have_next = true;
+
         SORT_PH(9);  // copy-out issued
         __syncthreads();
         SORT_PH(10);  // everybody's copy-out issued
