@@ -309,7 +309,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
             // Every chunk but a workgroup's first gets its ticket while the chunk before it is copied out (thread 0 asks before
             // the copy-out loop and puts the value into *s_chunk behind it): all workgroups shift alike, so nobody waits longer
             // for a predecessor (24.8 -> 24.2 ms for seven passes over 796 M keys).  Requesting the next chunk's KEYS there as
-            // well, into the registers the LDS scatter has freed, costs 45 % (36 ms; profiles/r02_sort_phases.txt) -- the second
+            // well, into the registers the LDS scatter has freed, costs 45 % (36 ms; profiles/r02_b_sort_phases_and_streams.txt) -- the second
             // time this was measured: reads issued in front of the copy-out stores hold the stores up.
             if (!have_next) {
                 if (tid == 0) *s_chunk = take_ticket_fn(abort_word, ticket, n_blocks);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restric
                         return sv;
                     };
                     // SORT_LB statuses per round trip (the loads of a round are independent).  Wider rounds are SLOWER: 16 per
-                    // round +1.0 ms, 32 per round +3.1 ms for the seven passes over 796 M keys (profiles/r02_sort_phases.txt)
+                    // round +1.0 ms, 32 per round +3.1 ms for the seven passes over 796 M keys (profiles/r02_b_sort_phases_and_streams.txt)
                     // -- every status word read crosses the fabric (other XCDs wrote it), and a round of 32 reads as many
                     // bytes as the chunk's own keys.
                     uint64_t p = cidx;  // chunks [0, p) are still to be added; chunk 0 always carries an inclusive prefix
