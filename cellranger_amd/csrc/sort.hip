@@ -234,9 +234,7 @@ extern "C" int crgpu_debug_sort_phases(unsigned long long *out16) {
 #ifndef OS_GROUP
 #define OS_GROUP 8u  // consecutive chunks handed to one XCD
 #endif
-// ST32: status words of 32 bits (flag in the top two, counts below 2^30) for sorts of fewer than 2^30 keys -- the look-back
-// reads ~21 predecessor rows per chunk (scripts/sort_phases.py), a third of the bytes of the keys themselves with 64-bit
-// words: 25.8 -> 24.9 ms for the seven passes over 796 M keys.
+// the ticket of a workgroup's next chunk: a counter per XCD (n_xcc > 1) or one global sequence; 0xFFFFFFFF once a pass has aborted
 __device__ __forceinline__ uint32_t take_ticket_fn(uint32_t *abort_word, uint32_t *ticket, uint32_t n_xcc) {
     uint32_t xcc = 0;
     if (n_xcc > 1) {
@@ -249,6 +247,9 @@ __device__ __forceinline__ uint32_t take_ticket_fn(uint32_t *abort_word, uint32_
     const uint32_t c = n_xcc > 1 ? ((k / OS_GROUP) * n_xcc + xcc) * OS_GROUP + (k % OS_GROUP) : k;
     return ab != 0u ? 0xFFFFFFFFu : c;
 }
+// ST32: status words of 32 bits (flag in the top two, counts below 2^30) for sorts of fewer than 2^30 keys -- the look-back
+// reads ~21 predecessor rows per chunk (scripts/sort_phases.py), a third of the bytes of the keys themselves with 64-bit
+// words: 25.8 -> 24.9 ms for the seven passes over 796 M keys.
 template <typename K, bool HAS_VALS, typename DIG, int BITS, bool ONESWEEP = false, bool ST32 = false>
 __global__ __launch_bounds__(SORT_BLOCK) void k_radix_scatter(const K *__restrict__ keys_in, K *__restrict__ keys_out,
                                                               const uint32_t *__restrict__ vals_in,
