@@ -29,7 +29,8 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *ld
 }
 
 // Same for a workgroup of THREADS threads (a multiple of 64, at most 1024).  `lds` >= THREADS/64 uint32.
-template <uint32_t THREADS>
+// TRAILING_BARRIER = false: the caller guarantees a barrier of its own before anybody writes `lds` again.
+template <uint32_t THREADS, bool TRAILING_BARRIER = true>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds, uint32_t *total_out) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t x = v;
@@ -47,7 +48,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds, u
         if (w < wave) wpre += t;
         tot += t;
     }
-    __syncthreads();
+    if (TRAILING_BARRIER) __syncthreads();
     if (total_out) *total_out = tot;
     return wpre + x - v;
 }
