@@ -298,6 +298,14 @@ def test_barcode_summary_csv(tmp_path):
     assert lines[1:-1] == want
     assert int(rows["reads"].sum()) == int((dev["idx"].to_host() != E.MISS).sum())
 
+def _needs_onesweep():
+    """The tests of the onesweep machinery itself (watchdog fallback, finishing passes) assert on its counters: they have no
+    meaning in a run of the suite that forces the classic three-kernel passes (CRGPU_SORT=classic)."""
+    import os
+
+    if os.environ.get("CRGPU_SORT") == "classic":
+        pytest.skip("CRGPU_SORT=classic: the onesweep path under test is switched off")
+
 
 @pytest.mark.parametrize("big_run,top_bits_sort", [(50_000, False), (50_000, True), (90_000, True)])
 def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, top_bits_sort, monkeypatch):
@@ -307,6 +315,8 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, top_bits_s
     top_bits_sort (CRGPU_SORT_FINISH=2): the sort leaves the lowest key bits to k_order_runs -- runs inside a wave by an
     odd-even transposition in registers, longer ones through memory (insertion up to 32 keys, in-place bucket permutation up
     to 65 536), and a run of 90 000 keys makes it hand the job back to a sort on all bits (CRGPU_STAT_SORT_REFINISHED)."""
+    if top_bits_sort:
+        _needs_onesweep()
     import gpu_helpers as G
 
     if top_bits_sort:
@@ -381,6 +391,7 @@ def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, monkeypatc
     The watchdog raises the abort word, that pass and the ones queued behind it write nothing, and the host finishes the
     sort from the failed pass on with the classic histogram / scan / scatter passes inside the same call: the call
     succeeds and its results are identical to an undisturbed run."""
+    _needs_onesweep()
     import gpu_helpers as G
     from cellranger_amd import synth as S
 
@@ -440,6 +451,7 @@ def test_finishing_pass_hands_long_runs_back_to_the_full_sort(monkeypatch):
     One (barcode, feature) whose UMIs all share their leading bases makes a run far longer than the finishing pass
     stages (FIN_RUN_MAX): the sort must notice, redo the buffer on all key bits, and give the same molecules as the
     plain seven / eight-pass sort (CRGPU_SORT_FINISH=0) -- checked through the oracle."""
+    _needs_onesweep()
     import gpu_helpers as G
     import oracle_lib as O
     from cellranger_amd import engine as E
