@@ -724,12 +724,23 @@ __device__ __forceinline__ uint32_t st_inc1(uint32_t s) { return s >> 2; }
 __device__ __forceinline__ void st_or(uint16_t *st, uint64_t k, uint32_t bits) {
     atomicOr(reinterpret_cast<uint32_t *>(st) + (k >> 1), bits << (16u * (uint32_t)(k & 1u)));
 }
-__device__ __forceinline__ void move_reads(uint32_t *corr, uint16_t *st, uint32_t *inc_all, uint64_t k, uint32_t target,
-                                           uint32_t my_cnt) {
+// minidx[K] (set to all ones) = the smallest raw key corrected onto K.  The representative-read rule (mark_dups.rs:248-268)
+// takes the lexicographically smallest raw UMI R corrected onto K among those with (R < K or K itself corrected away); R and K
+// lie in one (barcode, feature, library) segment where the distinct keys are sorted by UMI, so UMI order is index order, and
+// the smallest qualifying R is the smallest R of all whenever one qualifies: K corrected away -> every R qualifies; otherwise an
+// R < K exists exactly when the smallest R is below K.  The readers apply that test (rep_source); a separate pass over all
+// distinct keys (k_rep_utype, 0.75 ms per 1 B reads on the critical path) used to apply it before the atomicMin.
+__device__ __forceinline__ void move_reads(uint32_t *corr, uint16_t *st, uint32_t *inc_all, uint32_t *minidx, uint64_t k,
+                                           uint32_t target, uint32_t my_cnt) {
     corr[k] = target;
     st_or(st, k, ST_CORRECTED);
     atomicAdd(reinterpret_cast<uint32_t *>(st) + (target >> 1), 4u << (16u * (target & 1u)));  // inc1[target] += 1
     atomicAdd(&inc_all[target], my_cnt);
+    atomicMin(&minidx[target], (uint32_t)k);
+}
+// the raw key whose representative read stands for target K (state word sK), or NONE32: K's own reads do
+__device__ __forceinline__ uint32_t rep_source(uint32_t min_raw, uint32_t K, uint32_t sK) {
+    return (min_raw != 0xFFFFFFFFu && (min_raw < K || (sK & ST_CORRECTED))) ? min_raw : 0xFFFFFFFFu;
 }
 
 // ---- functors --------------------------------------------------------------------------------------
@@ -822,7 +833,7 @@ struct EmitMol {
         uint32_t inc = 0u, mi = NONE32;
         if (st_inc1(p.s)) {
             inc = inc_all[k];
-            mi = minidx[k];
+            mi = rep_source(minidx[k], (uint32_t)k, p.s);
         }
         const uint64_t bit = (mi != NONE32 ? ukey[mi] : p.key) & 1ull;
         mkeys[o] = (p.key & ~1ull) | bit;
@@ -1199,33 +1210,6 @@ __device__ __forceinline__ uint32_t run_count(const uint32_t *__restrict__ upos,
 
 #include "umi_correct.h"
 
-// Representative-read bookkeeping (mark_dups.rs:248-268): for a corrected key K the representative
-// is the min-(utype, qname) read of the lexicographically smallest raw UMI R corrected onto K with
-// (R < K or K itself corrected away).  R and K lie in one (barcode, feature, library) segment, where the distinct keys
-// are sorted by UMI: the smallest such R is the smallest INDEX, kept by a 32-bit atomicMin in minidx[K].
-__global__ __launch_bounds__(256) void k_rep_utype(const uint64_t *__restrict__ ukey, uint64_t nd,
-                                                   const uint32_t *__restrict__ corr, const uint16_t *__restrict__ st,
-                                                   uint32_t *__restrict__ minidx) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 8;
-    // 8 keys per thread per round: the state loads are all issued before the first one is looked at (only ~2 % of
-    // the keys are corrected and take the dependent loads)
-    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x * 8; base < nd; base += stride) {
-        uint32_t t[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint64_t k = base + (uint64_t)j * blockDim.x + threadIdx.x;
-            t[j] = st[k < nd ? k : nd - 1];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint64_t k = base + (uint64_t)j * blockDim.x + threadIdx.x;
-            if (k >= nd || !(t[j] & ST_CORRECTED)) continue;
-            const uint32_t tgt = corr[k];
-            if (k < tgt || (st[tgt] & ST_CORRECTED)) atomicMin(&minidx[tgt], (uint32_t)k);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // low-support filter (determine_low_support_umigenes, mark_dups.rs:87-108)
 // ------------------------------------------------------------------------------------------------
@@ -1491,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_per_read(const KL kl, const uint64_t *_
         const bool is_target = st_inc1(sK) != 0u;
         const uint32_t read_count = ((sK & ST_CORRECTED) ? 0u : cntK) + (is_target ? inc_all[K] : 0u);  // umigene_counts[corrected_key]
         const uint32_t umi = (uint32_t)((ukey[K] >> kl.sh_umi) & lowmask(kl.bits_umi));
-        const uint32_t mi = is_target ? minidx[K] : NONE32;
+        const uint32_t mi = is_target ? rep_source(minidx[K], K, sK) : NONE32;
         const uint32_t rep_key = mi != NONE32 ? mi : K;  // umigene_min_key[corrected_key]
         const uint32_t rep = rep_read[rep_key];
         const bool lowK = (sK & ST_LOW) != 0u;
@@ -1565,7 +1549,7 @@ __global__ __launch_bounds__(256) void k_per_read_sorted(const KL kl, const uint
         const uint32_t read_count = ((sK & ST_CORRECTED) ? 0u : cntK) + (is_target ? inc_all[K] : 0u);
         if (read_count >> PR_COUNT_BITS) *overflow = 1u;
         const uint32_t umi = (uint32_t)((ukey[K] >> kl.sh_umi) & lowmask(kl.bits_umi));
-        const uint32_t mi = is_target ? minidx[K] : NONE32;
+        const uint32_t mi = is_target ? rep_source(minidx[K], K, sK) : NONE32;
         const uint32_t rep = rep_read[mi != NONE32 ? mi : K];
         const bool lowK = (sK & ST_LOW) != 0u;
         const bool filt = tf.filtered(ukey[K], read_count, lowK);
@@ -1890,7 +1874,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
 #define UC_GRID_WG 5u  // workgroups per CU: what LDS and registers allow (4 left a fifth of the CU idle: 4.39 -> 3.67 ms; 6 with 80 VGPRs: 4.2)
 #endif
         hipLaunchKernelGGL(k_correct_umis_tiled, dim3(cr_grid(n_tiles, 1, 256u * UC_GRID_WG)), dim3(256), 0, ctx->stream, kl, ukey,
-                           upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all);
+                           upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all, minidx);
         if (n_tiles > 1) {
             const size_t lds_small = (2 * UES_CAP + UES_BUCKETS * 8) * sizeof(uint32_t);
             const size_t lds_large = (2 * UE_CAP + UE_BUCKETS * 8) * sizeof(uint32_t);
@@ -1906,19 +1890,18 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             CR_HIP(ctx, hipMemsetAsync(n_giant, 0, sizeof(uint32_t), ctx->stream));
             hipLaunchKernelGGL(k_correct_umis_edges<true>, dim3(cr_grid(n_tiles - 1, 1, 256u * 6u)), dim3(UES_THREADS),
                                lds_small, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all,
-                               items, n_giant);
+                               minidx, items, n_giant);
             hipLaunchKernelGGL(k_correct_umis_edges<false>, dim3(cr_grid(n_tiles - 1, 1, 256u * 2u)), dim3(UE_THREADS),
                                lds_large, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all,
-                               items, n_giant);
+                               minidx, items, n_giant);
             // the three kernels loop over the device-side item count (usually a few hundred, often zero)
             hipLaunchKernelGGL(k_giant_init, dim3(512), dim3(UE_THREADS), 0, ctx->stream, kl, ukey, upos, nd, n_keys, items,
                                n_giant, best);
             hipLaunchKernelGGL(k_giant_probe, dim3(512), dim3(UE_THREADS), lds_large, ctx->stream, kl, ukey, upos, nd, n_keys,
                                items, n_giant, best);
             hipLaunchKernelGGL(k_giant_final, dim3(512), dim3(UE_THREADS), 0, ctx->stream, upos, nd, n_keys, items, n_giant, best,
-                               corr, st, inc_all);
+                               corr, st, inc_all, minidx);
         }
-        hipLaunchKernelGGL(k_rep_utype, dim3(cr_grid(nd, 256 * 8)), dim3(256), 0, ctx->stream, ukey, nd, corr, st, minidx);
         CR_HIP(ctx, hipGetLastError());
     }
 

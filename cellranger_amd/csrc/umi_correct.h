@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256, UC_MIN_WG) void k_correct_umis_tiled(const KL 
                                                             const uint32_t *__restrict__ upos, uint64_t nd,
                                                             uint64_t n_keys, uint32_t *__restrict__ tile_first,
                                                             uint32_t *__restrict__ tile_last, uint32_t *__restrict__ corr,
-                                                            uint16_t *__restrict__ st, uint32_t *__restrict__ inc_all) {
+                                                            uint16_t *__restrict__ st, uint32_t *__restrict__ inc_all,
+                                                            uint32_t *__restrict__ minidx) {
     __shared__ uint32_t s_umi[UC_TILE];
     __shared__ uint32_t s_cnt[UC_TILE];    // read count | UC_NOCORR
     __shared__ uint16_t s_start[UC_TILE];  // segment start inside the tile, UC_OPEN = not fully inside the tile
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256, UC_MIN_WG) void k_correct_umis_tiled(const KL 
                                                                               s_umi[p], my_cnt, sp);
                 if (bp != p) target = (uint32_t)(t0 + bp);
             }
-            if (target != NONE32) move_reads(corr, st, inc_all, k, target, my_cnt);
+            if (target != NONE32) move_reads(corr, st, inc_all, minidx, k, target, my_cnt);
         }
         __syncthreads();
         if (s_any_long) {
@@ -336,7 +337,7 @@ template <bool SMALL>
 __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
     const KL kl, const uint64_t *__restrict__ ukey, const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
     const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_last, uint32_t *__restrict__ corr,
-    uint16_t *__restrict__ st, uint32_t *__restrict__ inc_all, GiantItem *__restrict__ giant_items,
+    uint16_t *__restrict__ st, uint32_t *__restrict__ inc_all, uint32_t *__restrict__ minidx, GiantItem *__restrict__ giant_items,
     uint32_t *__restrict__ n_giant) {
     constexpr uint32_t UE_T = EdgeCfg<SMALL>::THREADS, CAP = EdgeCfg<SMALL>::CAP, BUCKETS = EdgeCfg<SMALL>::BUCKETS,
                        POSBITS = EdgeCfg<SMALL>::POSBITS;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
                 const uint32_t my_cnt = s_cnt[p];
                 const uint32_t bp = best_neighbour_lds<BUCKETS, POSBITS>(s_umi, s_cnt, s_hash, nullptr, 0u, mm, 0u, p,
                                                                               s_umi[p], my_cnt, sp);
-                if (bp != p) move_reads(corr, st, inc_all, s + p, (uint32_t)(s + bp), my_cnt);
+                if (bp != p) move_reads(corr, st, inc_all, minidx, s + p, (uint32_t)(s + bp), my_cnt);
             }
             __syncthreads();
             continue;
@@ -504,14 +505,14 @@ __global__ __launch_bounds__(UE_THREADS) void k_giant_final(const uint32_t *__re
                                                             const uint32_t *__restrict__ n_items_ptr,
                                                             const unsigned long long *__restrict__ best,
                                                             uint32_t *__restrict__ corr, uint16_t *__restrict__ st,
-                                                            uint32_t *__restrict__ inc_all) {
+                                                            uint32_t *__restrict__ inc_all, uint32_t *__restrict__ minidx) {
     const uint32_t n_items = *n_items_ptr;
     for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
         const GiantItem g = items[it];
         const uint64_t c1 = (uint64_t)g.c0 + UE_CAP < g.e ? (uint64_t)g.c0 + UE_CAP : g.e;
         for (uint64_t k = g.c0 + threadIdx.x; k < c1; k += UE_THREADS) {
             const uint32_t target = (uint32_t)best[k];
-            if (target != (uint32_t)k) move_reads(corr, st, inc_all, k, target, run_count(upos, nd, n_keys, k));
+            if (target != (uint32_t)k) move_reads(corr, st, inc_all, minidx, k, target, run_count(upos, nd, n_keys, k));
         }
     }
 }
