@@ -26,7 +26,7 @@ def family(k):
     if any(x in k for x in ("k_lookup_hot", "k_stage_idx", "k_hist_buckets", "k_match_binned", "k_hot_", "k_match<")): return "match"
     if any(x in k for x in ("k_correct_records", "k_collect_miss", "k_correct<", "k_region_offsets")): return "correct"
     if any(x in k for x in ("k_csc", "SeenFlag")): return "matrix"
-    if any(x in k for x in ("k_cp_", "k_correct_umis", "k_giant", "k_group_", "k_low_support", "k_triplets", "k_radix_scatter<unsigned int",
+    if any(x in k for x in ("k_cp_", "k_correct_umis", "k_giant", "k_rep_", "k_group_", "k_low_support", "k_triplets", "k_radix_scatter<unsigned int",
                             "k_radix_hist<unsigned int", "k_per_read", "k_unpack", "k_corrected_reads", "k_mt_", "k_rl_", "k_trip_counts")): return "dedup"
     return None
 kern, fam = [], collections.defaultdict(float)
