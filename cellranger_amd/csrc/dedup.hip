@@ -1980,10 +1980,15 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         // scattered stores per read instead of one.  Kept as a tested experiment for windows that fit the L2 (two levels).
         bool direct = !windowed;
         if (!direct) {
-            DevBuf prec_b, prec2_b, ord2_b;
+            // CRGPU_DUPINFO_WINDOWED=2: two stable partition passes (18 bits of the ordinal, low digit first) leave windows of
+            // 2^(bits - 18) reads -- 32 KB of output per array at 1 B reads, which the L2 merges into whole lines
+            const char *wenv = getenv("CRGPU_DUPINFO_WINDOWED");
+            const bool two_level = wenv && wenv[0] == '2';
+            DevBuf prec_b, prec2_b, ord2_b, ord3_b;
             CR_TRY(dmalloc(ctx, prec_b, n_keys * sizeof(uint64_t)));
             CR_TRY(dmalloc(ctx, prec2_b, n_keys * sizeof(uint64_t)));
             CR_TRY(dmalloc(ctx, ord2_b, n_keys * sizeof(uint32_t)));
+            if (two_level) CR_TRY(dmalloc(ctx, ord3_b, n_keys * sizeof(uint32_t)));
             uint32_t *d_over = ctx->d_scalars + 56, over = 0;
             CR_HIP(ctx, hipMemsetAsync(d_over, 0, sizeof(uint32_t), ctx->stream));
             hipLaunchKernelGGL(k_per_read_sorted, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
@@ -1994,10 +1999,19 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
                 direct = true;
             } else {
                 const uint32_t bits = cr_ceil_log2(pr.n_reads ? pr.n_reads : 1);
-                CR_TRY(cr_partition_by_payload(ctx, prec_b.as<uint64_t>(), prec2_b.as<uint64_t>(), vals, ord2_b.as<uint32_t>(), n_keys,
-                                               bits > 9 ? bits - 9 : 0));
-                hipLaunchKernelGGL(k_scatter_records, dim3(cr_grid(n_keys, 256)), dim3(256), 0, ctx->stream, prec2_b.as<uint64_t>(),
-                                   ord2_b.as<uint32_t>(), n_keys, pr.out_umi, pr.out_cnt, pr.out_flags, pr.packed_out);
+                if (two_level && bits > 18) {
+                    CR_TRY(cr_partition_by_payload(ctx, prec_b.as<uint64_t>(), prec2_b.as<uint64_t>(), vals, ord2_b.as<uint32_t>(), n_keys,
+                                                   bits - 18));
+                    CR_TRY(cr_partition_by_payload(ctx, prec2_b.as<uint64_t>(), prec_b.as<uint64_t>(), ord2_b.as<uint32_t>(),
+                                                   ord3_b.as<uint32_t>(), n_keys, bits - 9));
+                    hipLaunchKernelGGL(k_scatter_records, dim3(cr_grid(n_keys, 256)), dim3(256), 0, ctx->stream, prec_b.as<uint64_t>(),
+                                       ord3_b.as<uint32_t>(), n_keys, pr.out_umi, pr.out_cnt, pr.out_flags, pr.packed_out);
+                } else {
+                    CR_TRY(cr_partition_by_payload(ctx, prec_b.as<uint64_t>(), prec2_b.as<uint64_t>(), vals, ord2_b.as<uint32_t>(), n_keys,
+                                                   bits > 9 ? bits - 9 : 0));
+                    hipLaunchKernelGGL(k_scatter_records, dim3(cr_grid(n_keys, 256)), dim3(256), 0, ctx->stream, prec2_b.as<uint64_t>(),
+                                       ord2_b.as<uint32_t>(), n_keys, pr.out_umi, pr.out_cnt, pr.out_flags, pr.packed_out);
+                }
                 CR_HIP(ctx, hipGetLastError());
             }
         }

@@ -486,15 +486,16 @@ def test_finishing_pass_hands_long_runs_back_to_the_full_sort(monkeypatch):
     c.close()
 
 
+@pytest.mark.parametrize("levels", ["1", "2"])
 @pytest.mark.parametrize("n", [300_000, 2_000_000])
-def test_windowed_dupinfo_scatter_matches_the_oracle(n, monkeypatch):
+def test_windowed_dupinfo_scatter_matches_the_oracle(n, levels, monkeypatch):
     """The experimental windowed scatter of the per-read records (CRGPU_DUPINFO_WINDOWED=1: k_per_read_sorted ->
-    cr_partition_by_payload -> k_scatter_records): every read's DupInfo equals the oracle's, as the direct path's does in
-    the other tests."""
+    cr_partition_by_payload -> k_scatter_records; =2: two partition passes, windows of 2^(bits - 18) reads): every read's
+    DupInfo equals the oracle's, as the direct path's does in the other tests."""
     import gpu_helpers as G
     from cellranger_amd import synth as S
 
-    monkeypatch.setenv("CRGPU_DUPINFO_WINDOWED", "1")
+    monkeypatch.setenv("CRGPU_DUPINFO_WINDOWED", levels)
     w = S.Workload(n_total=n, seed=S.SEED0 + 9, n_wl=100_000, n_cells=300, n_ambient=20000, n_genes=2000)
     c = G.fresh_ctx()
     c.set_whitelist(0, w.wl_packed, length=16)
