@@ -41,6 +41,7 @@ class Records(C.Structure):
         ("d_feature", C.c_void_p),
         ("d_flags", C.c_void_p),
         ("d_umi_len", C.c_void_p),
+        ("d_probe_idx", C.c_void_p),
     ]
 
 
@@ -83,6 +84,11 @@ class ShardMetrics(C.Structure):
 class RowsMetrics(C.Structure):
     _fields_ = [(f, C.c_uint64) for f in ("n_bases", "bases", "q30_bases", "q30_den")]
 
+
+# crgpu_dupinfo (crgpu_count_host's per-read output) as a numpy record
+DUPINFO_DTYPE = np.dtype([("processed_umi", np.uint32), ("read_count", np.uint32), ("flags", np.uint8), ("reserved", np.uint8, (3,))])
+NO_PROBE = -1
+ABI_VERSION = 3
 
 # crgpu_barcode_summary_row as a numpy record
 BARCODE_SUMMARY_DTYPE = np.dtype([("barcode_rank", np.uint32), ("library", np.uint32), ("reads", np.uint64), ("umis", np.uint64),
@@ -134,6 +140,9 @@ class BcCorrectionMetrics(C.Structure):
 _vp, _u8p, _u32, _u64, _i, _dbl = C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
 SYMBOLS = {
     "crgpu_abi_version": (_i, []),
+    "crgpu_abi_layout": (_i, [C.c_char_p, _vp, _u32]),
+    "crgpu_count_host": (_i, [_vp, C.POINTER(Records), _u32, C.POINTER(C.POINTER(MatrixView)), _vp, C.POINTER(_vp)]),
+    "crgpu_counts_probe_idx": (_i, [_vp, _vp, _vp]),
     "crgpu_get_unique_id": (_i, [_vp]),
     "crgpu_local_group_id": (_i, [_u32, _vp]),
     "crgpu_create": (_i, [C.POINTER(_vp), _i, _i, _i, _vp]),

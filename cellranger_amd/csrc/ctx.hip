@@ -25,6 +25,81 @@ int cr_fail(crgpu_ctx *ctx, int code, const char *fmt, ...) {
 
 extern "C" int crgpu_abi_version(void) { return CRGPU_ABI_VERSION; }
 
+// ---- layout of the public structs, for bindings to check their own declarations against (include/crgpu.h) -------------
+#include <cstddef>
+namespace {
+struct AbiField {
+    uint32_t offset, size;
+};
+struct AbiStruct {
+    const char *name;
+    uint32_t size, align;
+    std::vector<AbiField> fields;
+};
+#define ABI_F(T, f) AbiField{(uint32_t)offsetof(T, f), (uint32_t)sizeof(((T *)nullptr)->f)}
+#define ABI_S(T, ...) AbiStruct{#T, (uint32_t)sizeof(T), (uint32_t)alignof(T), {__VA_ARGS__}}
+const std::vector<AbiStruct> &abi_table() {
+    static const std::vector<AbiStruct> t = {
+        ABI_S(crgpu_records, ABI_F(crgpu_records, n), ABI_F(crgpu_records, umi_len), ABI_F(crgpu_records, d_bc_idx),
+              ABI_F(crgpu_records, d_umi), ABI_F(crgpu_records, d_umi_qualn), ABI_F(crgpu_records, d_feature),
+              ABI_F(crgpu_records, d_flags), ABI_F(crgpu_records, d_umi_len), ABI_F(crgpu_records, d_probe_idx)),
+        ABI_S(crgpu_matrix, ABI_F(crgpu_matrix, n_barcodes), ABI_F(crgpu_matrix, nnz), ABI_F(crgpu_matrix, n_features),
+              ABI_F(crgpu_matrix, cb_len), ABI_F(crgpu_matrix, barcode_rank), ABI_F(crgpu_matrix, barcode_seq),
+              ABI_F(crgpu_matrix, indptr), ABI_F(crgpu_matrix, indices), ABI_F(crgpu_matrix, data), ABI_F(crgpu_matrix, gem_group),
+              ABI_F(crgpu_matrix, barcode_seq_hi)),
+        ABI_S(crgpu_matrix_dev, ABI_F(crgpu_matrix_dev, n_barcodes), ABI_F(crgpu_matrix_dev, nnz),
+              ABI_F(crgpu_matrix_dev, d_barcode_rank), ABI_F(crgpu_matrix_dev, d_indptr), ABI_F(crgpu_matrix_dev, d_indices),
+              ABI_F(crgpu_matrix_dev, d_data)),
+        ABI_S(crgpu_dupinfo, ABI_F(crgpu_dupinfo, processed_umi), ABI_F(crgpu_dupinfo, read_count), ABI_F(crgpu_dupinfo, flags),
+              ABI_F(crgpu_dupinfo, reserved)),
+        ABI_S(crgpu_barcode_summary_row, ABI_F(crgpu_barcode_summary_row, barcode_rank), ABI_F(crgpu_barcode_summary_row, library),
+              ABI_F(crgpu_barcode_summary_row, reads), ABI_F(crgpu_barcode_summary_row, umis),
+              ABI_F(crgpu_barcode_summary_row, candidate_dup_reads), ABI_F(crgpu_barcode_summary_row, umi_corrected_reads)),
+        ABI_S(crgpu_bc_correction_metrics, ABI_F(crgpu_bc_correction_metrics, valid_reads),
+              ABI_F(crgpu_bc_correction_metrics, corrected_reads), ABI_F(crgpu_bc_correction_metrics, barcodes_detected),
+              ABI_F(crgpu_bc_correction_metrics, effective_barcode_diversity)),
+        ABI_S(crgpu_shard_metrics, ABI_F(crgpu_shard_metrics, sequenced_reads), ABI_F(crgpu_shard_metrics, bc_n_bases),
+              ABI_F(crgpu_shard_metrics, bc_bases), ABI_F(crgpu_shard_metrics, umi_n_bases), ABI_F(crgpu_shard_metrics, umi_bases),
+              ABI_F(crgpu_shard_metrics, bc_q30_bases), ABI_F(crgpu_shard_metrics, bc_q30_den), ABI_F(crgpu_shard_metrics, umi_q30_bases),
+              ABI_F(crgpu_shard_metrics, umi_q30_den), ABI_F(crgpu_shard_metrics, good_umi), ABI_F(crgpu_shard_metrics, has_n_barcode),
+              ABI_F(crgpu_shard_metrics, has_n_umi), ABI_F(crgpu_shard_metrics, homopolymer_barcode),
+              ABI_F(crgpu_shard_metrics, homopolymer_umi), ABI_F(crgpu_shard_metrics, low_min_qual_barcode),
+              ABI_F(crgpu_shard_metrics, low_min_qual_umi), ABI_F(crgpu_shard_metrics, miss_whitelist_barcode),
+              ABI_F(crgpu_shard_metrics, polyt_suffix_umi)),
+        ABI_S(crgpu_rows_metrics, ABI_F(crgpu_rows_metrics, n_bases), ABI_F(crgpu_rows_metrics, bases),
+              ABI_F(crgpu_rows_metrics, q30_bases), ABI_F(crgpu_rows_metrics, q30_den)),
+        ABI_S(crgpu_feature_def, ABI_F(crgpu_feature_def, pattern), ABI_F(crgpu_feature_def, sequence),
+              ABI_F(crgpu_feature_def, index), ABI_F(crgpu_feature_def, read)),
+        ABI_S(crgpu_synth_params, ABI_F(crgpu_synth_params, seed), ABI_F(crgpu_synth_params, cb_len), ABI_F(crgpu_synth_params, umi_len),
+              ABI_F(crgpu_synth_params, n_wl), ABI_F(crgpu_synth_params, wl_packed), ABI_F(crgpu_synth_params, n_cells),
+              ABI_F(crgpu_synth_params, cell_wl_pos), ABI_F(crgpu_synth_params, cell_cdf), ABI_F(crgpu_synth_params, n_ambient),
+              ABI_F(crgpu_synth_params, ambient_wl_pos), ABI_F(crgpu_synth_params, n_genes), ABI_F(crgpu_synth_params, gene_cdf),
+              ABI_F(crgpu_synth_params, ambient_per_2_16), ABI_F(crgpu_synth_params, cb_err_per_2_16),
+              ABI_F(crgpu_synth_params, umi_err_per_2_16), ABI_F(crgpu_synth_params, n_per_2_20),
+              ABI_F(crgpu_synth_params, no_feature_per_2_16), ABI_F(crgpu_synth_params, reads_per_umi),
+              ABI_F(crgpu_synth_params, n_total), ABI_F(crgpu_synth_params, n_libs)),
+        ABI_S(crgpu_synth_out, ABI_F(crgpu_synth_out, cb), ABI_F(crgpu_synth_out, cb_qualn), ABI_F(crgpu_synth_out, umi),
+              ABI_F(crgpu_synth_out, umi_qualn), ABI_F(crgpu_synth_out, feature), ABI_F(crgpu_synth_out, flags)),
+    };
+    return t;
+}
+}  // namespace
+
+extern "C" int crgpu_abi_layout(const char *struct_name, uint32_t *out, uint32_t cap) {
+    if (!struct_name) return CRGPU_EINVAL;
+    for (const AbiStruct &s : abi_table()) {
+        if (strcmp(s.name, struct_name) != 0) continue;
+        std::vector<uint32_t> w = {s.size, s.align, (uint32_t)s.fields.size()};
+        for (const AbiField &f : s.fields) {
+            w.push_back(f.offset);
+            w.push_back(f.size);
+        }
+        for (uint32_t i = 0; i < w.size() && i < cap && out; i++) out[i] = w[i];
+        return (int)w.size();
+    }
+    return cr_fail(nullptr, CRGPU_EINVAL, "crgpu_abi_layout: no public struct named %s", struct_name);
+}
+
 extern "C" const char *crgpu_last_error(const crgpu_ctx *ctx) {
     return ctx ? ctx->err.c_str() : g_thread_err.c_str();
 }

@@ -34,6 +34,7 @@ struct crgpu_counts {
     uint32_t *d_mreads = nullptr;   // read_count of each molecule
     uint32_t *d_corr_reads = nullptr;  // [library][barcode rank] reads whose UMI was corrected (BarcodeSummary), or NULL
     uint32_t *d_filt_reads = nullptr;  // [library][barcode rank] reads of molecules the targeted-panel filter removed, or NULL
+    int32_t *d_mprobe = nullptr;    // probe_idx of each molecule's representative read (crgpu_records.d_probe_idx given), or NULL
     uint32_t n_canon = 0;
     KeyLayout layout;
 };
@@ -805,6 +806,10 @@ struct EmitMol {
     uint64_t n_keys, n_dist;
     uint64_t *mkeys;
     uint32_t *mreads;
+    // UmiCount::probe_idx (mark_dups.rs:332-342): the probe of the representative read, when the records carry probes
+    const uint32_t *rep_read = nullptr;
+    const int32_t *probe = nullptr;
+    int32_t *mprobe = nullptr;
     struct Pre {
         uint64_t key;
         uint32_t p0, p1, s;
@@ -841,6 +846,7 @@ struct EmitMol {
         const uint32_t cnt = end - p.p0;
         // umigene_counts after both moves (mark_dups.rs:226-246): own reads stay only if not corrected away
         mreads[o] = ((p.s & ST_CORRECTED) ? 0u : cnt) + inc;
+        if (mprobe) mprobe[o] = probe[rep_read[mi != NONE32 ? mi : (uint32_t)k]];
     }
 };
 struct EmitTriplet {
@@ -1688,6 +1694,7 @@ struct PerRead {
     uint32_t *out_umi = nullptr, *out_cnt = nullptr;
     uint8_t *out_flags = nullptr;
     struct DupRec *packed_out = nullptr;  // non-NULL: leave the packed 12-byte records here (n_reads entries), no unpacking
+    const int32_t *d_probe = nullptr;     // probe index per read ordinal (crgpu_records.d_probe_idx): molecules get d_mprobe
 };
 
 // Two branches of the count stage that only read the distinct keys run side by side: the UMI correction stays on the
@@ -1952,6 +1959,14 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     CrFork fork2(ctx);
     DevBuf rep_b, packed_b;
     const bool windowed = getenv("CRGPU_DUPINFO_WINDOWED") != nullptr;
+    const bool want_probe = vals && pr.d_probe;
+    if (vals) CR_TRY(dmalloc(ctx, rep_b, nd * sizeof(uint32_t)));
+    if (want_probe) {  // the molecule pass of step 5 needs the representative reads, too: before the streams part
+        CrTimer t(ctx, CRGPU_T_DEDUP);
+        hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
+                           rep_b.as<uint32_t>());
+        CR_HIP(ctx, hipGetLastError());
+    }
     if (vals && !windowed && CrFork::enabled(ctx, nd)) {
         CR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         if (ctx->timing) {
@@ -1962,10 +1977,10 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CR_TRY(fork2.side(fork2.t0));
     }
     if (vals) {
-        CR_TRY(dmalloc(ctx, rep_b, nd * sizeof(uint32_t)));
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
-                           rep_b.as<uint32_t>());
+        if (!want_probe)
+            hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
+                               rep_b.as<uint32_t>());
         // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): zeros
         if (pr.packed_out) {
             CR_HIP(ctx, hipMemsetAsync(pr.packed_out, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
@@ -2049,6 +2064,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     CR_TRY(dmalloc(ctx, mkeys_b, nd * sizeof(uint64_t)));
     CR_TRY(dmalloc(ctx, mreads_b, nd * sizeof(uint32_t)));
     uint32_t nm32 = 0, nt32 = 0;
+    if (want_probe) CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_mprobe, nd * sizeof(int32_t)));
     const char *fused_env = getenv("CRGPU_MOL_FUSED");
     const bool fused = nd > 0 && !(fused_env && fused_env[0] == '0');
     if (fused) {
@@ -2060,7 +2076,12 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         uint32_t *d_total_h = ctx->d_scalars + 17;
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
-            const EmitMol emit{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()};
+            EmitMol emit{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()};
+            if (want_probe) {
+                emit.rep_read = rep_b.as<uint32_t>();
+                emit.probe = pr.d_probe;
+                emit.mprobe = res->d_mprobe;
+            }
             uint64_t tile;
             const uint32_t nb = cp_blocks(nd, &tile);
             const MolFlagTargeted flag_t{st, ukey, upos, inc_all, n_keys, nd, tf};
@@ -2085,7 +2106,12 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CR_TRY(read_u32(ctx, d_total_h, &nt32));
     } else {
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        const EmitMol emit{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()};
+        EmitMol emit{ukey, upos, inc_all, minidx, st, n_keys, nd, mkeys_b.as<uint64_t>(), mreads_b.as<uint32_t>()};
+        if (want_probe) {
+            emit.rep_read = rep_b.as<uint32_t>();
+            emit.probe = pr.d_probe;
+            emit.mprobe = res->d_mprobe;
+        }
         if (tf.min_reads)
             CR_TRY(compact(ctx, MolFlagTargeted{st, ukey, upos, inc_all, n_keys, nd, tf}, emit, nd, d_block, d_total));
         else
@@ -2179,6 +2205,7 @@ extern "C" int crgpu_count_records_dev(crgpu_ctx *ctx, const crgpu_records *recs
     pr.out_umi = d_processed_umi_out;
     pr.out_cnt = d_read_count_out;
     pr.out_flags = d_dupflags_out;
+    pr.d_probe = recs->d_probe_idx;
     if (n_keys == 0) {  // no read reaches DupBuilder::observe: no DupInfo anywhere (mark_dups.rs:289-291)
         if (d_processed_umi_out) CR_HIP(ctx, hipMemsetAsync(d_processed_umi_out, 0, n * sizeof(uint32_t), ctx->stream));
         if (d_read_count_out) CR_HIP(ctx, hipMemsetAsync(d_read_count_out, 0, n * sizeof(uint32_t), ctx->stream));
@@ -2220,6 +2247,9 @@ extern "C" int crgpu_count_records_sharded_dev(crgpu_ctx *ctx, const crgpu_recor
     if (!ctx || !recs || !out) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     *out = nullptr;
+    CR_REQUIRE(ctx, !recs->d_probe_idx, CRGPU_EINVAL,
+               "crgpu_count_records_sharded: d_probe_idx is not carried across ranks (join probe indices on the host by the "
+               "is_umi_count reads)");
     cr_invalidate(ctx);
     CR_REQUIRE(ctx, recs->n <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_records_sharded: at most 2^31-1 records per call");
     const uint64_t n = recs->n;
@@ -2646,21 +2676,18 @@ extern "C" int crgpu_counts_triplets(crgpu_ctx *ctx, const crgpu_counts *c, uint
     return CRGPU_OK;
 }
 
-extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint8_t *lib_out,
-                                      uint32_t *feature_out, uint32_t *umi_out, uint32_t *read_count_out,
-                                      uint8_t *utype_out) {
-    if (!ctx || !c) return CRGPU_EINVAL;
-    CR_ENTER(ctx);
+// the molecule table on the host in the order ALIGN_AND_COUNT emits it: order[o] = device position of the o-th UmiCount
+static int molecule_order(crgpu_ctx *ctx, const crgpu_counts *c, std::vector<uint64_t> &keys, std::vector<uint32_t> &reads,
+                          std::vector<uint32_t> &order) {
     const uint64_t nm = c->n_molecules;
-    if (!nm) return CRGPU_OK;
-    std::vector<uint64_t> keys(nm);
-    std::vector<uint32_t> reads(nm);
+    keys.resize(nm);
+    reads.resize(nm);
+    order.resize(nm);
     CR_TRY(crgpu_memcpy_d2h(ctx, keys.data(), c->d_mkeys, nm * sizeof(uint64_t)));
     CR_TRY(crgpu_memcpy_d2h(ctx, reads.data(), c->d_mreads, nm * sizeof(uint32_t)));
     const KeyLayout &L = c->layout;
     // align_and_count.rs:314 sorts a barcode's UmiCounts by (library_idx, feature_idx, umi, ...):
     // the device order is (barcode, feature, library, umi); reorder inside each barcode.
-    std::vector<uint32_t> order(nm);
     for (uint64_t i = 0; i < nm; i++) order[i] = (uint32_t)i;
     auto fld = [&](uint64_t k, uint32_t sh, uint32_t bits) { return (uint32_t)((k >> sh) & (bits >= 64 ? ~0ull : ((1ull << bits) - 1))); };
     // with a single library and one UMI length the device order (barcode, feature, umi) already is the required one;
@@ -2678,6 +2705,21 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
         if (reads[a] != reads[b]) return reads[a] < reads[b];
         return (ka & 1ull) < (kb & 1ull);
     });
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint8_t *lib_out,
+                                      uint32_t *feature_out, uint32_t *umi_out, uint32_t *read_count_out,
+                                      uint8_t *utype_out) {
+    if (!ctx || !c) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    const uint64_t nm = c->n_molecules;
+    if (!nm) return CRGPU_OK;
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> reads, order;
+    CR_TRY(molecule_order(ctx, c, keys, reads, order));
+    const KeyLayout &L = c->layout;
+    auto fld = [&](uint64_t k, uint32_t sh, uint32_t bits) { return (uint32_t)((k >> sh) & (bits >= 64 ? ~0ull : ((1ull << bits) - 1))); };
     for (uint64_t o = 0; o < nm; o++) {
         const uint64_t k = keys[order[o]];
         if (bc_out) bc_out[o] = (uint32_t)(k >> L.sh_bc());
@@ -2687,6 +2729,23 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
         if (read_count_out) read_count_out[o] = reads[order[o]];
         if (utype_out) utype_out[o] = (uint8_t)(k & 1ull);
     }
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_counts_probe_idx(crgpu_ctx *ctx, const crgpu_counts *c, int32_t *probe_idx_out) {
+    if (!ctx || !c) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    const uint64_t nm = c->n_molecules;
+    if (!nm) return CRGPU_OK;
+    CR_REQUIRE(ctx, c->d_mprobe, CRGPU_ESTATE,
+               "crgpu_counts_probe_idx: these counts were made without crgpu_records.d_probe_idx (crgpu_count_records_dev / crgpu_count_host)");
+    CR_REQUIRE(ctx, probe_idx_out, CRGPU_EINVAL, "crgpu_counts_probe_idx: NULL output");
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> reads, order;
+    CR_TRY(molecule_order(ctx, c, keys, reads, order));
+    std::vector<int32_t> probe(nm);
+    CR_TRY(crgpu_memcpy_d2h(ctx, probe.data(), c->d_mprobe, nm * sizeof(int32_t)));
+    for (uint64_t o = 0; o < nm; o++) probe_idx_out[o] = probe[order[o]];
     return CRGPU_OK;
 }
 
@@ -2765,6 +2824,7 @@ extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
     cr_pool_free(ctx, c->d_mreads);
     cr_pool_free(ctx, c->d_corr_reads);
     cr_pool_free(ctx, c->d_filt_reads);
+    cr_pool_free(ctx, c->d_mprobe);
     delete c;
 }
 

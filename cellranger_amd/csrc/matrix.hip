@@ -345,6 +345,89 @@ extern "C" int crgpu_count(crgpu_ctx *ctx, const crgpu_records *recs, uint32_t n
     return crgpu_assemble_matrix(ctx, bc.data(), ft.data(), ct.data(), nt, n_features, out);
 }
 
+// The count entry of SURVEY 8(b) for host-resident records: upload -> crgpu_count_records_dev (per-read DupInfo wanted) or
+// keys + crgpu_count_keys_dev -> triplets -> matrix; DupInfo comes back as an array of structs (mark_dups.rs:61-72).
+extern "C" int crgpu_count_host(crgpu_ctx *ctx, const crgpu_records *recs_host, uint32_t n_features, crgpu_matrix **out,
+                                crgpu_dupinfo *per_read, crgpu_counts **counts_out) {
+    if (!ctx || !recs_host || !out) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    *out = nullptr;
+    if (counts_out) *counts_out = nullptr;
+    CR_REQUIRE(ctx, ctx->layout.set && ctx->layout.n_features == n_features, CRGPU_ESTATE,
+               "crgpu_count_host: call crgpu_set_key_layout with the same n_features first");
+    const crgpu_records &h = *recs_host;
+    const uint64_t n = h.n;
+    CR_REQUIRE(ctx, n <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_host: at most 2^31-1 records per call");
+    CR_REQUIRE(ctx, n == 0 || (h.d_bc_idx && h.d_umi && h.d_umi_qualn && h.d_feature), CRGPU_EINVAL, "crgpu_count_host: NULL buffer");
+    struct Up {  // pooled device copy of one host array
+        crgpu_ctx *c;
+        void *p = nullptr;
+        ~Up() { cr_pool_free(c, p); }
+        int put(const void *src, uint64_t bytes) {
+            if (!src || !bytes) return CRGPU_OK;
+            CR_TRY(cr_pool_alloc(c, &p, bytes));
+            return crgpu_memcpy_h2d(c, p, src, bytes);
+        }
+        int room(uint64_t bytes) { return bytes ? cr_pool_alloc(c, &p, bytes) : CRGPU_OK; }
+    };
+    Up bc{ctx}, umi{ctx}, uq{ctx}, ft{ctx}, fl{ctx}, ul{ctx}, pb{ctx}, o_umi{ctx}, o_cnt{ctx}, o_fl{ctx};
+    CR_TRY(bc.put(h.d_bc_idx, n * 4));
+    CR_TRY(umi.put(h.d_umi, n * 4));
+    CR_TRY(uq.put(h.d_umi_qualn, n * (uint64_t)h.umi_len));
+    CR_TRY(ft.put(h.d_feature, n * 4));
+    CR_TRY(fl.put(h.d_flags, n));
+    CR_TRY(ul.put(h.d_umi_len, n));
+    CR_TRY(pb.put(h.d_probe_idx, n * 4));
+    crgpu_records d{n, h.umi_len, (const uint32_t *)bc.p, (const uint32_t *)umi.p, (const uint8_t *)uq.p, (const uint32_t *)ft.p,
+                    (const uint8_t *)fl.p, (const uint8_t *)ul.p, (const int32_t *)pb.p};
+    crgpu_counts *c = nullptr;
+    const bool want_reads = per_read != nullptr || h.d_probe_idx != nullptr;
+    if (n == 0) {
+        CR_TRY(crgpu_count_keys_dev(ctx, nullptr, 0, &c));
+    } else if (want_reads) {
+        if (per_read) {
+            CR_TRY(o_umi.room(n * 4));
+            CR_TRY(o_cnt.room(n * 4));
+            CR_TRY(o_fl.room(n));
+        }
+        CR_TRY(crgpu_count_records_dev(ctx, &d, &c, (uint32_t *)o_umi.p, (uint32_t *)o_cnt.p, (uint8_t *)o_fl.p));
+    } else {
+        Up keys{ctx};
+        CR_TRY(keys.room((n ? n : 1) * sizeof(uint64_t)));
+        uint64_t n_keys = 0;
+        CR_TRY(crgpu_build_keys_dev(ctx, &d, (uint64_t *)keys.p, &n_keys));
+        CR_TRY(crgpu_count_keys_dev(ctx, (uint64_t *)keys.p, n_keys, &c));
+    }
+    struct CountsGuard {
+        crgpu_ctx *ctx;
+        crgpu_counts *c;
+        ~CountsGuard() {
+            if (c) crgpu_counts_free(ctx, c);
+        }
+    } guard{ctx, c};
+    uint64_t nt = 0;
+    CR_TRY(crgpu_counts_info(ctx, c, &nt, nullptr));
+    std::vector<uint32_t> tb(nt), tf(nt), tc(nt);
+    CR_TRY(crgpu_counts_triplets(ctx, c, tb.data(), tf.data(), tc.data()));
+    if (per_read && n) {
+        std::vector<uint32_t> pu(n), rc(n);
+        std::vector<uint8_t> df(n);
+        CR_TRY(crgpu_memcpy_d2h(ctx, pu.data(), o_umi.p, n * 4));
+        CR_TRY(crgpu_memcpy_d2h(ctx, rc.data(), o_cnt.p, n * 4));
+        CR_TRY(crgpu_memcpy_d2h(ctx, df.data(), o_fl.p, n));
+        for (uint64_t i = 0; i < n; i++) per_read[i] = crgpu_dupinfo{pu[i], rc[i], df[i], {0, 0, 0}};
+    }
+    {
+        CrTimer t(ctx, CRGPU_T_MATRIX);
+        CR_TRY(crgpu_assemble_matrix(ctx, tb.data(), tf.data(), tc.data(), nt, n_features, out));
+    }
+    if (counts_out) {
+        *counts_out = c;
+        guard.c = nullptr;
+    }
+    return CRGPU_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // barcode_summary.csv (ALIGN_AND_COUNT join, cr_lib/src/stages/align_and_count.rs:806-817)
 // ------------------------------------------------------------------------------------------------

@@ -240,6 +240,13 @@ class Counts:
                 ptr(out["library_idx"]), ptr(out["umi"]), ptr(out["count"]), ptr(out["umi_type"])))
         return out
 
+    def probe_idx(self):
+        """UmiCount::probe_idx per molecule, in the order of molecules() / molecule_info() (records with d_probe_idx)"""
+        out = np.full(self.n_molecules, _lib.NO_PROBE, np.int32)
+        if self.n_molecules:
+            self.ctx._check(self.ctx.L.crgpu_counts_probe_idx(self.ctx.h, self.h, ptr(out)))
+        return out
+
     def barcode_summary(self, rank_lo=0, rank_hi=0xFFFFFFFF):
         """BarcodeSummary rows (cr_lib/src/aligner.rs:33-68) of the barcode ranks in [rank_lo, rank_hi), ordered by
         (library, rank): a numpy record array of _lib.BARCODE_SUMMARY_DTYPE"""
@@ -508,12 +515,33 @@ class Context:
         a = None if on_target is None else np.ascontiguousarray(on_target, dtype=np.uint8)
         self._check(self.L.crgpu_set_target_filter(self.h, ptr(a), 0 if a is None else len(a), int(min_read_count)))
 
-    def records(self, n, umi_len, d_bc_idx, d_umi, d_umi_qualn, d_feature, d_flags=None, d_umi_len=None):
+    def records(self, n, umi_len, d_bc_idx, d_umi, d_umi_qualn, d_feature, d_flags=None, d_umi_len=None, d_probe_idx=None):
         r = Records()
         r.n, r.umi_len = n, umi_len
         r.d_bc_idx, r.d_umi, r.d_umi_qualn = _p(d_bc_idx), _p(d_umi), _p(d_umi_qualn)
         r.d_feature, r.d_flags, r.d_umi_len = _p(d_feature), _p(d_flags), _p(d_umi_len)
+        r.d_probe_idx = _p(d_probe_idx)
         return r
+
+    def count_host(self, n_features, bc_idx, umi, umi_qualn, feature, flags=None, umi_len_per_read=None, probe_idx=None,
+                   want_dupinfo=True, want_counts=False):
+        """crgpu_count_host: records in HOST arrays -> (Matrix, per-read crgpu_dupinfo records or None[, Counts])"""
+        def h(a, dt):
+            return None if a is None else np.ascontiguousarray(a, dtype=dt)
+        bc_idx, umi, feature = h(bc_idx, np.uint32), h(umi, np.uint32), h(feature, np.uint32)
+        umi_qualn, flags, ulen, probe = h(umi_qualn, np.uint8), h(flags, np.uint8), h(umi_len_per_read, np.uint8), h(probe_idx, np.int32)
+        n = len(bc_idx)
+        r = Records()
+        r.n, r.umi_len = n, (umi_qualn.shape[1] if umi_qualn.ndim == 2 else self.umi_len)
+        r.d_bc_idx, r.d_umi, r.d_umi_qualn, r.d_feature = ptr(bc_idx), ptr(umi), ptr(umi_qualn), ptr(feature)
+        r.d_flags, r.d_umi_len, r.d_probe_idx = ptr(flags), ptr(ulen), ptr(probe)
+        dup = np.zeros(n, _lib.DUPINFO_DTYPE) if want_dupinfo else None
+        mv = C.POINTER(MatrixView)()
+        ch = C.c_void_p()
+        self._check(self.L.crgpu_count_host(self.h, C.byref(r), n_features, C.byref(mv), ptr(dup) if n else None,
+                                            C.byref(ch) if want_counts else None))
+        m = Matrix(self, mv)
+        return (m, dup, Counts(self, ch)) if want_counts else (m, dup)
 
     def set_umi_min_len(self, umi_min_len):
         """per-read UMI lengths umi_min_len .. umi_len (after set_key_layout)"""

@@ -52,7 +52,11 @@
 extern "C" {
 #endif
 
-#define CRGPU_ABI_VERSION 2
+/* 3: crgpu_records grew d_umi_len and crgpu_matrix grew barcode_seq_hi (both appended in round 2 without a bump: a binding
+ * built against version 2 passes structs that are 8 bytes short); crgpu_abi_layout, crgpu_count_host, crgpu_dupinfo added.
+ * The version changes whenever a public struct changes size or field order; a host checks it (and crgpu_abi_layout) once
+ * at start-up. */
+#define CRGPU_ABI_VERSION 3
 #define CRGPU_MAX_LIB 16
 #define CRGPU_MISS 0xFFFFFFFFu
 #define CRGPU_NO_FEATURE 0xFFFFFFFFu
@@ -76,6 +80,12 @@ typedef struct crgpu_ctx crgpu_ctx;
 
 /* ---- context ------------------------------------------------------------------------------ */
 int crgpu_abi_version(void);
+/* The layout of a public struct as THIS build of the library sees it, for a binding to check its own declaration against
+ * (Rust: size_of / offset_of of the #[repr(C)] mirror; tests/test_abi_and_host.py does it for INTEGRATION.md's blocks, the
+ * ctypes table and this header).  struct_name: "crgpu_records", "crgpu_matrix", ... (every typedef struct of this header);
+ * out[0] = sizeof, out[1] = alignof, out[2] = number of fields, then (offsetof, sizeof) per field in declaration order.
+ * Returns the number of words the description has (writes at most cap of them), CRGPU_EINVAL for an unknown name. */
+int crgpu_abi_layout(const char *struct_name, uint32_t *out, uint32_t cap);
 /* The signature of SURVEY.md 8(b).  n_ranks / rank: this context's place among the GPUs that share ONE GEM well (reads
  * sharded over the ranks); unique_id (CRGPU_UNIQUE_ID_BYTES bytes, the same on every rank): the rendezvous
  * token, from crgpu_get_unique_id (one process per GPU, RCCL over xGMI: rank 0 makes it and ships the bytes to the other
@@ -351,7 +361,12 @@ typedef struct {
     const uint8_t *d_flags;    /* library id / NONTXOMIC; nullable (library 0, Txomic) */
     const uint8_t *d_umi_len;  /* nullable: bases of every read's UMI, umi_min_len .. umi_len (crgpu_set_umi_min_len); the packed
                                   UMI holds that many bases right-aligned, d_umi_qualn keeps its stride of umi_len bytes */
+    const int32_t *d_probe_idx;/* nullable: probe index of the read's confidently mapped LHS probe, CRGPU_NO_PROBE = None
+                                  (RTL / Flex reads: mark_dups.rs:332-342).  Only crgpu_count_records_dev, its sharded twin and
+                                  crgpu_count_host look at it: the UmiCount of a molecule carries the probe of its
+                                  representative read (crgpu_counts_probe_idx) */
 } crgpu_records;
+#define CRGPU_NO_PROBE (-1)  /* PROBE_IDX_SENTINEL_VALUE (cr_types/src/types.rs:29) */
 
 /* 64-bit molecule keys: the exchange unit between GPUs and the input of the
  * dedup.  Build keeps only reads that reach DupBuilder::observe (valid barcode, valid UMI,
@@ -432,11 +447,17 @@ int crgpu_counts_triplets(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_ou
  * entry per UmiCount in the order ALIGN_AND_COUNT emits them (barcodes ascending, inside a barcode sorted as
  * align_and_count.rs:314): gem_group (constant), barcode_idx = position of the barcode in the BarcodeIndex of this
  * context (== matrix column), feature_idx, library_idx, umi (2-bit), count (reads), umi_type (UmiType::to_u32: 0 Txomic,
- * 1 NonTxomic).  n_molecules entries each (crgpu_counts_info), host pointers, any may be NULL.  probe_idx is not
- * produced (probe alignments are not an input of this path). */
+ * 1 NonTxomic).  n_molecules entries each (crgpu_counts_info), host pointers, any may be NULL.  The eighth dataset,
+ * probe_idx, comes from crgpu_counts_probe_idx. */
 int crgpu_counts_molecule_info(crgpu_ctx *ctx, const crgpu_counts *c, uint16_t gem_group, uint16_t *gem_group_out,
                                uint64_t *barcode_idx_out, uint32_t *feature_idx_out, uint16_t *library_idx_out,
                                uint32_t *umi_out, uint32_t *count_out, uint32_t *umi_type_out);
+/* UmiCount::probe_idx (cr_types/src/types.rs:152-160; the probe_idx dataset MoleculeInfoWriter::fill appends,
+ * cr_h5/src/molecule_info.rs:980-987): per molecule, in the order of crgpu_counts_molecule_info / crgpu_counts_molecules, the
+ * d_probe_idx of the molecule's representative read (the read with DupInfo::is_umi_count), CRGPU_NO_PROBE where that read
+ * has none.  CRGPU_ESTATE when the counts were made without crgpu_records.d_probe_idx (or by crgpu_count_keys_dev: keys
+ * carry no read identity). */
+int crgpu_counts_probe_idx(crgpu_ctx *ctx, const crgpu_counts *c, int32_t *probe_idx_out);
 /* molecule table: bc rank, library, feature, 2-bit umi, read_count, utype (0 Txomic,1 NonTxomic) */
 int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uint32_t *bc_out, uint8_t *lib_out,
                            uint32_t *feature_out, uint32_t *umi_out, uint32_t *read_count_out,
@@ -548,6 +569,21 @@ int crgpu_matrix_dev_download(crgpu_ctx *ctx, const crgpu_matrix_dev *m, uint32_
 
 /* one-call convenience (single GPU): build keys -> dedup -> matrix */
 int crgpu_count(crgpu_ctx *ctx, const crgpu_records *recs, uint32_t n_features, crgpu_matrix **out);
+/* The count entry of SURVEY.md 8(b) for a host that holds its records in HOST memory (the Rust stage code after STAR
+ * annotation): `recs` is a crgpu_records whose pointers are HOST arrays (same meaning, d_flags / d_umi_len nullable).
+ * Uploads, builds keys, dedups, assembles the matrix (library-owned, crgpu_matrix_free) and, when per_read is not NULL,
+ * fills the caller-allocated array of n crgpu_dupinfo -- DupInfo of mark_dups.rs:61-72 per read, in record order (the
+ * record's position is its qname rank): what the unchanged host turns into the UB tag, the duplicate flag and xf
+ * (tx_annotation/src/read.rs:536-590).  counts_out (nullable): the crgpu_counts of the call (molecule table, summary
+ * rows), else it is freed.  PCIe-bound like crgpu_match_and_count / crgpu_correct: for drop-in use, not for the bench. */
+typedef struct {
+    uint32_t processed_umi; /* DupInfo::processed_umi, 2-bit */
+    uint32_t read_count;    /* umigene_counts[corrected key] */
+    uint8_t flags;          /* CRGPU_DUP_* ; 0 = process() returned None */
+    uint8_t reserved[3];
+} crgpu_dupinfo;
+int crgpu_count_host(crgpu_ctx *ctx, const crgpu_records *recs_host, uint32_t n_features, crgpu_matrix **out,
+                     crgpu_dupinfo *per_read, crgpu_counts **counts_out);
 
 /* ---- feature-barcode matching (K3) ---------------------------------------------------------------
  * Replaces FeatureExtractor::find_closest / correct_feature_barcode for one tethered pattern

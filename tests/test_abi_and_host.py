@@ -35,7 +35,123 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and the Python binding table covers exactly the header
     assert sorted(_lib.SYMBOLS) == declared
-    assert _lib.load().crgpu_abi_version() == 2
+    assert _lib.load().crgpu_abi_version() == _lib.ABI_VERSION == 3
+
+
+# ---- the layout of every public struct: header == library == ctypes table == the Rust blocks of INTEGRATION.md -------------
+_C_SIZES = {"uint64_t": 8, "int64_t": 8, "uint32_t": 4, "int32_t": 4, "uint16_t": 2, "uint8_t": 1, "double": 8, "int": 4}
+_RUST_SIZES = {"u64": 8, "i64": 8, "u32": 4, "i32": 4, "u16": 2, "u8": 1, "f64": 8, "c_int": 4}
+
+
+def _layout(fields):
+    """C / repr(C) layout of [(name, size, align, count)] -> (sizeof, alignof, [(name, offset, size)])"""
+    off, amax, out = 0, 1, []
+    for name, size, align, count in fields:
+        off = (off + align - 1) // align * align
+        out.append((name, off, size * count))
+        off += size * count
+        amax = max(amax, align)
+    return (off + amax - 1) // amax * amax, amax, out
+
+
+def header_structs():
+    with open(os.path.join(ROOT, "include", "crgpu.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s*\w*\s*\{(.*?)\}\s*(crgpu_\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            mm = re.match(r"(?:const\s+)?(\w+)\s*((?:\*\s*(?:const\s*)?)*)(.*)$", decl)
+            ctype, stars, names = mm.group(1), mm.group(2), mm.group(3)
+            for nm in names.split(","):
+                nm = nm.strip()
+                ptr = "*" in stars or nm.startswith("*")
+                nm = nm.lstrip("* ")
+                arr = re.match(r"(\w+)\[(\d+)\]$", nm)
+                count = int(arr.group(2)) if arr else 1
+                nm = arr.group(1) if arr else nm
+                size = 8 if ptr else _C_SIZES[ctype]
+                fields.append((nm, size, size, count))
+        structs[m.group(2)] = _layout(fields)
+    return structs
+
+
+def rust_structs():
+    """every `#[repr(C)] pub struct Name { ... }  // crgpu_name` block of INTEGRATION.md"""
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        text = f.read()
+    structs = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*pub struct (\w+)\s*\{\s*//\s*(crgpu_\w+)[^\n]*\n(.*?)\n\}", text, flags=re.S):
+        body = re.sub(r"//[^\n]*", "", m.group(3))
+        fields = []
+        for nm, ty in re.findall(r"pub\s+(\w+)\s*:\s*([^,]+?)\s*(?:,|$)", body.replace("\n", " ")):
+            ty = ty.strip()
+            arr = re.match(r"\[(\w+);\s*(\d+)\]$", ty)
+            if ty.startswith("*const") or ty.startswith("*mut"):
+                fields.append((nm, 8, 8, 1))
+            elif arr:
+                fields.append((nm, _RUST_SIZES[arr.group(1)], _RUST_SIZES[arr.group(1)], int(arr.group(2))))
+            else:
+                fields.append((nm, _RUST_SIZES[ty], _RUST_SIZES[ty], 1))
+        structs[m.group(2)] = (m.group(1), _layout(fields))
+    return structs
+
+
+def library_layout(name):
+    from cellranger_amd import _lib
+    L = _lib.load()
+    w = np.zeros(256, np.uint32)
+    n = L.crgpu_abi_layout(name.encode(), _lib.ptr(w), len(w))
+    assert n >= 3, (name, n)
+    nf = int(w[2])
+    assert n == 3 + 2 * nf
+    return int(w[0]), int(w[1]), [(int(w[3 + 2 * i]), int(w[4 + 2 * i])) for i in range(nf)]
+
+
+def test_public_struct_layouts_agree_everywhere():
+    """INTEGRATION.md's CrgpuRecords / CrgpuMatrix were 8 bytes short of the header.  Four views of every struct
+    that crosses the ABI must agree on field count, order, offset and width: the header (parsed), the library
+    (crgpu_abi_layout, what a binding checks at start-up), the ctypes table and the Rust #[repr(C)] blocks of INTEGRATION.md."""
+    from cellranger_amd import _lib
+    hdr = header_structs()
+    assert {"crgpu_records", "crgpu_matrix", "crgpu_matrix_dev", "crgpu_dupinfo", "crgpu_barcode_summary_row",
+            "crgpu_shard_metrics", "crgpu_rows_metrics", "crgpu_bc_correction_metrics", "crgpu_feature_def",
+            "crgpu_synth_params", "crgpu_synth_out"} == set(hdr)
+    for name, (size, align, fields) in hdr.items():
+        lsize, lalign, lfields = library_layout(name)
+        assert (size, align) == (lsize, lalign), name
+        assert [(o, s) for _, o, s in fields] == lfields, name
+    assert _lib.load().crgpu_abi_layout(b"crgpu_nonsense", None, 0) < 0
+    # ctypes table
+    ct = {"crgpu_records": _lib.Records, "crgpu_matrix": _lib.MatrixView, "crgpu_matrix_dev": _lib.MatrixDevView,
+          "crgpu_shard_metrics": _lib.ShardMetrics, "crgpu_rows_metrics": _lib.RowsMetrics,
+          "crgpu_bc_correction_metrics": _lib.BcCorrectionMetrics, "crgpu_feature_def": _lib.FeatureDef,
+          "crgpu_synth_params": _lib.SynthParams, "crgpu_synth_out": _lib.SynthOut}
+    for name, cls in ct.items():
+        size, _, fields = hdr[name]
+        assert C.sizeof(cls) == size, name
+        assert [(f[0], getattr(cls, f[0]).offset, getattr(cls, f[0]).size) for f in cls._fields_] == fields, name
+    for name, dt in (("crgpu_dupinfo", _lib.DUPINFO_DTYPE), ("crgpu_barcode_summary_row", _lib.BARCODE_SUMMARY_DTYPE)):
+        size, _, fields = hdr[name]
+        assert dt.itemsize == size, name
+        assert [(n, dt.fields[n][1], dt.fields[n][0].itemsize) for n in dt.names] == fields, name
+    # the Rust mirrors a maintainer would paste
+    rust = rust_structs()
+    assert {"crgpu_records", "crgpu_matrix", "crgpu_matrix_dev", "crgpu_dupinfo", "crgpu_barcode_summary_row",
+            "crgpu_bc_correction_metrics", "crgpu_feature_def"} <= set(rust)
+    for name, (rname, (size, align, fields)) in rust.items():
+        assert name in hdr, (rname, name)
+        assert (size, align, fields) == hdr[name], "INTEGRATION.md %s does not match %s of include/crgpu.h" % (rname, name)
+
+
+def test_stale_rust_struct_is_caught():
+    """the checker itself: the round-2 CrgpuRecords (7 fields, no d_umi_len) must not pass"""
+    stale = _layout([("n", 8, 8, 1), ("umi_len", 4, 4, 1)] + [(f, 8, 8, 1) for f in
+                    ("d_bc_idx", "d_umi", "d_umi_qualn", "d_feature", "d_flags")])
+    assert stale != header_structs()["crgpu_records"]
 
 
 def test_create_fails_loudly_without_gpu():

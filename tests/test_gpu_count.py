@@ -48,6 +48,23 @@ def _run_gpu(c, r, n, w_cb_len, umi_len, n_features, n_libs=1, mux_mask=0):
     whole = np.concatenate(parts)
     order = np.lexsort((whole["barcode_rank"], whole["library"]))
     assert np.array_equal(whole[order], dup["summary"])
+    # the host-pointer entry of SURVEY 8(b) (crgpu_count_host): same matrix, DupInfo as an array of structs, and with probe
+    # indices per read the UmiCount::probe_idx of every molecule
+    probe = (((np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) >> np.uint64(7)) % np.uint64(37)).astype(np.int32) - 1
+    m3, hd, counts5 = c.count_host(n_features, idx_b, r["umi"], r["umi_qualn"].reshape(n, umi_len), r["feature"], r["flags"],
+                                   probe_idx=probe, want_counts=True)
+    for a in ("barcode_rank", "indptr", "indices", "data"):
+        assert np.array_equal(getattr(m, a), getattr(m3, a)), a
+    assert np.array_equal(hd["processed_umi"], dup["processed_umi"]) and np.array_equal(hd["read_count"], dup["read_count"])
+    assert np.array_equal(hd["flags"], dup["flags"]) and not hd["reserved"].any()
+    for k, v in counts5.molecules().items():
+        assert np.array_equal(v, mol[k]), k
+    dup["probe_in"], dup["mol_probe"] = probe, counts5.probe_idx()
+    m4, none = c.count_host(n_features, idx_b, r["umi"], r["umi_qualn"].reshape(n, umi_len), r["feature"], r["flags"], want_dupinfo=False)
+    assert none is None and np.array_equal(m4.data, m.data) and np.array_equal(m4.indptr, m.indptr)
+    if counts.n_molecules:
+        with pytest.raises(Exception, match="without crgpu_records.d_probe_idx"):
+            counts3.probe_idx()
     return idx_b, (bc, ft, ct), mol, m, dup
 
 
@@ -74,6 +91,13 @@ def _compare_with_oracle(c, w, r, n, n_features, n_libs=1, mux_mask=0, whitelist
     assert np.array_equal(dup["read_count"][has], od["read_count"][has])
     assert not dup["read_count"][~has].any() and not dup["processed_umi"][~has].any()
     assert int(((dup["flags"] & 8) != 0).sum()) == len(mol["bc"])      # one representative read per molecule
+    # UmiCount::probe_idx (mark_dups.rs:332-342): the probe of the read process() marks is_umi_count.  The reads with that
+    # flag and the molecules are the same set of (barcode, library, feature, corrected UMI): align both by sorting
+    rep = np.flatnonzero(od["is_umi_count"] != 0)
+    r_order = np.lexsort((od["processed_umi"][rep], r["feature"][rep], (r["flags"][rep] & 0x0F), idx_b[rep]))
+    m_order = np.lexsort((mol["umi"], mol["feature"], mol["lib"], mol["bc"]))
+    assert np.array_equal(idx_b[rep][r_order], mol["bc"][m_order]) and np.array_equal(od["processed_umi"][rep][r_order], mol["umi"][m_order])
+    assert np.array_equal(dup["mol_probe"][m_order], dup["probe_in"][rep][r_order])
     # BarcodeSummary (aligner.rs:33-68) per (library, barcode)
     osum, gsum = O.barcode_summary(res, (r["flags"] & 0x0F)), dup["summary"]
     assert len(gsum) == len(osum["reads"])
