@@ -20,7 +20,7 @@ FLAG_CB_HAS_N = 0x10
 FLAG_NONTXOMIC = 0x20
 
 COUNTS_VALID, COUNTS_CORRECTED, COUNTS_PRIOR = 0, 1, 2
-T_NAMES = ["pack", "match", "correct", "keys", "sort_scatter", "dedup", "matrix", "synth", "sort_hist", "scan", "comm"]
+T_NAMES = ["pack", "match", "correct", "keys", "sort_scatter", "dedup", "matrix", "synth", "sort_hist", "scan", "comm", "feature"]
 UNIQUE_ID_BYTES = 128
 OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS = 0
 
@@ -156,6 +156,7 @@ SYMBOLS = {
     "crgpu_gatherv_dev": (_i, [_vp, _vp, _u64, _i, C.POINTER(_vp), _vp]),
     "crgpu_gather_triplets_dev": (_i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64)]),
     "crgpu_allreduce_max_f64": (_i, [_vp, C.POINTER(_dbl)]),
+    "crgpu_allreduce_sum_i64": (_i, [_vp, _vp, _u32]),
     "crgpu_destroy": (None, [_vp]),
     "crgpu_last_error": (C.c_char_p, [_vp]),
     "crgpu_synchronize": (_i, [_vp]),
@@ -230,6 +231,10 @@ SYMBOLS = {
     "crgpu_compile_feature_pattern": (_i, [C.c_char_p, _u32, C.c_char_p, _u64]),
     "crgpu_feature_extractor_regex": (_i, [_vp, _i, _u32, C.c_char_p, _u64, _vp]),
     "crgpu_extract_features_dev": (_i, [_vp, _i, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp]),
+    "crgpu_feature_counts_dev": (_i, [_vp, _vp, _u64, _u32, _vp]),
+    "crgpu_compute_feature_dist": (_i, [_vp, _vp, _u32, _vp]),
+    "crgpu_synth_rows_dev": (_i, [_vp, _u64, _u64, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
+    "crgpu_synth_rows_host": (_i, [_u64, _u64, _u64, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "crgpu_synth_dev": (_i, [_vp, C.POINTER(SynthParams), _u64, _u64, C.POINTER(SynthOut)]),
     "crgpu_synth_host": (_i, [C.POINTER(SynthParams), _u64, _u64, C.POINTER(SynthOut)]),
 }

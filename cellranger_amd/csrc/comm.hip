@@ -336,6 +336,24 @@ extern "C" int crgpu_allreduce_max_f64(crgpu_ctx *ctx, double *value_inout) {
     return CRGPU_OK;
 }
 
+// sum over the ranks of a small host array (MAKE_SHARD's feature counts, read totals): one all-gather of n words
+extern "C" int crgpu_allreduce_sum_i64(crgpu_ctx *ctx, int64_t *values_inout, uint32_t n) {
+    if (!ctx || (n && !values_inout)) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_REQUIRE(ctx, n <= (1u << 20), CRGPU_ERANGE, "crgpu_allreduce_sum_i64: at most 2^20 values (a host-side helper, not a data path)");
+    if (ctx->n_ranks == 1 || n == 0) return CRGPU_OK;
+    const int W = ctx->n_ranks;
+    std::vector<uint64_t> mine(n), all((size_t)W * n);
+    memcpy(mine.data(), values_inout, n * sizeof(uint64_t));
+    CR_TRY(comm_allgather_u64(ctx, mine.data(), n, all.data()));
+    for (uint32_t j = 0; j < n; j++) {
+        int64_t s = 0;
+        for (int r = 0; r < W; r++) s += (int64_t)all[(size_t)r * n + j];
+        values_inout[j] = s;
+    }
+    return CRGPU_OK;
+}
+
 extern "C" int crgpu_allreduce_counts(crgpu_ctx *ctx, int lib, int which) {
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);

@@ -66,6 +66,10 @@ struct FeatureExtractorSet {
     bool has_dist = false;
     bool uses_read[2] = {false, false};
     std::vector<std::string> regex;  // regex_str of every pattern as the reference would build it
+    // the extractor's only pattern when that one is tethered (the usual feature reference): k_extract_tethered_lds applies
+    bool one_tethered = false;
+    uint32_t t_read = 0, t_anchor5 = 0, t_anchor3 = 0, t_pre_len = 0, t_suf_len = 0, t_L = 0, t_n_feat = 0;
+    bool t_pre_dots = false, t_suf_dots = false;  // prefix / suffix are wildcards only
 };
 
 struct TimedSpan {
@@ -159,6 +163,7 @@ struct crgpu_ctx {
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
     uint64_t sort_refinished = 0;          // sorts whose finishing pass met a run too long for it and that were redone on all bits
     uint64_t k1_split_rounds = 0;          // table rounds of K1 whose histogram was split (table slots in LDS + staged cold hits)
+    uint64_t feature_fast_launches = 0;    // crgpu_extract_features_dev calls that took k_extract_tethered_lds
     uint64_t feature_reads_requeued = 0;   // reads k_extract_features handed to the wide-map launch
     uint64_t sort_fallbacks = 0;           // sorts whose look-back watchdog fired and that were finished by the classic passes
 

@@ -205,6 +205,9 @@ extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
         case CRGPU_STAT_K1_SPLIT_ROUNDS:
             *value_out = ctx->k1_split_rounds;
             return CRGPU_OK;
+        case CRGPU_STAT_FEATURE_FAST_LAUNCHES:
+            *value_out = ctx->feature_fast_launches;
+            return CRGPU_OK;
         case CRGPU_STAT_FEATURE_READS_REQUEUED:
             *value_out = ctx->feature_reads_requeued;
             return CRGPU_OK;

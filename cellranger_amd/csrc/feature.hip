@@ -284,7 +284,7 @@ extern "C" int crgpu_match_features_dev(crgpu_ctx *ctx, int pattern, const uint3
     CR_HIP(ctx, hipMemcpyAsync(d_pe, pe, sizeof(pe), hipMemcpyHostToDevice, ctx->stream));
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pe is a stack buffer
     PatView v{P.d_seq, P.d_index, P.has_dist ? P.d_dist : nullptr, P.n, P.len};
-    CrTimer t(ctx, CRGPU_T_MATCH, n);
+    CrTimer t(ctx, CRGPU_T_FEATURE, n);
     if (P.n <= FM_MAX_FEATURES && (uintptr_t)d_qualn % 4 == 0 && !getenv("CRGPU_FEATURES_GLOBAL")) {
         uint32_t slots = 64;
         while (slots < 2u * P.n) slots <<= 1;  // load factor <= 0.5

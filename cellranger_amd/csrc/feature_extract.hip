@@ -295,6 +295,193 @@ __global__ __launch_bounds__(256) void k_extract_features_queued(const FxView v,
     (void)fx_match_read(v, pedit, r1, r2, queue[k], rows + (size_t)k * row_entries, row_entries, feature_out, n_ids_out, capture_out);
 }
 
+// ---- ONE tethered pattern, wave per 64 rows, feature table in LDS -------------------------------------------------------
+// The common feature reference holds one pattern for all its features (Antibody Capture "5PNNNNNNNNNN(BC)", CRISPR
+// "(BC)GTTTAAGAGCTAAGCTGGAA").  k_extract_features gives such a read to one thread: 15 - 100 byte loads 96 bytes apart from
+// the next lane's, a binary search in L2 per lookup and the 3L-candidate posterior inline (2.2 / 1.3 G reads/s,
+// profiles/r02_feature_extract_throughput.txt).  Here:
+//   * a wave copies the window of its 64 rows that the pattern can touch (anchored: prefix + capture + suffix; floating: the
+//     whole row) into LDS with dword loads that sweep the rows in address order, and every lane then works on its row out
+//     of LDS (row pitch odd: no bank conflicts);
+//   * the features live in an LDS open-addressing set of 64-bit keys (sequences of up to 32 bases), as in feature.hip;
+//   * with a single capture correct_feature_barcode's map holds every candidate feature at most once (candidates of one
+//     capture are distinct sequences), so the map degenerates to a running sum and a first maximum in the reference's
+//     order -- no 16-entry map, no overflow queue; captures that need the posterior (no exact hit, at most one N) are
+//     queued per workgroup and corrected with every lane busy; only they touch the quality rows (in global memory).
+// Same results as fx_match_read for an extractor with one tethered pattern; tests/test_gpu_feature_extract.py runs both.
+#define FXT_EMPTY 0xFFFFFFFFFFFFFFFFull
+struct FxtParams {
+    uint32_t read, anchor5, anchor3, pre_len, suf_len, L, n_feat;
+    uint32_t pre_dots, suf_dots;  // the prefix / suffix hold wildcards only: nothing to compare
+    uint32_t win_lo, win_dw;      // first byte (multiple of 4) and dwords of the row window staged into LDS
+    uint32_t lanes_per_row;       // power of two >= win_dw, <= 64
+    uint32_t pitch;               // LDS dwords per row (odd)
+    uint32_t slot_mask;
+};
+struct FxtPending {
+    unsigned long long key;
+    uint32_t i_lo, i_hi, start, npos;  // npos: 1 + position of the capture's N, 0 = none
+};
+__device__ __forceinline__ uint32_t fxt_hash(unsigned long long key, uint32_t mask) {
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+}
+__device__ __forceinline__ int fxt_find(const unsigned long long *tk, const uint32_t *tv, uint32_t mask, unsigned long long key) {
+    uint32_t s = fxt_hash(key, mask);
+    for (;;) {
+        const unsigned long long e = tk[s];
+        if (e == FXT_EMPTY) return -1;
+        if (e == key) return (int)tv[s];
+        s = (s + 1u) & mask;
+    }
+}
+__device__ __forceinline__ uint32_t fxt_byte(const uint32_t *row, uint32_t b) { return (row[b >> 2] >> (8u * (b & 3u))) & 0xFFu; }
+
+template <uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v, const FxtParams P, const double *__restrict__ pedit,
+                                                                  const FxRows R, uint64_t n, uint32_t *__restrict__ feature_out,
+                                                                  uint32_t *__restrict__ n_ids_out, uint32_t *__restrict__ capture_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
+    const uint32_t slots = P.slot_mask + 1u;
+    uint32_t *s_val = reinterpret_cast<uint32_t *>(s_key + slots);
+    uint32_t *s_rows = s_val + slots + (threadIdx.x >> 6) * (64u * P.pitch);
+    FxtPending *s_pend = reinterpret_cast<FxtPending *>(s_val + slots + (THREADS / 64u) * (64u * P.pitch) +
+                                                        ((slots + (THREADS / 64u) * 64u * P.pitch) & 1u));  // 8-byte aligned
+    __shared__ uint32_t s_npend;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t L = P.L;
+    const unsigned long long *fk = reinterpret_cast<const unsigned long long *>(v.key);  // the one pattern's slice starts at 0
+    for (uint32_t t = tid; t < slots; t += THREADS) s_key[t] = FXT_EMPTY;
+    if (tid == 0) s_npend = 0;
+    __syncthreads();
+    for (uint32_t f = tid; f < P.n_feat; f += THREADS) {
+        const unsigned long long k = fk[f];
+        uint32_t t = fxt_hash(k, P.slot_mask);
+        while (atomicCAS(&s_key[t], FXT_EMPTY, k) != FXT_EMPTY) t = (t + 1u) & P.slot_mask;
+        s_val[t] = f;
+    }
+    __syncthreads();
+    const char *pre = v.chars + v.pat[0].pre_off, *suf = v.chars + v.pat[0].suf_off;
+    const uint32_t need = P.pre_len + L + P.suf_len;
+    const uint32_t tag = P.read << 30;
+
+    auto drain = [&](uint32_t first, uint32_t count) {  // pending captures [first, first + count), count <= THREADS
+        if (tid < count) {
+            const FxtPending e = s_pend[first + tid];
+            const uint64_t i = ((uint64_t)e.i_hi << 32) | e.i_lo;
+            const uint8_t *q = R.qual + i * R.stride + e.start;
+            double sum = 0.0, mx = -1.0;
+            int best = -1;
+            for (uint32_t pos = 0; pos < L; pos++) {
+                if (e.npos && e.npos != pos + 1u) continue;  // the other positions keep the N: no candidate there is a feature
+                const uint32_t sh = 2u * (L - 1u - pos);
+                const uint32_t orig = (uint32_t)(e.key >> sh) & 3u;
+                for (uint32_t b = 0; b < 4; b++) {
+                    if (!e.npos && b == orig) continue;
+                    const int f = fxt_find(s_key, s_val, P.slot_mask, (e.key & ~(3ull << sh)) | ((unsigned long long)b << sh));
+                    if (f < 0) continue;
+                    uint32_t qv = (uint8_t)(q[pos] - 33u);  // u8 arithmetic as in feature_extraction.rs:43
+                    qv = qv < 33u ? qv : 33u;
+                    const double like = v.dist[f] * pedit[qv];
+                    sum += like;
+                    if (like > mx) {
+                        mx = like;
+                        best = f;
+                    }
+                }
+            }
+            const bool hit = best >= 0 && (mx / sum) >= 0.975;  // FEATURE_CONF_THRESHOLD (:21-22,113)
+            feature_out[i] = hit ? v.index[best] : CRGPU_NO_FEATURE;
+            if (n_ids_out) n_ids_out[i] = hit ? 1u : 0u;
+            if (capture_out) capture_out[i] = (hit ? 0x80000000u : 0u) | tag | (e.start << 8) | L;
+        }
+    };
+
+    for (uint64_t base = (uint64_t)blockIdx.x * THREADS; base < n; base += (uint64_t)gridDim.x * THREADS) {
+        const uint64_t wrow = base + (tid & ~63u);  // the wave's first row
+        // ---- stage the window of 64 rows --------------------------------------------------------------------------
+        __builtin_amdgcn_wave_barrier();
+        {
+            const uint32_t rows_per = 64u / P.lanes_per_row, col = lane & (P.lanes_per_row - 1u), sub = lane / P.lanes_per_row;
+            const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(R.seq);
+            const uint64_t stride_dw = R.stride >> 2;
+#pragma unroll 4
+            for (uint32_t it = 0; it < P.lanes_per_row; it++) {
+                const uint32_t r = it * rows_per + sub;
+                const uint64_t row = wrow + r;
+                const uint64_t rc = row < n ? row : n - 1;  // clamped: no load behind a branch
+                const uint32_t cc = col < P.win_dw ? col : P.win_dw - 1u;
+                const uint32_t w = src[rc * stride_dw + (P.win_lo >> 2) + cc];
+                if (col < P.win_dw) s_rows[r * P.pitch + col] = w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t i = base + tid;
+        if (i < n) {
+            const uint32_t *row = s_rows + lane * P.pitch;
+            const uint32_t len = R.len ? min(R.len[i], R.stride) : R.stride;
+            uint32_t found = FX_NO_CAPTURE;
+            if (len >= need) {
+                uint32_t s_lo = 0, s_hi = len - need;
+                bool possible = true;
+                if (P.anchor3) s_lo = s_hi;
+                if (P.anchor5) {
+                    possible = s_lo == 0;
+                    s_hi = 0;
+                }
+                if (possible)
+                    for (uint32_t st = s_lo; st <= s_hi && found == FX_NO_CAPTURE; st++) {
+                        bool ok = true;
+                        if (!P.pre_dots)
+                            for (uint32_t k = 0; k < P.pre_len && ok; k++)
+                                ok = pre[k] == '.' || (uint32_t)(uint8_t)pre[k] == fxt_byte(row, st + k - P.win_lo);
+                        if (!P.suf_dots)
+                            for (uint32_t k = 0; k < P.suf_len && ok; k++)
+                                ok = suf[k] == '.' || (uint32_t)(uint8_t)suf[k] == fxt_byte(row, st + P.pre_len + L + k - P.win_lo);
+                        if (ok) found = st + P.pre_len;
+                    }
+            }
+            if (found == FX_NO_CAPTURE) {
+                feature_out[i] = CRGPU_NO_FEATURE;
+                if (n_ids_out) n_ids_out[i] = 0u;
+                if (capture_out) capture_out[i] = FX_NO_CAPTURE;
+            } else {
+                unsigned long long key = 0;
+                uint32_t n_bad = 0, npos = 0;
+                for (uint32_t k = 0; k < L; k++) {
+                    const uint32_t c = fx_code((uint8_t)fxt_byte(row, found + k - P.win_lo));
+                    key = (key << 2) | (c & 3u);
+                    if (c >> 2) {
+                        n_bad++;
+                        npos = k + 1u;
+                    }
+                }
+                const int exact = n_bad ? -1 : fxt_find(s_key, s_val, P.slot_mask, key);
+                if (exact >= 0) {
+                    feature_out[i] = v.index[exact];  // find_closest's fast path (:452-457)
+                    if (n_ids_out) n_ids_out[i] = 1u;
+                    if (capture_out) capture_out[i] = 0x80000000u | tag | (found << 8) | L;
+                } else if (v.dist && n_bad <= 1u) {
+                    const uint32_t slot = atomicAdd(&s_npend, 1u);  // < 2 * THREADS: fewer than THREADS left over + THREADS new
+                    s_pend[slot] = FxtPending{key, (uint32_t)i, (uint32_t)(i >> 32), found, npos};
+                } else {
+                    feature_out[i] = CRGPU_NO_FEATURE;
+                    if (n_ids_out) n_ids_out[i] = 0u;
+                    if (capture_out) capture_out[i] = tag | (found << 8) | L;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t np = s_npend;
+        if (np >= THREADS) {  // uniform
+            drain(np - THREADS, THREADS);  // the newest ones: the older ones stay at the front
+            __syncthreads();
+            if (tid == 0) s_npend = np - THREADS;
+        }
+        __syncthreads();
+    }
+    drain(0u, s_npend);  // fewer than THREADS left
+}
+
 // ---- host: the patterns ------------------------------------------------------------------------------------------------
 namespace {
 
@@ -549,6 +736,19 @@ extern "C" int crgpu_set_feature_extractor(crgpu_ctx *ctx, int extractor, const 
     X.uses_read[0] = X.uses_read[1] = false;
     for (const auto &P : pats) X.uses_read[P.read] = true;
     X.regex = regexes;
+    if (pats.size() == 1 && pats[0].tethered && !pats[0].never) {
+        const HostPattern &P0 = pats[0];
+        X.one_tethered = true;
+        X.t_read = (uint32_t)P0.read;
+        X.t_anchor5 = P0.anchor5;
+        X.t_anchor3 = P0.anchor3;
+        X.t_pre_len = (uint32_t)P0.prefix.size();
+        X.t_suf_len = (uint32_t)P0.suffix.size();
+        X.t_L = P0.L;
+        X.t_n_feat = (uint32_t)P0.feats.size();
+        X.t_pre_dots = P0.prefix.find_first_not_of('.') == std::string::npos;
+        X.t_suf_dots = P0.suffix.find_first_not_of('.') == std::string::npos;
+    }
     X.set = true;
     ctx->fx[extractor] = X;
     return CRGPU_OK;
@@ -599,6 +799,51 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
              (const uint32_t *)(base + X.off_ha_key), (const uint32_t *)(base + X.off_ha_f), (const uint32_t *)(base + X.off_hb_key),
              (const uint32_t *)(base + X.off_hb_f)};
     FxRows r1{d_r1_seq, d_r1_qual, d_r1_len, r1_stride}, r2{d_r2_seq, d_r2_qual, d_r2_len, r2_stride};
+    // ---- one tethered pattern: wave-per-rows kernel with the table in LDS (k_extract_tethered_lds) ----------------------
+    if (X.one_tethered && X.t_n_feat <= 4096u && !getenv("CRGPU_FEATURES_GLOBAL")) {
+        const FxRows &R = X.t_read ? r2 : r1;
+        const uint32_t need = X.t_pre_len + X.t_L + X.t_suf_len;
+        const bool aligned = R.stride % 4 == 0 && (uintptr_t)R.seq % 4 == 0;
+        uint32_t win_lo = 0, win_hi = R.stride;           // floating pattern (or per-row lengths with '$'): the whole row
+        if (X.t_anchor5) win_hi = std::min(R.stride, (need + 3u) & ~3u);
+        else if (X.t_anchor3 && !R.len && need <= R.stride) win_lo = (R.stride - need) & ~3u;
+        const uint32_t win_dw = (win_hi - win_lo) / 4u;
+        if (aligned && win_dw >= 1 && win_dw <= 64u && R.stride >= 4) {
+            FxtParams P{};
+            P.read = X.t_read;
+            P.anchor5 = X.t_anchor5;
+            P.anchor3 = X.t_anchor3;
+            P.pre_len = X.t_pre_len;
+            P.suf_len = X.t_suf_len;
+            P.L = X.t_L;
+            P.n_feat = X.t_n_feat;
+            P.pre_dots = X.t_pre_dots;
+            P.suf_dots = X.t_suf_dots;
+            P.win_lo = win_lo;
+            P.win_dw = win_dw;
+            P.lanes_per_row = 1;
+            while (P.lanes_per_row < win_dw) P.lanes_per_row <<= 1;
+            P.pitch = win_dw | 1u;
+            uint32_t slots = 64;
+            while (slots < 2u * X.t_n_feat) slots <<= 1;  // load factor <= 0.5
+            P.slot_mask = slots - 1u;
+            CrTimer t(ctx, CRGPU_T_FEATURE, n);
+            if (X.t_n_feat <= 1024u) {
+                const size_t lds = (size_t)slots * 12 + (size_t)4 * 64 * P.pitch * 4 + 8 + 2 * 256 * sizeof(FxtPending);
+                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<256>, lds);
+                hipLaunchKernelGGL(k_extract_tethered_lds<256>, dim3(cr_grid(n, 256, 256u * 4u)), dim3(256), lds, ctx->stream, v, P,
+                                   d_pe, R, n, d_feature_out, d_n_ids_out, d_capture_out);
+            } else {
+                const size_t lds = (size_t)slots * 12 + (size_t)16 * 64 * P.pitch * 4 + 8 + 2 * 1024 * sizeof(FxtPending);
+                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<1024>, lds);
+                hipLaunchKernelGGL(k_extract_tethered_lds<1024>, dim3(cr_grid(n, 1024, 256u)), dim3(1024), lds, ctx->stream, v, P, d_pe,
+                                   R, n, d_feature_out, d_n_ids_out, d_capture_out);
+            }
+            CR_HIP(ctx, hipGetLastError());
+            ctx->feature_fast_launches++;
+            return CRGPU_OK;
+        }
+    }
     // the queue of reads whose map outgrew the local array: sized so that their global map rows stay below 256 MB;
     // more than that many are handled by further rounds over what is left
     const uint32_t row_entries = std::max(X.max_feat, 1u);
@@ -612,7 +857,7 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
         ~Release() { cr_pool_free(c, p); }
     } rel_q{ctx, queue_p};
     uint64_t *d_queue = (uint64_t *)queue_p;
-    CrTimer t(ctx, CRGPU_T_MATCH, n);
+    CrTimer t(ctx, CRGPU_T_FEATURE, n);
     hipLaunchKernelGGL(k_extract_features, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, v, d_pe, r1, r2, n, d_feature_out,
                        d_n_ids_out, d_capture_out, d_nq, d_queue, queue_cap);
     CR_HIP(ctx, hipGetLastError());
@@ -630,5 +875,71 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
                        (FxEntry *)rows_p, row_entries, d_feature_out, d_n_ids_out, d_capture_out);
     CR_HIP(ctx, hipGetLastError());
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the rows go back to the pool
+    return CRGPU_OK;
+}
+
+// ---- the prior: MAKE_SHARD's exact-match feature counts and compute_feature_dist ------------------------------------------
+__global__ __launch_bounds__(256) void k_feature_counts(const uint32_t *__restrict__ feature, uint64_t n, uint32_t n_features,
+                                                        unsigned long long *__restrict__ counts) {
+    // a few hundred features: per-workgroup LDS counters for tables that fit, global atomics beyond
+    extern __shared__ uint32_t s_cnt[];
+    const bool lds = n_features <= 8192u;
+    if (lds) {
+        for (uint32_t f = threadIdx.x; f < n_features; f += 256) s_cnt[f] = 0;
+        __syncthreads();
+    }
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t f = feature[i];
+        if (f >= n_features) continue;
+        if (lds) atomicAdd(&s_cnt[f], 1u); else atomicAdd(&counts[f], 1ull);
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t f = threadIdx.x; f < n_features; f += 256)
+            if (s_cnt[f]) atomicAdd(&counts[f], (unsigned long long)s_cnt[f]);
+    }
+}
+
+extern "C" int crgpu_feature_counts_dev(crgpu_ctx *ctx, const uint32_t *d_feature, uint64_t n, uint32_t n_features,
+                                        int64_t *counts_inout) {
+    if (!ctx || !counts_inout || !n_features) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    if (n == 0) return CRGPU_OK;
+    CR_REQUIRE(ctx, d_feature, CRGPU_EINVAL, "crgpu_feature_counts_dev: NULL features");
+    void *d_c = nullptr;
+    CR_TRY(cr_pool_alloc(ctx, &d_c, (uint64_t)n_features * 8));
+    struct Rel {
+        crgpu_ctx *c;
+        void *p;
+        ~Rel() { cr_pool_free(c, p); }
+    } rel{ctx, d_c};
+    CR_HIP(ctx, hipMemsetAsync(d_c, 0, (size_t)n_features * 8, ctx->stream));
+    {
+        CrTimer t(ctx, CRGPU_T_FEATURE, n);
+        const size_t lds = n_features <= 8192u ? (size_t)n_features * 4 : 4;
+        hipLaunchKernelGGL(k_feature_counts, dim3(cr_grid(n, 256 * 8, 256u * 4u)), dim3(256), lds, ctx->stream, d_feature, n, n_features,
+                           (unsigned long long *)d_c);
+        CR_HIP(ctx, hipGetLastError());
+    }
+    std::vector<unsigned long long> h(n_features);
+    CR_TRY(crgpu_memcpy_d2h(ctx, h.data(), d_c, (uint64_t)n_features * 8));
+    for (uint32_t f = 0; f < n_features; f++) counts_inout[f] += (int64_t)h[f];
+    return CRGPU_OK;
+}
+
+// compute_feature_dist (cr_types/src/reference/feature_checker.rs:8-50)
+extern "C" int crgpu_compute_feature_dist(const int64_t *counts, const uint32_t *feature_type, uint32_t n_features, double *dist_out) {
+    if (!counts || !dist_out) return CRGPU_EINVAL;
+    std::map<uint32_t, int64_t> sums;
+    for (uint32_t i = 0; i < n_features; i++) sums[feature_type ? feature_type[i] : 0u] += counts[i];
+    bool all_zero = true;
+    for (uint32_t i = 0; i < n_features; i++) {
+        const int64_t sum = sums[feature_type ? feature_type[i] : 0u];
+        dist_out[i] = sum > 0 ? (double)counts[i] / (double)sum : 0.0;
+        if (dist_out[i] != 0.0) all_zero = false;
+    }
+    if (all_zero)
+        for (uint32_t i = 0; i < n_features; i++) dist_out[i] = 1.0 / (double)n_features;
     return CRGPU_OK;
 }

@@ -101,3 +101,61 @@ extern "C" int crgpu_synth_host(const crgpu_synth_params *p, uint64_t first, uin
     for (auto &t : th) t.join();
     return CRGPU_OK;
 }
+
+// ---- Feature Barcoding read rows (synth_core.h: cr_synth_row) -------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_synth_rows(uint64_t seed, uint64_t first, uint64_t n, const uint32_t *__restrict__ feature,
+                                                    const uint64_t *__restrict__ feat_seq, uint32_t n_feat, uint32_t L, uint32_t offset,
+                                                    uint32_t row_stride, uint32_t err, uint32_t n_rate, uint8_t *__restrict__ seq,
+                                                    uint8_t *__restrict__ qual) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        cr_synth_row(seed, first + k, feature ? feature[k] : CRGPU_NO_FEATURE, feat_seq, n_feat, L, offset, row_stride, err, n_rate,
+                     seq + k * row_stride, qual + k * row_stride);
+}
+
+static int check_rows(crgpu_ctx *ctx, const uint64_t *feat_seq, uint32_t n_feat, uint32_t L, uint32_t offset, uint32_t row_stride) {
+    if (!feat_seq || !n_feat || L < 1 || L > 32 || offset + L > row_stride)
+        return cr_fail(ctx, CRGPU_EINVAL, "synth rows: %u features of %u bases at offset %u in rows of %u bytes", n_feat, L, offset, row_stride);
+    return CRGPU_OK;
+}
+
+extern "C" int crgpu_synth_rows_dev(crgpu_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, const uint32_t *d_feature,
+                                    const uint64_t *feat_seq, uint32_t n_feat, uint32_t L, uint32_t offset, uint32_t row_stride,
+                                    uint32_t err_per_2_16, uint32_t n_per_2_20, uint8_t *d_seq_rows, uint8_t *d_qual_rows) {
+    if (!ctx || !d_seq_rows || !d_qual_rows) return CRGPU_EINVAL;
+    CR_ENTER(ctx);
+    CR_TRY(check_rows(ctx, feat_seq, n_feat, L, offset, row_stride));
+    if (n == 0) return CRGPU_OK;
+    cr_invalidate(ctx);
+    void *d_fs = nullptr;
+    CR_TRY(cr_pool_alloc(ctx, &d_fs, n_feat * sizeof(uint64_t)));
+    int rc = crgpu_memcpy_h2d(ctx, d_fs, feat_seq, n_feat * sizeof(uint64_t));
+    if (rc == CRGPU_OK) {
+        CrTimer t(ctx, CRGPU_T_SYNTH, n);
+        hipLaunchKernelGGL(k_synth_rows, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, seed, first, n, d_feature,
+                           (const uint64_t *)d_fs, n_feat, L, offset, row_stride, err_per_2_16, n_per_2_20, d_seq_rows, d_qual_rows);
+        if (hipGetLastError() != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "k_synth_rows launch failed");
+    }
+    cr_pool_free(ctx, d_fs);
+    return rc;
+}
+
+extern "C" int crgpu_synth_rows_host(uint64_t seed, uint64_t first, uint64_t n, const uint32_t *feature, const uint64_t *feat_seq,
+                                     uint32_t n_feat, uint32_t L, uint32_t offset, uint32_t row_stride, uint32_t err_per_2_16,
+                                     uint32_t n_per_2_20, uint8_t *seq_rows, uint8_t *qual_rows) {
+    if (!seq_rows || !qual_rows) return CRGPU_EINVAL;
+    CR_TRY(check_rows(nullptr, feat_seq, n_feat, L, offset, row_stride));
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 16) nt = 16;
+    if (n < 65536) nt = 1;
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t k = lo; k < hi; k++)
+            cr_synth_row(seed, first + k, feature ? feature[k] : CRGPU_NO_FEATURE, feat_seq, n_feat, L, offset, row_stride, err_per_2_16,
+                         n_per_2_20, seq_rows + k * row_stride, qual_rows + k * row_stride);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto &t : th) t.join();
+    return CRGPU_OK;
+}

@@ -127,3 +127,34 @@ CR_HD void cr_synth_read(const crgpu_synth_params &p, uint64_t i, CrSynthRead &o
     if (p.n_libs > 1) lib = (uint32_t)(cr_rnd(p.seed, i, 5) % p.n_libs);
     out.flags = (uint8_t)(lib | (cb_n ? CRGPU_FLAG_CB_HAS_N : 0u));
 }
+
+// ---- read rows of a Feature Barcoding library (BASELINE configs[3]) ---------------------------------------------------------
+// Row i: row_stride random bases with plain qualities; bases [offset, offset + L) hold the sequence of the read's true
+// feature (feat_seq[feature], 2-bit packed, first base most significant) -- or stay random when the read has none --
+// with per-base substitutions (quality from the error model) and Ns.  ASCII, as the FASTQ holds them.
+CR_HD void cr_synth_row(uint64_t seed, uint64_t i, uint32_t feature, const uint64_t *feat_seq, uint32_t n_feat, uint32_t L,
+                        uint32_t offset, uint32_t row_stride, uint32_t err_per_2_16, uint32_t n_per_2_20, uint8_t *seq,
+                        uint8_t *qual) {
+    const char acgt[4] = {'A', 'C', 'G', 'T'};
+    const bool planted = feature < n_feat;
+    const uint64_t fs = planted ? feat_seq[feature] : 0ull;
+    for (uint32_t b = 0; b < row_stride; b++) {
+        const uint64_t r = cr_rnd(seed, i, 1000u + b);
+        uint32_t base = (uint32_t)(r >> 60) & 3u;
+        uint32_t q = cr_qual_ok((uint32_t)((r >> 16) & 0xFFFFu));
+        bool is_n = false;
+        if (b >= offset && b < offset + L) {
+            if (planted) base = (uint32_t)(fs >> (2u * (L - 1u - (b - offset)))) & 3u;
+            const uint32_t r_err = (uint32_t)(r & 0xFFFFu), r_n = (uint32_t)((r >> 32) & 0xFFFFFu);
+            if (r_n < n_per_2_20) {
+                is_n = true;
+                q = 35u;
+            } else if (r_err < err_per_2_16) {
+                base = (base + 1u + (uint32_t)(r >> 52) % 3u) & 3u;
+                q = cr_qual_err((uint32_t)((r >> 16) & 0xFFFFu));
+            }
+        }
+        seq[b] = is_n ? (uint8_t)'N' : (uint8_t)acgt[base];
+        qual[b] = (uint8_t)q;
+    }
+}

@@ -39,6 +39,29 @@ def unpack_seqs(packed, length):
     return out
 
 
+def compute_feature_dist(counts, feature_types=None):
+    """compute_feature_dist (feature_checker.rs:8-50) through the C ABI (host code)"""
+    c = np.ascontiguousarray(counts, dtype=np.int64)
+    t = None if feature_types is None else np.ascontiguousarray(feature_types, dtype=np.uint32)
+    out = np.zeros(len(c), np.float64)
+    rc = _lib.load().crgpu_compute_feature_dist(ptr(c), ptr(t), len(c), ptr(out))
+    if rc != 0:
+        raise _lib.CrgpuError(rc, "crgpu_compute_feature_dist")
+    return out
+
+
+def synth_rows_host(seed, first, n, feature, feat_seq, L, offset, row_stride, err=0.005, n_rate=0.0005):
+    """host twin of Context.synth_rows: (seq rows, qual rows) uint8 (n, row_stride)"""
+    fs = np.ascontiguousarray(feat_seq, dtype=np.uint64)
+    ft = None if feature is None else np.ascontiguousarray(feature, dtype=np.uint32)
+    s, q = np.zeros((n, row_stride), np.uint8), np.zeros((n, row_stride), np.uint8)
+    rc = _lib.load().crgpu_synth_rows_host(seed, first, n, ptr(ft), ptr(fs), len(fs), L, offset, row_stride,
+                                           int(round(err * 65536)), int(round(n_rate * (1 << 20))), ptr(s), ptr(q))
+    if rc != 0:
+        raise _lib.CrgpuError(rc, "crgpu_synth_rows_host")
+    return s, q
+
+
 def compile_feature_pattern(pattern, length):
     """compile_pattern (feature_extraction.rs:307-343): the regular expression as text, None for a rejected pattern"""
     buf = C.create_string_buffer(4096)
@@ -336,6 +359,12 @@ class Context:
         self._check(self.L.crgpu_allreduce_max_f64(self.h, C.byref(v)))
         return v.value
 
+    def allreduce_sum(self, values):
+        """element-wise sum over the ranks of a small int64 host array, in place"""
+        assert values.dtype == np.int64 and values.flags["C_CONTIGUOUS"]
+        self._check(self.L.crgpu_allreduce_sum_i64(self.h, ptr(values), len(values)))
+        return values
+
     def exchange_keys(self, d_keys, n_keys):
         """C2: (DeviceArray of this rank's keys, n, bounds)"""
         p, n = C.c_void_p(), C.c_uint64()
@@ -387,6 +416,10 @@ class Context:
     def upload(self, arr):
         a = np.ascontiguousarray(arr)
         return DeviceArray(self, a.shape, a.dtype).upload(a)
+
+    def stream_handle(self):
+        """the hipStream_t of the context as an integer (torch.cuda.ExternalStream)"""
+        return int(self.L.crgpu_stream(self.h) or 0)
 
     def synchronize(self):
         self._check(self.L.crgpu_synchronize(self.h))
@@ -742,6 +775,18 @@ class Context:
         b = r2 or (None, None, None, 0)
         self._check(self.L.crgpu_extract_features_dev(self.h, extractor, _p(a[0]), _p(a[1]), _p(a[2]), a[3], _p(b[0]), _p(b[1]),
                                                       _p(b[2]), b[3], n, _p(d_feature_out), _p(d_n_ids_out), _p(d_capture_out)))
+
+    def feature_counts(self, d_feature, n, n_features, counts=None):
+        """MAKE_SHARD's feature_counts (make_shard_metrics.rs:336-345): counts[f] += reads whose feature is f"""
+        counts = np.zeros(n_features, np.int64) if counts is None else counts
+        self._check(self.L.crgpu_feature_counts_dev(self.h, _p(d_feature), n, n_features, ptr(counts)))
+        return counts
+
+    def synth_rows(self, seed, first, n, d_feature, feat_seq, L, offset, row_stride, d_seq_rows, d_qual_rows, err=0.005, n_rate=0.0005):
+        """Feature Barcoding read rows on the device (crgpu_synth_rows_dev); feat_seq: packed u64 sequences"""
+        fs = np.ascontiguousarray(feat_seq, dtype=np.uint64)
+        self._check(self.L.crgpu_synth_rows_dev(self.h, seed, first, n, _p(d_feature), ptr(fs), len(fs), L, offset, row_stride,
+                                                int(round(err * 65536)), int(round(n_rate * (1 << 20))), _p(d_seq_rows), _p(d_qual_rows)))
 
     # ---- synthetic data --------------------------------------------------------------------------------
     def synth(self, params, first, n, cb=None, cb_qualn=None, umi=None, umi_qualn=None, feature=None, flags=None):

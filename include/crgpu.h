@@ -107,6 +107,7 @@ int crgpu_invalidate(crgpu_ctx *ctx);
 #define CRGPU_STAT_SORT_FALLBACKS 0  /* sorts whose look-back watchdog fired and that the classic passes finished */
 #define CRGPU_STAT_K1_SPLIT_ROUNDS 3 /* table rounds of pass A whose histogram was split: table hits counted per slot in LDS, the other hits staged */
 #define CRGPU_STAT_FEATURE_READS_REQUEUED 2 /* reads of crgpu_extract_features_dev redone with the wide correction map */
+#define CRGPU_STAT_FEATURE_FAST_LAUNCHES 4 /* crgpu_extract_features_dev calls served by the one-tethered-pattern LDS kernel */
 #define CRGPU_STAT_SORT_REFINISHED 1 /* sorts redone on all key bits because a run of equal top bits was too long for the finishing pass */
 int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out);
 /* ctx may be NULL: returns the message of the last failed crgpu_create on this thread. */
@@ -138,7 +139,8 @@ int crgpu_memset(crgpu_ctx *ctx, void *d_dst, int value, uint64_t bytes);
 #define CRGPU_T_SORT_HIST 8   /* radix sort: digit histogram kernel (one span per pass) */
 #define CRGPU_T_SCAN 9        /* small scans of block histograms / block counts */
 #define CRGPU_T_COMM 10       /* collectives (C1 all-reduce, C2 key exchange, C3 gather) incl. their waiting time */
-#define CRGPU_T_NSLOTS 11
+#define CRGPU_T_FEATURE 11    /* feature-barcode extraction / matching (K3, K3x) and the exact-match feature counts */
+#define CRGPU_T_NSLOTS 12
 int crgpu_timing_enable(crgpu_ctx *ctx, int on);
 int crgpu_timing_reset(crgpu_ctx *ctx);
 /* ms_out / launches_out / units_out [CRGPU_T_NSLOTS] (any may be NULL); synchronises.  units = the
@@ -336,6 +338,9 @@ int crgpu_exchange_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, uint64_t n_k
 int crgpu_gatherv_dev(crgpu_ctx *ctx, const void *d_src, uint64_t bytes, int root, void **d_out, uint64_t *bytes_out);
 /* max over the ranks of a host double (bench timing) */
 int crgpu_allreduce_max_f64(crgpu_ctx *ctx, double *value_inout);
+/* element-wise sum over the ranks of a small host array, in place (the per-feature exact-match counts of a read-sharded
+ * Feature Barcoding library before crgpu_compute_feature_dist: the join of make_shard.rs:343-358 sums them over chunks) */
+int crgpu_allreduce_sum_i64(crgpu_ctx *ctx, int64_t *values_inout, uint32_t n);
 
 /* ---- host-buffer convenience: the signatures of SURVEY.md 8(b) ------------------------------------
  * seq/qual are n x len ASCII host arrays exactly as the Rust host holds them (RnaRead raw barcode
@@ -635,6 +640,17 @@ int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const uint8_t *d_r
                                const uint8_t *d_r2_qual, const uint32_t *d_r2_len, uint32_t r2_stride, uint64_t n,
                                uint32_t *d_feature_out, uint32_t *d_n_ids_out, uint32_t *d_capture_out);
 
+/* The prior of the feature-barcode correction: MAKE_SHARD counts, per feature, the reads whose
+ * match_read WITHOUT a distribution yields exactly one id (cr_lib/src/make_shard_metrics.rs:336-345), and
+ * compute_feature_dist turns the counts into proportions within each feature type (cr_types/src/reference/
+ * feature_checker.rs:8-50; all-zero counts: 1 / n each).
+ *   crgpu_feature_counts_dev      counts_inout[f] += reads with d_feature[i] == f (f < n_features; CRGPU_NO_FEATURE and
+ *                                 out-of-range values are skipped): run crgpu_extract_features_dev on an extractor set
+ *                                 WITHOUT feat_dist, then this; host array, accumulates over batches.
+ *   crgpu_compute_feature_dist    feature_type[f] = small id of the feature's type (NULL: one type); dist_out[n_features]. */
+int crgpu_feature_counts_dev(crgpu_ctx *ctx, const uint32_t *d_feature, uint64_t n, uint32_t n_features, int64_t *counts_inout);
+int crgpu_compute_feature_dist(const int64_t *counts, const uint32_t *feature_type, uint32_t n_features, double *dist_out);
+
 /* ---- synthetic workloads (bench / tests) ---------------------------------------------
  * Counter-based integer generator: read i of a given seed is identical on the host and on the
  * device.  Tables are host arrays built by cellranger_amd.synth. */
@@ -669,6 +685,18 @@ typedef struct {
 int crgpu_synth_dev(crgpu_ctx *ctx, const crgpu_synth_params *p, uint64_t first, uint64_t n,
                     const crgpu_synth_out *d_out);
 int crgpu_synth_host(const crgpu_synth_params *p, uint64_t first, uint64_t n, const crgpu_synth_out *h_out);
+
+/* Read rows of a Feature Barcoding library (BASELINE configs[3]; bench / tests): row i = row_stride random bases with plain
+ * qualities whose bases [offset, offset + L) hold feat_seq[feature[i]] (2-bit packed, host array of n_feat sequences of L
+ * <= 32 bases; a read whose feature is >= n_feat, e.g. CRGPU_NO_FEATURE, keeps random bases there), with substitutions
+ * (err_per_2_16) and Ns (n_per_2_20) as in crgpu_synth_params.  ASCII rows as the FASTQ holds them
+ * (crgpu_extract_features_dev's input).  Host and device produce the same bytes. */
+int crgpu_synth_rows_dev(crgpu_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, const uint32_t *d_feature,
+                         const uint64_t *feat_seq, uint32_t n_feat, uint32_t L, uint32_t offset, uint32_t row_stride,
+                         uint32_t err_per_2_16, uint32_t n_per_2_20, uint8_t *d_seq_rows, uint8_t *d_qual_rows);
+int crgpu_synth_rows_host(uint64_t seed, uint64_t first, uint64_t n, const uint32_t *feature, const uint64_t *feat_seq,
+                          uint32_t n_feat, uint32_t L, uint32_t offset, uint32_t row_stride, uint32_t err_per_2_16,
+                          uint32_t n_per_2_20, uint8_t *seq_rows, uint8_t *qual_rows);
 
 #ifdef __cplusplus
 }

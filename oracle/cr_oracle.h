@@ -241,6 +241,9 @@ uint32_t oracle_extractor_n_patterns(const oracle_extractor *x);
 const char *oracle_extractor_regex(const oracle_extractor *x, uint32_t pattern);
 int oracle_match_read(const oracle_extractor *x, const char *r1, const uint8_t *q1, uint32_t l1, const char *r2,
                       const uint8_t *q2, uint32_t l2, oracle_feature_data *out);
+/* match_read over n rows -> feature index when ids.len() == 1, else ORACLE_NO_FEATURE (OpenMP over rows) */
+void oracle_match_rows(const oracle_extractor *x, int which_read, const char *rows, const uint8_t *quals, const uint32_t *len,
+                       uint32_t stride, uint64_t n, int n_threads, uint32_t *feature_out);
 /* compile_pattern (:307-343) / compile_bare_patterns (:291-305): the regular expression as a string; -1 = invalid */
 int oracle_compile_feature_pattern(const char *orig_pat, uint32_t length, char *out, size_t out_cap);
 int oracle_compile_bare_patterns(const char *const *seqs, uint32_t n, char *out, size_t out_cap);

@@ -499,3 +499,21 @@ int oracle_match_read(const oracle_extractor *x, const char *r1, const uint8_t *
     }
     return 0;
 }
+
+/* match_read over rows (one read per row of `stride` bytes, every row full unless len is given): the feature index when
+ * FeatureData::ids holds exactly one id, else ORACLE_NO_FEATURE -- what make_shard_metrics.rs:336-345 counts and what
+ * tx_annotation counts as the read's feature (read.rs:983-987).  n_threads > 1: rows fanned out with OpenMP (the CPU
+ * baseline of bench.py's cfg4; the reference does this per read inside its chunk processes). */
+void oracle_match_rows(const oracle_extractor *x, int which_read, const char *rows, const uint8_t *quals, const uint32_t *len,
+                       uint32_t stride, uint64_t n, int n_threads, uint32_t *feature_out) {
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for num_threads(n_threads) schedule(static, 4096)
+    for (uint64_t i = 0; i < n; i++) {
+        oracle_feature_data d;
+        const uint32_t l = len ? (len[i] < stride ? len[i] : stride) : stride;
+        const char *s = rows + i * stride;
+        const uint8_t *q = quals + i * stride;
+        int ok = which_read == 0 ? oracle_match_read(x, s, q, l, NULL, NULL, 0, &d) : oracle_match_read(x, NULL, NULL, 0, s, q, l, &d);
+        feature_out[i] = (ok && d.n_ids == 1) ? d.ids[0] : ORACLE_NO_FEATURE;
+    }
+}

@@ -485,6 +485,18 @@ class FeatureExtractor:
         return dict(corrected=bool(out.corrected), n_ids=out.n_ids, ids=sorted(out.ids[:min(out.n_ids, 16)]), read=out.read,
                     start=out.start, len=out.len, corrected_barcode=out.corrected_barcode.decode() if out.corrected else None)
 
+    def match_rows(self, rows, quals, read=1, lengths=None, n_threads=1):
+        """match_read over (n, stride) uint8 rows -> feature index where ids.len() == 1, else NO_FEATURE"""
+        rows, quals = np.ascontiguousarray(rows, np.uint8), np.ascontiguousarray(quals, np.uint8)
+        n, stride = rows.shape
+        out = np.zeros(n, np.uint32)
+        ln = None if lengths is None else np.ascontiguousarray(lengths, np.uint32)
+        f = lib().oracle_match_rows
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+        f(self.h, read, _ptr(rows), _ptr(quals), None if ln is None else _ptr(ln), stride, n, n_threads, _ptr(out))
+        return out
+
     def close(self):
         if self.h:
             lib().oracle_extractor_free(self.h)

@@ -325,3 +325,115 @@ def test_fastq_ingest_rows_and_whole_read_metrics():
     with pytest.raises(CrgpuError):
         c.fastq_to_rows(c.upload(bad), len(bad), stride, 4, d_seq, d_qual, d_len)
     c.close()
+
+
+def test_cfg4_one_flow_trans_whitelist_pattern_two_libraries():
+    """BASELINE configs[3] as SURVEY 8(d) specifies it, as ONE flow on the device: an Antibody Capture library on a `Trans`
+    whitelist (raw FB barcodes translate onto the GEX list, whitelist.rs:497-504) beside a Gene Expression library in the
+    same GEM well; the FB reads' features come from whole R2 rows through the anchored pattern ^N{10}(BC)
+    (crgpu_extract_features_dev), first without a distribution to collect MAKE_SHARD's exact-match counts
+    (make_shard_metrics.rs:336-345 -> compute_feature_dist), then with it; both libraries are then counted together.
+    Every stage is compared with the oracle: per-read barcode ranks, the prior, per-read features, per-read DupInfo, matrix."""
+    import gpu_helpers as G
+    import oracle_lib as O
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import NO_FEATURE
+
+    n0, n1, n_genes, n_fb, L, off, stride = 40_000, 60_000, 300, 48, 15, 10, 40
+    rng = np.random.default_rng(40404)   # not the workload's seed: the same PCG64 stream would redraw its whitelist
+    kw = dict(n_wl=3000, n_cells=60, n_ambient=300, reads_per_umi=3)
+    w = S.Workload(n_total=n0, seed=404, n_genes=n_genes, **kw)
+    canon = w.wl_packed
+    raw = np.setdiff1d(np.unique(rng.integers(0, 1 << 32, size=5000, dtype=np.uint64)).astype(np.uint32), canon)[:3000]
+    raw = rng.permutation(raw)
+    translate_to = rng.permutation(3000).astype(np.uint32)     # raw[i] pairs with canon[translate_to[i]]
+    # the FB library's reads come from the same cells: same tables, raw barcodes at the paired positions
+    w_fb = S.Workload(n_total=n1, seed=404, n_genes=n_fb, **kw)
+    inv = np.empty(3000, np.uint32)
+    inv[translate_to] = np.arange(3000, dtype=np.uint32)
+    w_fb.wl_packed[:] = raw[inv]      # position p of the generator's list <-> canon[p]
+    w_fb.c.seed = 405
+    r0, r1 = w.host_reads(0, n0), w_fb.host_reads(0, n1)
+    r1["flags"] |= 1
+    feats = np.unique(rng.integers(0, 1 << 30, size=4 * n_fb, dtype=np.uint64))[:n_fb]
+    feats = rng.permutation(feats)
+    feat_ascii = [bytes(x).decode() for x in E.unpack_seqs(feats.astype(np.uint32), L)]
+    rows_s, rows_q = E.synth_rows_host(777, 0, n1, r1["feature"], feats, L, off, stride, err=0.01, n_rate=0.002)
+    defs = [("5PNNNNNNNNNN(BC)", feat_ascii[k], n_genes + k, 1) for k in range(n_fb)]
+    n_feat_all = n_genes + n_fb
+    types = np.array([0] * n_genes + [1] * n_fb, np.uint32)
+
+    # ---- device flow --------------------------------------------------------------------------------------------------
+    c = G.fresh_ctx()
+    c.set_whitelist(0, canon, length=16)
+    c.set_whitelist(1, raw, canon=canon, translate_to=translate_to, length=16)
+    _, canon_sorted = c.canon_order()
+    dev = []
+    for r, n in ((r0, n0), (r1, n1)):       # one library per call: the one-library kernels
+        d = dict(cb=c.upload(r["cb"]), cbq=c.upload(r["cb_qualn"]), flags=c.upload(r["flags"]), idx=c.empty(n, np.uint32), n=n)
+        c.match_and_count(d["cb"], d["flags"], n, d["idx"])
+        dev.append(d)
+    d_rs, d_rq = c.upload(rows_s), c.upload(rows_q)
+    d_f1 = c.empty(n1, np.uint32)
+    c.set_feature_extractor(1, defs)                                   # MAKE_SHARD: no distribution yet
+    c.extract_features(1, n1, d_f1, r2=(d_rs, d_rq, None, stride))
+    counts = c.feature_counts(d_f1, n1, n_feat_all)
+    dist = E.compute_feature_dist(counts, types)
+    c.set_feature_extractor(1, defs, dist)
+    for d in dev:
+        c.correct(d["cb"], d["cbq"], d["flags"], d["n"], d["idx"])
+    d_n_ids, d_cap = c.empty(n1, np.uint32), c.empty(n1, np.uint32)
+    c.extract_features(1, n1, d_f1, r2=(d_rs, d_rq, None, stride), d_n_ids_out=d_n_ids, d_capture_out=d_cap)
+    assert c.stat(4) == 2                                              # both passes took the one-pattern LDS kernel
+    got_f1 = d_f1.to_host()
+    idx_all = np.concatenate([dev[0]["idx"].to_host(), dev[1]["idx"].to_host()])
+    n = n0 + n1
+    feat_all = np.concatenate([r0["feature"], got_f1])
+    flags_all = np.concatenate([r0["flags"], r1["flags"]])
+    umi_all, uq_all = np.concatenate([r0["umi"], r1["umi"]]), np.concatenate([r0["umi_qualn"], r1["umi_qualn"]])
+    c.set_key_layout(n_feat_all, 12, 2, 0)
+    recs = c.records(n, 12, c.upload(idx_all), c.upload(umi_all), c.upload(uq_all), c.upload(feat_all), c.upload(flags_all))
+    d_pu, d_rc, d_fl = c.empty(n, np.uint32), c.empty(n, np.uint32), c.empty(n, np.uint8)
+    cnt = c.count_records(recs, d_pu, d_rc, d_fl)
+    m = c.assemble_matrix(*cnt.triplets(), n_feat_all)
+
+    # ---- oracle -------------------------------------------------------------------------------------------------------
+    ox0 = O.FeatureExtractor(defs, None)
+    ocounts = np.zeros(n_feat_all, np.int64)
+    for i in range(n1):
+        h = ox0.match_read(None, None, bytes(rows_s[i]), bytes(rows_q[i]))
+        if h is not None and h["n_ids"] == 1:
+            ocounts[h["ids"][0]] += 1
+    assert np.array_equal(counts, ocounts) and counts[n_genes:].sum() > n1 // 2 and not counts[:n_genes].any()
+    odist = O.compute_feature_dist(ocounts, types)
+    assert np.array_equal(dist, odist)
+    ox1 = O.FeatureExtractor(defs, odist)
+    exp_f1 = np.full(n1, NO_FEATURE, np.uint32)
+    for i in range(n1):
+        h = ox1.match_read(None, None, bytes(rows_s[i]), bytes(rows_q[i]))
+        if h is not None and h["n_ids"] == 1:
+            exp_f1[i] = h["ids"][0]
+    assert np.array_equal(got_f1, exp_f1)
+    exact = (exp_f1 != NO_FEATURE).sum()
+    assert exact > counts.sum() + 500, "the posterior must recover reads the exact pass missed"
+    r_all = {k: np.concatenate([r0[k], r1[k]]) for k in r0}
+    r_all["feature"] = np.concatenate([r0["feature"], exp_f1])
+    owl0 = O.Whitelist(E.unpack_seqs(canon, 16))
+    owl1 = O.Whitelist(E.unpack_seqs(raw, 16), translated=E.unpack_seqs(canon[translate_to], 16))
+    res = O.run_pipeline(G.oracle_reads_from_packed(r_all, 16, 12), [owl0, owl1], n_lib=2, n_threads=4, want_dupinfo=True)
+    _, exp_b = G.oracle_expected_idx(res, canon_sorted)
+    assert np.array_equal(idx_all, exp_b)
+    for lib in (0, 1):
+        assert np.array_equal(c.get_counts(lib, 0), G.hist_as_rank_counts(res.valid_hist[lib], 16, canon_sorted))
+    assert (res.bc_state[n0:] == 2).sum() > 500        # FB reads corrected through the Trans list
+    assert np.array_equal(m.barcodes_ascii(), res.barcodes)
+    assert np.array_equal(m.indptr, res.indptr) and np.array_equal(m.indices, res.indices) and np.array_equal(m.data, res.data)
+    assert (m.indices >= n_genes).sum() > 500 and (m.indices < n_genes).sum() > 500    # both libraries reach the matrix
+    od, fl = res.dupinfo, d_fl.to_host()
+    has = od["has_dupinfo"] != 0
+    assert np.array_equal((fl & 1) != 0, has)
+    for bit, name in ((2, "is_corrected"), (4, "is_low_support"), (8, "is_umi_count")):
+        assert np.array_equal((fl & bit) != 0, od[name] != 0), name
+    assert np.array_equal(d_pu.to_host()[has], od["processed_umi"][has]) and np.array_equal(d_rc.to_host()[has], od["read_count"][has])
+    c.close()

@@ -24,17 +24,17 @@ def _rows(seqs, quals, stride):
     return s, q, ln
 
 
-def _gpu_extract(c, extractor, r1=None, r2=None):
-    """r1 / r2: (seqs, quals) lists -> (feature, n_ids, capture) host arrays"""
+def _gpu_extract(c, extractor, r1=None, r2=None, stride_pad=0, no_len=False):
+    """r1 / r2: (seqs, quals) lists -> (feature, n_ids, capture) host arrays.  no_len: every row is full (d_len NULL)"""
     n = len((r1 or r2)[0])
     args = {}
     keep = []
     for name, r in (("r1", r1), ("r2", r2)):
         if r is None:
             continue
-        stride = max(4, max(len(x) for x in r[0]))
+        stride = (max(4, max(len(x) for x in r[0])) + 3) // 4 * 4 + stride_pad   # dword rows unless stride_pad makes them odd
         s, q, ln = _rows(r[0], r[1], stride)
-        ds, dq, dl = c.upload(s), c.upload(q), c.upload(ln)
+        ds, dq, dl = c.upload(s), c.upload(q), (None if no_len else c.upload(ln))
         keep += [ds, dq, dl]
         args[name] = (ds, dq, dl, stride)
     d_f, d_n, d_c = c.empty(n, np.uint32), c.empty(n, np.uint32), c.empty(n, np.uint32)
@@ -137,9 +137,9 @@ def _random_reads(rng, n, defs, lo, hi):
     return seqs, quals
 
 
-def _compare_with_oracle(c, extractor, ox, r1, r2, n_feat_total):
+def _compare_with_oracle(c, extractor, ox, r1, r2, n_feat_total, **kw):
     from cellranger_amd._lib import NO_FEATURE
-    f, n_ids, cap = _gpu_extract(c, extractor, r1=r1, r2=r2)
+    f, n_ids, cap = _gpu_extract(c, extractor, r1=r1, r2=r2, **kw)
     n = len(f)
     stats = dict(none=0, raw=0, one=0, multi=0)
     for i in range(n):
@@ -240,4 +240,89 @@ def test_extractor_wide_map_goes_through_the_queue():
     stats = _compare_with_oracle(c, 0, ox, None, (seqs, quals), len(feats))
     assert stats["one"] > 100, stats
     assert c.stat(2) >= 300  # CRGPU_STAT_FEATURE_READS_REQUEUED
+    c.close()
+
+
+@pytest.mark.parametrize("pat,L,read,fixed", [("5PNNNNNNNNNN(BC)", 15, 1, True), ("5PNNNNNNNNNN(BC)", 15, 1, False),
+                                              ("(BC)GTTTAAGAGCTAAGCTGGAA", 20, 1, False), ("(BC)AC3P", 7, 1, True),
+                                              ("(BC)AC3P", 7, 1, False), ("ACGN(BC)", 12, 0, False), ("^NN(BC)NNC$", 10, 0, False),
+                                              ("^(BC)", 32, 0, True), ("TTN(BC)GNA", 9, 1, True)])
+@pytest.mark.parametrize("with_dist", [True, False])
+def test_single_tethered_pattern_lds_kernel_vs_oracle(pat, L, read, fixed, with_dist):
+    """An extractor whose definitions share ONE tethered pattern (the usual feature reference) goes through the
+    wave-per-rows kernel with the table in LDS: same answers as the oracle's regex interpreter and as the thread-per-read
+    kernel (CRGPU_FEATURES_GLOBAL=1), on anchored / floating patterns, with and without per-row lengths, dense families of
+    one-mismatch neighbours (more candidates than the generic kernel's 16-entry map), Ns and wrapping qualities."""
+    import gpu_helpers as G
+    import oracle_lib as O
+
+    rng = np.random.default_rng(len(pat) * 131 + L + 7 * fixed + with_dist)
+    acgt = "ACGT"
+
+    def rnd(k):
+        return "".join(acgt[j] for j in rng.integers(0, 4, k))
+
+    centre = rnd(L)
+    seen = set()
+    for i in range(L):                      # every neighbour of a centre that is no feature itself
+        for b in acgt:
+            if b != centre[i]:
+                seen.add(centre[:i] + b + centre[i + 1:])
+    base = rnd(L)
+    while len(seen) < 3 * L + 60:
+        s_ = list(base if rng.random() < 0.5 else rnd(L))
+        for j in rng.integers(0, L, int(rng.integers(0, 3))):
+            s_[j] = acgt[rng.integers(0, 4)]
+        if "".join(s_) != centre:
+            seen.add("".join(s_))
+    feats = sorted(seen)
+    order = rng.permutation(len(feats))
+    defs = [(pat, feats[k], int(j) + 3, read) for j, k in enumerate(order)]
+    n_idx = len(feats) + 3
+    counts = rng.integers(0, 1000, n_idx)
+    counts[rng.random(n_idx) < 0.1] = 0
+    dist = O.compute_feature_dist(counts, np.zeros(n_idx, np.uint32)) if with_dist else None
+    c = G.fresh_ctx()
+    c.set_feature_extractor(2, defs, dist)
+    ox = O.FeatureExtractor(defs, dist)
+    n = 5000
+    left = pat.split("(BC)")[0].lstrip("5Pp^-_")
+    right = pat.split("(BC)")[1].rstrip("3Pp$-_")
+    need = len(left) + L + len(right)
+    full = (need + 9 + 3) // 4 * 4            # rows without lengths must be full: one length, a multiple of 4
+    lo, hi = (full, full) if fixed else (max(4, need - 3), need + 40)
+    if pat.startswith("^") and pat.endswith("$"):
+        lo, hi = need - 1, need + 1
+    seqs, quals = _random_reads(rng, n, defs, lo, hi)
+    seqs, quals = list(seqs), list(quals)
+    an = np.frombuffer(b"ACGT", np.uint8)
+    for k in range(400):    # the centre where the pattern looks, under varied qualities: up to 3 L competing candidates
+        ln = int(rng.integers(lo, hi + 1))
+        s_ = an[rng.integers(0, 4, ln)].copy()
+        at = len(left) if pat[0] in "5^" else (ln - len(right) - L if pat.endswith(("3P", "$")) else int(rng.integers(len(left), max(len(left) + 1, ln - L - len(right) + 1))))
+        if at >= len(left) and at + L + len(right) <= ln:
+            s_[at - len(left):at] = np.frombuffer(left.replace("N", "C").encode(), np.uint8) if left else s_[at:at]
+            s_[at:at + L] = np.frombuffer(centre.encode(), np.uint8)
+            s_[at + L:at + L + len(right)] = np.frombuffer(right.replace("N", "G").encode(), np.uint8) if right else s_[at:at]
+        seqs.append(bytes(s_))
+        quals.append(bytes(rng.integers(33, 75, ln).astype(np.uint8)))
+    reads = (seqs, quals)
+    r1, r2 = (None, reads) if read else (reads, None)
+    before = c.stat(4)
+    stats = _compare_with_oracle(c, 2, ox, r1, r2, n_idx, no_len=fixed)
+    assert c.stat(4) == before + 1, "the one-pattern LDS kernel did not run"
+    assert stats["one"] > 500, stats
+    fast = _gpu_extract(c, 2, r1=r1, r2=r2, no_len=fixed)
+    os.environ["CRGPU_FEATURES_GLOBAL"] = "1"
+    try:
+        slow = _gpu_extract(c, 2, r1=r1, r2=r2, no_len=fixed)
+    finally:
+        del os.environ["CRGPU_FEATURES_GLOBAL"]
+    assert c.stat(4) == before + 2
+    for a, b in zip(fast, slow):
+        assert np.array_equal(a, b)
+    # an odd stride or base cannot take dword loads: the generic kernel serves those rows, same answers
+    odd = _gpu_extract(c, 2, r1=r1, r2=r2, stride_pad=1)
+    for a, b in zip(fast, odd):
+        assert np.array_equal(a, b)
     c.close()

@@ -159,3 +159,101 @@ def test_gel_bead_and_probe_construct_matches_the_oracle(n_probe, seed, tmp_path
     assert lines == [bytes(b).decode() + "-1" for b in res.barcodes]
     for c in (ca, cb, cc):
         c.close()
+
+
+def test_reference_barcode_vectors_through_the_writers(tmp_path):
+    """barcode/src/lib.rs:918-1103 (tests/golden/barcode_vectors.json) through the product: barcodes.tsv rows and
+    barcode_summary.csv rows are "SEQ-gem_group"; a GelBeadAndProbe barcode is the concatenation of its segments (16 + 8 and
+    16 + 6 bases) and exists only when every segment is valid (before or after correction)."""
+    import json
+    import os
+
+    import gpu_helpers as G
+    from cellranger_amd import engine as E
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "barcode_vectors.json")) as f:
+        g = json.load(f)
+
+    def parse(s):
+        seq, sep, gg = s.rpartition("-")
+        assert sep and gg.isdigit()
+        return seq, int(gg)
+
+    # ---- plain 16-base barcode: Display / parse ---------------------------------------------------------------------
+    v = g["plain_parse_display"][0]
+    c = G.fresh_ctx()
+    others = ["AAAACCCCGGGGTTTT", "TTTTGGGGCCCCAAAA"]
+    wl, _ = E.pack_seqs([v["sequence"]] + others)
+    c.set_whitelist(0, wl, length=16)
+    n = 6
+    cb = np.array([wl[0]] * 4 + [wl[1]] * 2, np.uint32)
+    qual = np.full((n, 16), 70, np.uint8)
+    d_cb, d_q, d_fl, d_idx = c.upload(cb), c.upload(qual), c.zeros(n, np.uint8), c.empty(n, np.uint32)
+    c.match_and_count(d_cb, d_fl, n, d_idx)
+    c.correct(d_cb, d_q, d_fl, n, d_idx)
+    c.set_key_layout(4, 12, 1, 0)
+    umi, _ = E.pack_seqs(["ACGTACGTACGT", "ACGTACGTACGT", "TTGTACGTACGA", "CCGTACGTACGA", "GAGTACGTACGA", "GAGTACGTACGA"])
+    recs = c.records(n, 12, d_idx, c.upload(umi), c.upload(np.full((n, 12), 70, np.uint8)), c.upload(np.array([0, 0, 1, 2, 3, 3], np.uint32)), d_fl)
+    counts = c.count_records(recs)
+    m = c.assemble_matrix(*counts.triplets(), 4)
+    p = tmp_path / "barcodes.tsv"
+    m.write_mtx(None, p, gem_group=v["gem_group"])
+    rows = p.read_text().split()
+    assert v["string"] in rows and all(parse(r)[1] == v["gem_group"] for r in rows)
+    assert sorted(parse(r)[0] for r in rows) == sorted([v["sequence"], others[0]])
+    csv = tmp_path / "barcode_summary.csv"
+    c.write_barcode_summary_csv(counts.barcode_summary(), str(csv), gem_group=v["gem_group"])
+    lines = csv.read_text().split("\n")
+    assert lines[0] == "library_type,barcode,reads,umis,candidate_dup_reads,umi_corrected_reads"
+    assert "Gene Expression,%s,4,3,4,0" % v["string"] in lines
+    c.close()
+
+    # ---- GelBeadAndProbe: concatenation + validity = every segment valid -----------------------------------------------
+    for LB, probe_wl in ((8, ["CTGCCACT", "GGATTACA", "TTTTCCCC"]), (6, ["CTGCCA", "GGATTA", "TTTTCC"])):
+        case = [x for x in g["segmented_to_barcode"] if len(x["segments"]) == 2 and len(x["segments"][1]["sequence"]) == LB][0]
+        gel = case["segments"][0]["sequence"]
+        ca, cb_, cc = G.fresh_ctx(), G.fresh_ctx(), G.fresh_ctx()
+        wa, _ = E.pack_seqs([gel, "CCCCAAAATTTTGGGG"])
+        wb, _ = E.pack_seqs(probe_wl)
+        ca.set_whitelist(0, wa, length=16)
+        cb_.set_whitelist(0, wb, length=LB)
+        _, a_sorted = ca.canon_order()
+        _, b_sorted = cb_.canon_order()
+        cc.set_barcode_segments(0, [a_sorted, b_sorted], [16, LB])
+        one_off = probe_wl[0][:-1] + ("A" if probe_wl[0][-1] != "A" else "C")      # corrected onto probe_wl[0]
+        reads = [(gel, probe_wl[0]),                 # ValidBeforeCorrection + ValidBeforeCorrection -> valid
+                 (gel, one_off),                     # ValidBeforeCorrection + ValidAfterCorrection  -> valid (lib.rs:967-983)
+                 ("GTGTGTGTGTGTGTGT", probe_wl[0]),  # Invalid + ValidBeforeCorrection              -> invalid (lib.rs:949-965)
+                 (gel, "ACACACAC"[:LB])]             # ValidBeforeCorrection + Invalid              -> invalid
+        nr = len(reads)
+        stride = 16 + LB
+        rows_s = np.frombuffer("".join(a + b for a, b in reads).encode(), np.uint8).reshape(nr, stride).copy()
+        rows_q = np.full((nr, stride), 70, np.uint8)
+        da_a, da, _ = _segment_stage(ca, rows_s, rows_q, nr, stride, 0, 16)
+        db_a, db, _ = _segment_stage(cb_, rows_s, rows_q, nr, stride, 16, LB)
+        d_idx = cc.empty(nr, np.uint32)
+        cc.combine_segments(0, [da_a, db_a], nr, d_idx)
+        before = d_idx.to_host()
+        cc.combine_segments(0, [da, db], nr, d_idx, after_correction=True)
+        after = d_idx.to_host()
+        assert list(before != MISS) == [True, False, False, False]
+        assert list(after != MISS) == [True, True, False, False]
+        assert after[0] == after[1]
+        cc.set_key_layout(2, 12, 1, 0)
+        u2, _ = E.pack_seqs(["ACGTACGTACGT", "TTGTACGTACGA", "ACGTACGTACGT", "ACGTACGTACGT"])
+        recs = cc.records(nr, 12, d_idx, cc.upload(u2), cc.upload(np.full((nr, 12), 70, np.uint8)), cc.upload(np.zeros(nr, np.uint32)),
+                          cc.zeros(nr, np.uint8))
+        counts = cc.count_records(recs)
+        m = cc.assemble_matrix(*counts.triplets(), 2)
+        full = gel + probe_wl[0]
+        if LB == 6:
+            assert full == case["barcode"] and case["valid"]
+        else:
+            assert full == [x for x in g["segmented_to_barcode"] if x["barcode"] == full][0]["barcode"]
+        assert [bytes(b).decode() for b in m.barcodes_ascii()] == [full] and m.cb_len == 16 + LB
+        assert m.data.tolist() == [2]
+        p = tmp_path / ("barcodes_%d.tsv" % LB)
+        m.write_mtx(None, p, gem_group=1)
+        assert p.read_text().split() == [full + "-1"]
+        for x in (ca, cb_, cc):
+            x.close()

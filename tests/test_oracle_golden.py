@@ -290,3 +290,33 @@ def test_umi_extraction_vectors():
         L = max(min(max(read_len - g["offset"], 0), g["length"]), g["min_length"])
         assert L == case["range_len"] and g["offset"] + L <= read_len
         assert case["seq"][g["offset"]:g["offset"] + L] == case["umi"]
+
+
+def test_barcode_string_vectors_are_consistent():
+    """barcode/src/lib.rs:918-1103 as data (tests/golden/barcode_vectors.json): Display = "SEQ-gem_group", parse needs the
+    suffix, a segmented barcode is the concatenation of its segment sequences and is valid iff every segment is
+    ValidBefore/AfterCorrection (lib.rs:793-908).  The GPU tests feed exactly these sequences through the writers
+    (tests/test_gpu_segments.py::test_reference_barcode_vectors_through_the_writers); here the rule itself is checked on
+    the transcription, and the oracle's matrix column strings follow it."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "barcode_vectors.json")) as f:
+        g = json.load(f)
+
+    def parse(s):
+        seq, sep, gg = s.rpartition("-")
+        if not sep or not gg.isdigit() or not seq:
+            raise ValueError(s)
+        return seq, int(gg)
+
+    for v in g["plain_parse_display"]:
+        assert parse(v["string"]) == (v["sequence"], v["gem_group"])
+        assert "%s-%d" % (v["sequence"], v["gem_group"]) == v["string"]
+    for v in g["parse_errors"]:
+        with pytest.raises(ValueError):
+            parse(v["string"])
+    ok = {"ValidBeforeCorrection", "ValidAfterCorrection"}
+    for v in g["segmented_to_barcode"]:
+        assert "".join(s["sequence"] for s in v["segments"]) == v["barcode"], v["_source"]
+        assert all(s["state"] in ok for s in v["segments"]) == v["valid"], v["_source"]
+        if "string" in v:
+            assert "%s-%d" % (v["barcode"], v["gem_group"]) == v["string"]
