@@ -752,7 +752,7 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
 uint32_t cr_sort_low_bits(uint32_t total_bits, uint32_t umi_bits) {
     const char *e = getenv("CRGPU_SORT_FINISH");
     if (!onesweep_enabled() || total_bits <= 27) return 0;
-    if (!e || atoi(e) == 0) return 0;
+    if (e && atoi(e) == 0) return 0;   // round 3: leaving the few low bits that save a pass is the default (cr_repair_runs)
     const uint32_t p8 = (total_bits + 7) / 8, p9 = (total_bits + 8) / 9;
     const uint32_t full = p9 < p8 ? p9 : p8;
     if (e && atoi(e) == 1) {
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_order_runs(uint64_t *__restrict__ keys,
     }
 }
 
-int cr_order_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
+static int cr_order_runs_r02(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
     *fell_back = false;
     if (n < 2 || low_bits == 0) return CRGPU_OK;
     uint32_t *d_flag = ctx->d_scalars + 52;
@@ -1072,6 +1072,131 @@ int cr_order_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n
     CR_TRY(crgpu_memcpy_d2h(ctx, &flag, d_flag, sizeof(flag)));
     *fell_back = flag != 0;
     return CRGPU_OK;
+}
+
+// ---- the same in two steps: find the descents, repair only the runs that hold one (the default since round 3) -------------
+// k_order_runs touches every key of the buffer one load per lane at a time (3.7 ms per 796 M keys, more than the radix pass
+// it saves).  But almost every run of equal top bits is a single key or copies of ONE key: nothing to do.  So:
+//   k_find_descents   a streaming read with the wave-blocked layout of the run-length passes (several loads per lane in
+//                     flight, the left neighbour from the lane below): bit i of desc[] = key i continues the run of its left
+//                     neighbour (same bits above `low`) and is SMALLER than it -- the run is out of order there.  One 64-bit
+//                     ballot word per 64 keys is written: 1.6 % of the bytes read.
+//   k_repair_runs     one lane per set bit; the lane whose bit is the FIRST descent of its run (no other one between the
+//                     run's head and it) puts the whole run in order through memory (or_run_through_memory: insertion sort,
+//                     bucket permutation for long runs, *bad for runs beyond OR_MAX -> the caller sorts on all bits).
+// Runs are disjoint, so the repairing lanes never touch each other's keys.
+#define FD_ITEMS 8
+__global__ __launch_bounds__(256) void k_find_descents(const uint64_t *__restrict__ keys, uint64_t n, uint32_t low,
+                                                       unsigned long long *__restrict__ desc, uint32_t *__restrict__ n_words_set) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t span = 64ull * FD_ITEMS;
+    const uint64_t n_spans = (n + span - 1) / span;
+    const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    uint32_t set = 0;
+    for (uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); gw < n_spans; gw += wave_stride) {
+        const uint64_t w0 = gw * span;
+        uint64_t key[FD_ITEMS];
+        uint64_t carry = keys[w0 > 0 ? w0 - 1 : 0];
+        bool carry_valid = w0 > 0;
+#pragma unroll
+        for (int j = 0; j < FD_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            key[j] = keys[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < FD_ITEMS; j++) {
+            const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+            uint64_t left = __shfl_up(key[j], 1);
+            if (lane == 0) left = carry;
+            const bool has_left = lane > 0 || carry_valid;
+            const bool d = i < n && has_left && (key[j] >> low) == (left >> low) && key[j] < left;
+            const unsigned long long m = __ballot(d);
+            if (lane == 0 && w0 + (uint64_t)j * 64 < n) {
+                desc[(w0 >> 6) + j] = m;
+                set += m != 0ull;
+            }
+            carry = __shfl(key[j], 63);
+            carry_valid = true;
+        }
+    }
+    if (lane == 0 && set) atomicAdd(n_words_set, set);
+}
+
+template <bool HAS_VALS>
+__global__ __launch_bounds__(256) void k_repair_runs(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low,
+                                                     const unsigned long long *__restrict__ desc, uint64_t n_words,
+                                                     uint32_t *__restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        unsigned long long m = desc[w];
+        while (m) {
+            const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
+            m &= m - 1ull;
+            const uint64_t p = w * 64 + b;  // keys[p] < keys[p - 1], same top bits
+            // Walk back to the head of the run.  An earlier descent on the way means another lane owns the run.  Only things
+            // that no repair changes are looked at: the descent bits (read-only here) and the TOP bits of the keys (a repair
+            // permutes keys inside one run, whose top bits are all equal) -- the owner may already be rewriting this run.
+            const uint64_t top = keys[p] >> low;
+            uint64_t h = p;
+            bool first = true;
+            for (;;) {
+                h--;  // keys[h] belongs to the run (p - 1 does by construction)
+                if ((desc[h >> 6] >> (h & 63u)) & 1ull) {
+                    first = false;
+                    break;
+                }
+                if (h == 0 || (keys[h - 1] >> low) != top) break;  // h is the head
+                if (p - h > OR_MAX) break;
+            }
+            if (first && p - h > OR_MAX) {
+                atomicOr(bad, 1u);
+                continue;
+            }
+            if (first) or_run_through_memory<HAS_VALS>(keys, vals, n, low, h, bad);
+        }
+    }
+}
+
+int cr_repair_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
+    *fell_back = false;
+    if (n < 2 || low_bits == 0) return CRGPU_OK;
+    uint32_t *d_flag = ctx->d_scalars + 52, *d_set = ctx->d_scalars + 53;
+    const uint64_t n_words = (n + 63) / 64;
+    void *d_desc = nullptr;
+    CR_TRY(cr_pool_alloc(ctx, &d_desc, n_words * sizeof(unsigned long long)));
+    struct Rel {
+        crgpu_ctx *c;
+        void *p;
+        ~Rel() { cr_pool_free(c, p); }
+    } rel{ctx, d_desc};
+    {
+        CrTimer t(ctx, CRGPU_T_SORT_HIST, n);  // booked beside the histogram slot: "sort, not a scatter pass"
+        CR_HIP(ctx, hipMemsetAsync(d_flag, 0, 2 * sizeof(uint32_t), ctx->stream));
+        const uint64_t n_spans = (n + 64ull * FD_ITEMS - 1) / (64ull * FD_ITEMS);
+        hipLaunchKernelGGL(k_find_descents, dim3(cr_grid(n_spans * 64u, 256, 256u * 8u)), dim3(256), 0, ctx->stream, d_keys, n, low_bits,
+                           (unsigned long long *)d_desc, d_set);
+        const dim3 grid(cr_grid(n_words, 256, 256u * 8u));
+        if (d_vals)
+            hipLaunchKernelGGL(k_repair_runs<true>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits,
+                               (const unsigned long long *)d_desc, n_words, d_flag);
+        else
+            hipLaunchKernelGGL(k_repair_runs<false>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits,
+                               (const unsigned long long *)d_desc, n_words, d_flag);
+        CR_HIP(ctx, hipGetLastError());
+    }
+    uint32_t flag = 0;
+    CR_TRY(crgpu_memcpy_d2h(ctx, &flag, d_flag, sizeof(flag)));
+    *fell_back = flag != 0;
+    return CRGPU_OK;
+}
+// the finishing step behind the passes on the top bits: CRGPU_SORT_FINISH=3 keeps round 2's k_order_runs (A/B)
+static int order_low_bits(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
+    const char *e = getenv("CRGPU_SORT_FINISH");
+    if (e && atoi(e) == 3) return cr_order_runs_r02(ctx, d_keys, d_vals, n, low_bits, fell_back);
+    return cr_repair_runs(ctx, d_keys, d_vals, n, low_bits, fell_back);
+}
+int cr_order_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
+    return order_low_bits(ctx, d_keys, d_vals, n, low_bits, fell_back);
 }
 
 static int finish_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
@@ -1145,8 +1270,8 @@ static int radix_sort(crgpu_ctx *ctx, K *d_keys, K *d_tmp, uint32_t *d_vals, uin
                 CR_TRY(finish_runs(ctx, *result_in_tmp ? k1 : k0, d_vals ? (*result_in_tmp ? d_vals_tmp : d_vals) : nullptr, n, low,
                                    &fell_back));
             else
-                CR_TRY(cr_order_runs(ctx, *result_in_tmp ? k1 : k0, d_vals ? (*result_in_tmp ? d_vals_tmp : d_vals) : nullptr, n, low,
-                                     &fell_back));
+                CR_TRY(order_low_bits(ctx, *result_in_tmp ? k1 : k0, d_vals ? (*result_in_tmp ? d_vals_tmp : d_vals) : nullptr, n, low,
+                                      &fell_back));
             if (!fell_back) return CRGPU_OK;
             // a run of equal top bits too long for the finishing pass (it may have moved keys inside other runs: the
             // buffer still holds every key): sort it again on all bits

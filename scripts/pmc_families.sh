@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_${tag}_$c
-  timeout -k 5 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python3 bench.py "$@" --no-cpu-baseline --no-verify --no-end-to-end > gpurun_out/pmc_${tag}_$c.json 2> gpurun_out/pmc_${tag}_$c.err
+  timeout -k 5 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$c -- python3 bench.py "$@" --no-cpu-baseline --no-verify --no-end-to-end --no-default-options > gpurun_out/pmc_${tag}_$c.json 2> gpurun_out/pmc_${tag}_$c.err
 done
 python3 - "$tag" "$*" <<'PY'
 import csv, glob, collections, json, sys
@@ -26,6 +26,8 @@ def family(k):
     if any(x in k for x in ("k_lookup_hot", "k_stage_idx", "k_hist_buckets", "k_match_binned", "k_hot_", "k_match<")): return "match"
     if any(x in k for x in ("k_correct_records", "k_collect_miss", "k_correct<", "k_region_offsets")): return "correct"
     if any(x in k for x in ("k_csc", "SeenFlag")): return "matrix"
+    if any(x in k for x in ("k_extract_", "k_feature_counts", "k_match_features")): return "feature"
+    if any(x in k for x in ("k_find_descents", "k_repair_runs", "k_order_runs", "k_global_hist")): return "sort_hist"
     if any(x in k for x in ("k_cp_", "k_correct_umis", "k_giant", "k_rep_", "k_group_", "k_low_support", "k_triplets", "k_radix_scatter<unsigned int",
                             "k_radix_hist<unsigned int", "k_per_read", "k_unpack", "k_corrected_reads", "k_mt_", "k_rl_", "k_trip_counts")): return "dedup"
     return None

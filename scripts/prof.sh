@@ -3,7 +3,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py "$@" --no-cpu-baseline --no-verify > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py "$@" --no-cpu-baseline --no-verify --no-default-options > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err
 cat gpurun_out/prof_$tag/*/*_kernel_stats.csv | cut -c1-60,200- | head -30
 python3 - <<PY
 import csv,glob

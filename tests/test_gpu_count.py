@@ -331,20 +331,22 @@ def _needs_onesweep():
         pytest.skip("CRGPU_SORT=classic: the onesweep path under test is switched off")
 
 
-@pytest.mark.parametrize("big_run,top_bits_sort", [(50_000, False), (50_000, True), (90_000, True)])
-def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, top_bits_sort, monkeypatch):
+@pytest.mark.parametrize("big_run,finish", [(50_000, "0"), (50_000, "2"), (90_000, "2"), (50_000, "3"), (90_000, "3")])
+def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, monkeypatch):
     """UMIs that differ only in their last bases (three 8-base prefixes), UmiTypes mixed inside every UMI, and keys that
     agree in everything but the last 2.5 bases of the UMI in runs of 2..30, of 100 and of 50 000 reads: Hamming-1
     neighbourhoods are dense, counts tie, and one (barcode, feature) segment holds most of the reads.
-    top_bits_sort (CRGPU_SORT_FINISH=2): the sort leaves the lowest key bits to k_order_runs -- runs inside a wave by an
-    odd-even transposition in registers, longer ones through memory (insertion up to 32 keys, in-place bucket permutation up
-    to 65 536), and a run of 90 000 keys makes it hand the job back to a sort on all bits (CRGPU_STAT_SORT_REFINISHED)."""
+    finish (CRGPU_SORT_FINISH): "0" = radix passes on every key bit; "2" (the default since round 3) = the sort leaves the
+    lowest key bits that save a pass to k_find_descents + k_repair_runs (only the runs of equal top bits that are out of order
+    are touched: insertion up to 32 keys, in-place bucket permutation up to 65 536); "3" = round 2's k_order_runs (runs inside
+    a wave by an odd-even transposition in registers).  A run of 90 000 keys makes either hand the job back to a sort on all
+    bits (CRGPU_STAT_SORT_REFINISHED)."""
+    top_bits_sort = finish != "0"
     if top_bits_sort:
         _needs_onesweep()
     import gpu_helpers as G
 
-    if top_bits_sort:
-        monkeypatch.setenv("CRGPU_SORT_FINISH", "2")
+    monkeypatch.setenv("CRGPU_SORT_FINISH", finish)
     from cellranger_amd import synth as S
     from cellranger_amd._lib import FLAG_NONTXOMIC
 
