@@ -1010,6 +1010,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_cb && d_idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
     cr_drop_miss_records(ctx);
+    cr_dense_drop(ctx);  // the VALID table changes
     if (!d_flags) {
         // NULL flags mean "no barcode holds an N".  A pack call that ran without a flags array and met an N left a mark:
         // such a barcode would be looked up with its N read as A and could count as a whitelist hit, which the
@@ -1563,6 +1564,7 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_cb && d_idx_inout, CRGPU_EINVAL, "crgpu_correct: NULL buffer");
     CR_REQUIRE(ctx, n < 0xFFFFFFFFull, CRGPU_ERANGE, "crgpu_correct: batches are limited to 2^32-2 reads");
+    cr_dense_drop(ctx);  // the CORRECTED table changes
     if (ctx->cb_len == 16 && d_qualn)
         CR_REQUIRE(ctx, (uintptr_t)d_qualn % 16 == 0, CRGPU_EINVAL, "crgpu_correct: quality buffer must be 16-byte aligned");
     // NotNan::try_from(threshold).ok()? (corrector.rs:152): a NaN threshold corrects nothing
@@ -1700,6 +1702,7 @@ extern "C" int crgpu_combine_segments_dev(crgpu_ctx *ctx, int lib, const uint32_
                                           uint64_t n, int after_correction, uint32_t *d_idx_inout) {
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
+    cr_dense_drop(ctx);
     CR_REQUIRE(ctx, ctx->n_segments > 0, CRGPU_ESTATE, "crgpu_combine_segments_dev: call crgpu_set_barcode_segments first");
     CR_REQUIRE(ctx, lib >= 0 && lib < CRGPU_MAX_LIB && ctx->wl[lib].set, CRGPU_ESTATE, "library %d has no barcode space", lib);
     CR_REQUIRE(ctx, n_segments == ctx->n_segments && d_seg_idx, CRGPU_EINVAL, "crgpu_combine_segments_dev: %u segments expected",

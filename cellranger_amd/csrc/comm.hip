@@ -363,6 +363,7 @@ extern "C" int crgpu_allreduce_counts(crgpu_ctx *ctx, int lib, int which) {
     CR_REQUIRE(ctx, lib < CRGPU_MAX_LIB, CRGPU_EINVAL, "crgpu_allreduce_counts: library %d out of range", lib);
     CR_REQUIRE(ctx, lib < 0 || ctx->wl[lib].set, CRGPU_ESTATE, "crgpu_allreduce_counts: library %d has no whitelist", lib);
     if (ctx->n_ranks == 1) return CRGPU_OK;
+    cr_dense_drop(ctx);
     CrTimer t(ctx, CRGPU_T_COMM, ctx->n_canon);
     for (int l = 0; l < CRGPU_MAX_LIB; l++) {
         if ((lib >= 0 && l != lib) || !ctx->wl[l].set) continue;
@@ -381,6 +382,7 @@ extern "C" int crgpu_exchange_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, u
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_exchange_keys: call crgpu_set_key_layout first");
     CR_REQUIRE(ctx, n_keys == 0 || d_keys, CRGPU_EINVAL, "crgpu_exchange_keys: NULL keys");
     cr_invalidate(ctx);
+    CR_TRY(cr_dense_ensure(ctx));
     const int W = ctx->n_ranks;
     std::vector<uint32_t> bounds(W + 1);
     CR_TRY(crgpu_balanced_bounds(ctx, (uint32_t)W, bounds.data()));

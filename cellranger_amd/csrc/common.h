@@ -125,6 +125,20 @@ struct KeyHistograms {
     uint32_t *d_hist = nullptr;  // OS_MAX_PASSES x RADIX_MAX, pool block
 };
 
+// CRGPU_OPT_DENSE_BARCODE_KEYS: the barcode field of a molecule key holds the barcode's POSITION IN THE BARCODE INDEX (the
+// matrix column: the canonical barcodes with a non-zero VALID or CORRECTED count in any library, ascending --
+// cr_types/src/barcode_index.rs:20-53) instead of its rank on the whitelist: ~2 * 10^5 values (18 bits) where the
+// 3M-february-2018 list needs 23 and a GelBeadAndProbe product space 24+.  Built from the tables when the first key is
+// built, dropped by everything that changes a table (dedup.hip: cr_dense_ensure / cr_dense_drop).
+struct DenseIndex {
+    bool on = false, valid = false;
+    uint32_t V = 0;               // columns
+    uint32_t canon_bits = 0;      // bits_bc of the whitelist-rank layout (restored on drop)
+    uint32_t *d_fwd = nullptr;    // n_canon: rank -> column, CRGPU_MISS for a barcode without reads
+    uint32_t *d_back = nullptr;   // V: column -> rank
+    std::vector<uint32_t> h_back;
+};
+
 struct CrComm;  // comm.hip: RCCL communicator or in-process group of this context (NULL: single GPU)
 
 struct crgpu_ctx {
@@ -171,7 +185,8 @@ struct crgpu_ctx {
     double confidence_threshold = 0.975;                   // corrector.rs:83
     double *d_ptab = nullptr;  // 128 entries: probability(q) for q = 0..127 (corrector.rs:167-171)
 
-    KeyLayout layout;
+    KeyLayout layout;   // bits_bc follows the dense index while one is valid
+    DenseIndex dense;
     // targeted-panel UMI filter (mark_dups.rs:311-320): on-target flag per feature + minimum read count (0 = None)
     uint8_t *d_on_target = nullptr;
     uint32_t n_target_features = 0;
@@ -223,6 +238,10 @@ struct CrEnter {
 #define CR_ENTER(ctx) CrEnter _cr_enter(ctx)
 // forget every by-product kept for the next call (K1's miss records, the key histograms)
 void cr_invalidate(crgpu_ctx *ctx);
+// dedup.hip: (re)build the dense barcode index from the tables when the option is on (no-op otherwise) / forget it
+int cr_dense_ensure(crgpu_ctx *ctx);
+void cr_dense_drop(crgpu_ctx *ctx);
+void cr_dense_free(crgpu_ctx *ctx);
 void cr_feature_extractors_free(crgpu_ctx *ctx);  // feature_extract.hip
 // the sequence of a canonical rank as up to 32 bases: *lo = the first min(16, cb_len) bases packed, *hi = the rest (0 when
 // cb_len <= 16); whitelist.hip

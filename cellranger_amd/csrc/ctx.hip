@@ -187,6 +187,11 @@ extern "C" int crgpu_set_option(crgpu_ctx *ctx, int option, int64_t value) {
             ctx->trust_buffers = value != 0;
             cr_invalidate(ctx);
             return CRGPU_OK;
+        case CRGPU_OPT_DENSE_BARCODE_KEYS:
+            cr_invalidate(ctx);
+            cr_dense_drop(ctx);
+            ctx->dense.on = value != 0;
+            return CRGPU_OK;
         default:
             return cr_fail(ctx, CRGPU_EINVAL, "crgpu_set_option: unknown option %d", option);
     }
@@ -220,11 +225,25 @@ void cr_invalidate(crgpu_ctx *ctx) {
     cr_drop_miss_records(ctx);
     ctx->ghist.valid = false;
 }
+void cr_dense_drop(crgpu_ctx *ctx) {
+    if (!ctx->dense.valid) return;
+    ctx->dense.valid = false;
+    ctx->dense.V = 0;
+    if (ctx->layout.set) ctx->layout.bits_bc = ctx->dense.canon_bits;
+    ctx->ghist.valid = false;
+}
+void cr_dense_free(crgpu_ctx *ctx) {
+    cr_dense_drop(ctx);
+    (void)hipFree(ctx->dense.d_fwd);
+    (void)hipFree(ctx->dense.d_back);
+    ctx->dense.d_fwd = ctx->dense.d_back = nullptr;
+}
 
 extern "C" int crgpu_invalidate(crgpu_ctx *ctx) {
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     cr_invalidate(ctx);
+    cr_dense_drop(ctx);  // the host may have written a histogram table through crgpu_counts_dev (rebuilt from the tables on demand)
     return CRGPU_OK;
 }
 
@@ -257,6 +276,7 @@ extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
         hipFree(p.d_dist);
     }
     cr_feature_extractors_free(ctx);
+    cr_dense_free(ctx);
     hipFree(ctx->d_on_target);
     hipFree(ctx->d_canon_keys);
     hipFree(ctx->d_hot_image);

@@ -35,6 +35,8 @@ struct crgpu_counts {
     uint32_t *d_corr_reads = nullptr;  // [library][barcode rank] reads whose UMI was corrected (BarcodeSummary), or NULL
     uint32_t *d_filt_reads = nullptr;  // [library][barcode rank] reads of molecules the targeted-panel filter removed, or NULL
     int32_t *d_mprobe = nullptr;    // probe_idx of each molecule's representative read (crgpu_records.d_probe_idx given), or NULL
+    uint32_t *d_back = nullptr;     // CRGPU_OPT_DENSE_BARCODE_KEYS: column -> whitelist rank of the barcode field of d_mkeys (n_back), else NULL
+    uint32_t n_back = 0;
     uint32_t n_canon = 0;
     KeyLayout layout;
 };
@@ -60,11 +62,16 @@ extern "C" int crgpu_set_key_layout(crgpu_ctx *ctx, uint32_t n_features, uint32_
     L.umi_min_len = umi_len;
     L.n_libs = n_libs;
     L.mux_mask = multiplexing_lib_mask;
-    CR_REQUIRE(ctx, L.total_bits() <= 64, CRGPU_ERANGE,
-               "molecule key needs %u bits (barcode %u + feature %u + library %u + umi %u + 1) > 64", L.total_bits(),
-               L.bits_bc, L.bits_feat, L.bits_lib, L.bits_umi);
+    // with CRGPU_OPT_DENSE_BARCODE_KEYS the barcode field shrinks to the columns that occur (known when the first key is built)
+    CR_REQUIRE(ctx, L.total_bits() <= 64 || (ctx->dense.on && L.total_bits() - L.bits_bc + 1u <= 64u), CRGPU_ERANGE,
+               "molecule key needs %u bits (barcode %u + feature %u + library %u + umi %u + 1) > 64%s", L.total_bits(),
+               L.bits_bc, L.bits_feat, L.bits_lib, L.bits_umi,
+               ctx->dense.on ? "" : " (CRGPU_OPT_DENSE_BARCODE_KEYS shortens the barcode field to the barcodes that occur)");
     L.set = true;
+    cr_dense_drop(ctx);
+    ctx->dense.canon_bits = L.bits_bc;
     ctx->layout = L;
+    cr_invalidate(ctx);
     return CRGPU_OK;
 }
 
@@ -98,8 +105,10 @@ extern "C" int crgpu_set_umi_min_len(crgpu_ctx *ctx, uint32_t umi_min_len) {
     CR_REQUIRE(ctx, umi_min_len >= 1 && umi_min_len <= L.umi_len, CRGPU_EINVAL, "umi_min_len must be 1..umi_len (%u)", L.umi_len);
     L.umi_min_len = umi_min_len;
     L.bits_ulen = cr_ceil_log2(L.umi_len - umi_min_len + 1);
-    CR_REQUIRE(ctx, L.total_bits() <= 64, CRGPU_ERANGE, "molecule key needs %u bits with %u bits of UMI length > 64", L.total_bits(),
-               L.bits_ulen);
+    cr_dense_drop(ctx);
+    L.bits_bc = ctx->dense.canon_bits;
+    CR_REQUIRE(ctx, L.total_bits() <= 64 || (ctx->dense.on && L.total_bits() - L.bits_bc + 1u <= 64u), CRGPU_ERANGE,
+               "molecule key needs %u bits with %u bits of UMI length > 64", L.total_bits(), L.bits_ulen);
     ctx->layout = L;
     cr_invalidate(ctx);
     return CRGPU_OK;
@@ -157,7 +166,9 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                                                     uint32_t *__restrict__ vals_out,
                                                     unsigned long long *__restrict__ n_out, const SweepPlan plan,
                                                     uint32_t *__restrict__ ghist, unsigned long long *__restrict__ status,
-                                                    uint32_t *__restrict__ ticket, const uint8_t *__restrict__ ulen) {
+                                                    uint32_t *__restrict__ ticket, const uint8_t *__restrict__ ulen,
+                                                    const uint32_t *__restrict__ dense_fwd, uint32_t *__restrict__ n_unknown) {
+    // dense_fwd (nullable): barcode rank -> column of the BarcodeIndex (CRGPU_OPT_DENSE_BARCODE_KEYS)
     // ulen (nullable, byte path LQW == 0 only): the UMI length of every read, umi_min_len .. umi_len
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
     __shared__ unsigned long long s_c;  // ORDERED: the chunk of this round, then its output offset
@@ -207,8 +218,13 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
         for (int jj = 0; jj < KEY_BATCH; jj++) {
             const int j = j0 + jj;
             const uint64_t i = c * chunk + (uint64_t)j * 256 + threadIdx.x;
-            const uint32_t b = vb[jj], f = vf[jj], fl = vfl[jj];
+            uint32_t b = vb[jj];
+            const uint32_t f = vf[jj], fl = vfl[jj];
             const uint32_t lib = fl & CRGPU_FLAG_LIB_MASK;
+            if (dense_fwd && b != CRGPU_MISS) {
+                b = dense_fwd[b];
+                if (b == CRGPU_MISS) atomicAdd(n_unknown, 1u);  // a barcode without reads in the tables: the call fails
+            }
             bool keep = b != CRGPU_MISS && f != CRGPU_NO_FEATURE && f < kl.n_features && lib < kl.n_libs;
             // this read's UMI length (a length outside umi_min_len .. umi_len: the reference's check_range fails, no UMI)
             const uint32_t Li = LQW == 0 ? vl[jj] : L;
@@ -324,7 +340,8 @@ __global__ __launch_bounds__(256) void k_build_keys_v4(const KL kl, const uint32
                                                        const uint8_t *__restrict__ umi_q, const uint32_t *__restrict__ feature,
                                                        const uint8_t *__restrict__ flags, uint64_t n, uint64_t *__restrict__ keys_out,
                                                        unsigned long long *__restrict__ n_out, const SweepPlan plan,
-                                                       uint32_t *__restrict__ ghist) {
+                                                       uint32_t *__restrict__ ghist, const uint32_t *__restrict__ dense_fwd,
+                                                       uint32_t *__restrict__ n_unknown) {
     static_assert(LQW >= 1 && LQW <= 4, "dword quality rows");
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
     __shared__ uint32_t s_hist[HIST ? OS_MAX_PASSES * RADIX_MAX : 1];
@@ -366,7 +383,16 @@ __global__ __launch_bounds__(256) void k_build_keys_v4(const KL kl, const uint32
         for (int vv = 0; vv < KEY_VB; vv++) {
             const int v = v0 + vv;
             const uint64_t iv = c * (chunk / 4) + (uint64_t)v * 256 + threadIdx.x;
-            const uint32_t b4[4] = {vb[vv].x, vb[vv].y, vb[vv].z, vb[vv].w};
+            uint32_t b4[4] = {vb[vv].x, vb[vv].y, vb[vv].z, vb[vv].w};
+            if (dense_fwd) {  // rank -> column (four independent gathers from a table that stays in L2)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t rk = b4[r];
+                    const uint32_t c = dense_fwd[rk != CRGPU_MISS ? rk : 0u];
+                    if (rk != CRGPU_MISS && c == CRGPU_MISS && iv < n_vec) atomicAdd(n_unknown, 1u);
+                    b4[r] = rk != CRGPU_MISS ? c : CRGPU_MISS;
+                }
+            }
             const uint32_t f4[4] = {vf[vv].x, vf[vv].y, vf[vv].z, vf[vv].w};
             const uint32_t u4[4] = {vu[vv].x, vu[vv].y, vu[vv].z, vu[vv].w};
             uint32_t qw[4 * LQW];
@@ -441,9 +467,13 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     CR_REQUIRE(ctx, (recs->umi_len & 3u) != 0u || (uintptr_t)recs->d_umi_qualn % 4 == 0, CRGPU_EINVAL,
                "crgpu_build_keys: the UMI quality buffer must be 4-byte aligned");
     unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
+    CR_TRY(cr_dense_ensure(ctx));  // CRGPU_OPT_DENSE_BARCODE_KEYS: the BarcodeIndex of the tables as they stand (else nothing)
+    const uint32_t *d_fwd = ctx->dense.valid ? ctx->dense.d_fwd : nullptr;
+    uint32_t *d_unknown = ctx->d_scalars + 60;
     {
         CrTimer t(ctx, CRGPU_T_KEYS, recs->n);
         CR_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(*d_n), ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(d_unknown, 0, sizeof(uint32_t), ctx->stream));
         const KL kl = make_kl(ctx->layout);
         // keys only (no read ordinals): count the sort's digit histograms on the way (1024 workgroups keep the
         // flush at a few million atomics)
@@ -477,19 +507,19 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     if (d_vals_out && d_hist)                                                                                               \
         hipLaunchKernelGGL((k_build_keys<LQW, true, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket, recs->d_umi_len);                                                            \
+                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown);                                          \
     else if (d_vals_out)                                                                                                    \
         hipLaunchKernelGGL((k_build_keys<LQW, false, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket, recs->d_umi_len);                                                            \
+                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown);                                          \
     else if (d_hist)                                                                                                        \
         hipLaunchKernelGGL((k_build_keys<LQW, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,     \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket, recs->d_umi_len);                                                            \
+                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown);                                          \
     else                                                                                                                    \
         hipLaunchKernelGGL((k_build_keys<LQW, false>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,    \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket, recs->d_umi_len)
+                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown)
         // four reads per lane with 16-byte loads where the layout allows it (see k_build_keys_v4); the 1 - 3 reads behind the
         // last multiple of four go through the scalar kernel, appended by the same counter
         const bool aligned16 = ((uintptr_t)recs->d_bc_idx | (uintptr_t)recs->d_umi | (uintptr_t)recs->d_feature |
@@ -500,10 +530,10 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
 #define CR_BUILD_KEYS_V4(LQW)                                                                                                  \
     if (d_hist)                                                                                                                \
         hipLaunchKernelGGL((k_build_keys_v4<LQW, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,      \
-                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, n4, d_keys_out, d_n, plan, d_hist);              \
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, n4, d_keys_out, d_n, plan, d_hist, d_fwd, d_unknown); \
     else                                                                                                                       \
         hipLaunchKernelGGL((k_build_keys_v4<LQW, false>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,     \
-                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, n4, d_keys_out, d_n, plan, d_hist)
+                           recs->d_umi_qualn, recs->d_feature, recs->d_flags, n4, d_keys_out, d_n, plan, d_hist, d_fwd, d_unknown)
             switch (lqw) {
                 case 1: CR_BUILD_KEYS_V4(1); break;
                 case 2: CR_BUILD_KEYS_V4(2); break;
@@ -517,11 +547,11 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
                 if (d_hist)
                     hipLaunchKernelGGL((k_build_keys<0, true>), dim3(1), dim3(256), 0, ctx->stream, kl, recs->d_bc_idx + n4, recs->d_umi + n4,
                                        recs->d_umi_qualn + n4 * recs->umi_len, recs->d_feature + n4, tail_flags, rest, d_keys_out,
-                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr);
+                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr, d_fwd, d_unknown);
                 else
                     hipLaunchKernelGGL((k_build_keys<0, false>), dim3(1), dim3(256), 0, ctx->stream, kl, recs->d_bc_idx + n4, recs->d_umi + n4,
                                        recs->d_umi_qualn + n4 * recs->umi_len, recs->d_feature + n4, tail_flags, rest, d_keys_out,
-                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr);
+                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr, d_fwd, d_unknown);
             }
         } else
         switch (recs->d_umi_len ? 0u : recs->umi_len) {  // per-read lengths: the byte path
@@ -541,6 +571,15 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     }
     unsigned long long h = 0;
     CR_TRY(crgpu_memcpy_d2h(ctx, &h, d_n, sizeof(h)));
+    if (d_fwd) {
+        uint32_t unknown = 0;
+        CR_TRY(crgpu_memcpy_d2h(ctx, &unknown, d_unknown, sizeof(unknown)));
+        if (unknown) {
+            ctx->ghist.valid = false;
+            return cr_fail(ctx, CRGPU_ESTATE, "crgpu_build_keys: %u records carry a barcode that has no read in the VALID / CORRECTED tables "
+                           "(CRGPU_OPT_DENSE_BARCODE_KEYS needs the tables of the whole well before the first key is built)", unknown);
+        }
+    }
     *n_keys_out = h;
     ctx->ghist.n = h;
     return CRGPU_OK;
@@ -560,6 +599,7 @@ extern "C" int crgpu_partition_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, 
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_partition_keys: call crgpu_set_key_layout first");
     CR_REQUIRE(ctx, n == 0 || (d_keys && d_keys_out), CRGPU_EINVAL, "crgpu_partition_keys: NULL buffer");
     cr_invalidate(ctx);
+    CR_TRY(cr_dense_ensure(ctx));
     return cr_partition_by_owner(ctx, d_keys, d_keys_out, n, ctx->layout.sh_bc(), n_ranks, bounds, counts_out);
 }
 
@@ -1087,7 +1127,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mt_write(const Flag flag, const Em
                                                        const uint32_t bits_feat, const uint64_t nd, const uint64_t tile,
                                                        const uint32_t *__restrict__ mol_offs, const uint32_t *__restrict__ head_offs,
                                                        uint32_t *__restrict__ tbc, uint32_t *__restrict__ tfeat,
-                                                       uint32_t *__restrict__ tpos) {
+                                                       uint32_t *__restrict__ tpos, const uint32_t *__restrict__ back) {
+    // back (nullable): the keys' barcode field is a column of the BarcodeIndex; the triplets report whitelist ranks
     __shared__ uint32_t ws[CP_ITEMS * CP_WAVES];  // (molecules | heads << 16) of (wave, item slot), then their exclusive prefix
     __shared__ uint32_t round_total;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1154,7 +1195,8 @@ __global__ __launch_bounds__(CP_BLOCK) void k_mt_write(const Flag flag, const Em
                 emit(i, o, pre[j]);
                 if (h[j]) {
                     const uint32_t t = run_h + (w >> 16) + below_h[j];
-                    tbc[t] = (uint32_t)(pre[j].key >> sh_bc);
+                    const uint32_t bcf = (uint32_t)(pre[j].key >> sh_bc);
+                    tbc[t] = back ? back[bcf] : bcf;
                     tfeat[t] = (uint32_t)((pre[j].key >> sh_feat) & lowmask(bits_feat));
                     tpos[t] = o;
                 }
@@ -1422,13 +1464,14 @@ __global__ __launch_bounds__(256) void k_low_support(const KL kl, const uint32_t
 __global__ __launch_bounds__(256) void k_triplets(const KL kl, const uint64_t *__restrict__ mkeys,
                                                   const uint32_t *__restrict__ tpos, uint64_t nt, uint64_t nm,
                                                   uint32_t *__restrict__ bc, uint32_t *__restrict__ feat,
-                                                  uint32_t *__restrict__ cnt) {
+                                                  uint32_t *__restrict__ cnt, const uint32_t *__restrict__ back) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += stride) {
         const uint32_t p = tpos[t];
         const uint32_t end = t + 1 < nt ? tpos[t + 1] : (uint32_t)nm;
         const uint64_t key = mkeys[p];
-        bc[t] = (uint32_t)(key >> kl.sh_bc);
+        const uint32_t bcf = (uint32_t)(key >> kl.sh_bc);
+        bc[t] = back ? back[bcf] : bcf;
         feat[t] = (uint32_t)((key >> kl.sh_feat) & lowmask(kl.bits_feat));
         cnt[t] = end - p;  // number of surviving molecules of (barcode, feature): types.rs:180-188
     }
@@ -1590,14 +1633,15 @@ __global__ __launch_bounds__(256) void k_scatter_records(const uint64_t *__restr
 __global__ __launch_bounds__(256) void k_corrected_reads(const KL kl, const uint64_t *__restrict__ ukey,
                                                          const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
                                                          const uint16_t *__restrict__ st, uint32_t W,
-                                                         uint32_t *__restrict__ tab) {
+                                                         uint32_t *__restrict__ tab, const uint32_t *__restrict__ back) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
         if (!(st[k] & ST_CORRECTED)) continue;
         const uint64_t key = ukey[k];
         const uint32_t run = (k + 1 < nd ? upos[k + 1] : (uint32_t)n_keys) - upos[k];
         const uint32_t lib = (uint32_t)((key >> kl.sh_libid) & lowmask(kl.bits_lib));
-        atomicAdd(&tab[(size_t)lib * W + (uint32_t)(key >> kl.sh_bc)], run);
+        const uint32_t bcf = (uint32_t)(key >> kl.sh_bc);
+        atomicAdd(&tab[(size_t)lib * W + (back ? back[bcf] : bcf)], run);
     }
 }
 
@@ -1606,7 +1650,8 @@ __global__ __launch_bounds__(256) void k_corrected_reads(const KL kl, const uint
 __global__ __launch_bounds__(256) void k_filtered_reads(const KL kl, const uint64_t *__restrict__ ukey,
                                                         const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
                                                         const uint16_t *__restrict__ st, const uint32_t *__restrict__ inc_all,
-                                                        const TargetFilter tf, uint32_t W, uint32_t *__restrict__ tab) {
+                                                        const TargetFilter tf, uint32_t W, uint32_t *__restrict__ tab,
+                                                        const uint32_t *__restrict__ back) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nd; k += stride) {
         const uint32_t s = st[k];
@@ -1617,7 +1662,8 @@ __global__ __launch_bounds__(256) void k_filtered_reads(const KL kl, const uint6
         const uint64_t key = ukey[k];
         if (!tf.filtered(key, rc, false)) continue;
         const uint32_t lib = (uint32_t)((key >> kl.sh_libid) & lowmask(kl.bits_lib));
-        atomicAdd(&tab[(size_t)lib * W + (uint32_t)(key >> kl.sh_bc)], rc);
+        const uint32_t bcf = (uint32_t)(key >> kl.sh_bc);
+        atomicAdd(&tab[(size_t)lib * W + (back ? back[bcf] : bcf)], rc);
     }
 }
 
@@ -1627,7 +1673,8 @@ __global__ __launch_bounds__(256) void k_filtered_reads(const KL kl, const uint6
 constexpr int MS_ITEMS = 8;
 __global__ __launch_bounds__(256) void k_molecule_sums(const KL kl, const uint64_t *__restrict__ mkeys,
                                                        const uint32_t *__restrict__ mreads, uint64_t nm, uint32_t W,
-                                                       uint32_t *__restrict__ umis, uint32_t *__restrict__ cand) {
+                                                       uint32_t *__restrict__ umis, uint32_t *__restrict__ cand,
+                                                       const uint32_t *__restrict__ back) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * MS_ITEMS;
     for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * MS_ITEMS; base < nm; base += stride) {
         uint64_t key[MS_ITEMS];
@@ -1644,7 +1691,8 @@ __global__ __launch_bounds__(256) void k_molecule_sums(const KL kl, const uint64
         for (int j = 0; j < MS_ITEMS; j++) {
             if (base + j >= nm) break;
             const uint32_t lib = (uint32_t)((key[j] >> kl.sh_libid) & lowmask(kl.bits_lib));
-            const size_t slot = (size_t)lib * W + (uint32_t)(key[j] >> kl.sh_bc);
+            const uint32_t bcf = (uint32_t)(key[j] >> kl.sh_bc);
+            const size_t slot = (size_t)lib * W + (back ? back[bcf] : bcf);
             if (slot != cur) {
                 if (n_u) {
                     atomicAdd(&umis[cur], n_u);
@@ -1763,6 +1811,9 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     *out = nullptr;
     CR_REQUIRE(ctx, ctx->layout.set, CRGPU_ESTATE, "crgpu_count_keys: call crgpu_set_key_layout first");
     CR_REQUIRE(ctx, n_keys <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_keys: at most 2^31-1 keys per call");
+    // CRGPU_OPT_DENSE_BARCODE_KEYS: the index the keys were built with; if something (crgpu_invalidate, ...) dropped it in
+    // between, the tables -- unchanged by the host's promise -- give the same index again
+    CR_TRY(cr_dense_ensure(ctx));
     const KeyLayout &L = ctx->layout;
     const KL kl = make_kl(L);
     crgpu_counts *res = new (std::nothrow) crgpu_counts();
@@ -1773,6 +1824,9 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         *out = res;
         return CRGPU_OK;
     }
+    CR_REQUIRE(ctx, L.total_bits() <= 64, CRGPU_ESTATE,
+               "crgpu_count_keys: the key layout needs the dense barcode index (CRGPU_OPT_DENSE_BARCODE_KEYS) and none is valid -- "
+               "were the keys built before the last change of a histogram table?");
     CR_REQUIRE(ctx, d_keys_inout, CRGPU_EINVAL, "crgpu_count_keys: NULL keys");
     struct Guard {
         crgpu_ctx *c;
@@ -1785,6 +1839,12 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
 
     uint32_t *d_block = ctx->d_sort_hist;      // 4096 u32 block counters of the compactions
     uint32_t *d_total = ctx->d_scalars + 16;   // device-side totals
+    if (ctx->dense.valid) {  // the result keeps its own copy of the column -> rank map: the context's may change before it is read
+        res->n_back = ctx->dense.V;
+        CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_back, (size_t)ctx->dense.V * sizeof(uint32_t)));
+        CR_HIP(ctx, hipMemcpyAsync(res->d_back, ctx->dense.d_back, (size_t)ctx->dense.V * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+    }
 
     // 1. sort the keys: fully, or on their top bits with the finishing left to the run-length pass (CRGPU_SORT_FINISH)
     DevBuf tmp, vtmp;
@@ -2096,10 +2156,11 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             CR_TRY(cr_scan_small(ctx, d_heads, nb, d_total_h));
             if (tf.min_reads)
                 hipLaunchKernelGGL(k_mt_write<MolFlagTargeted>, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, flag_t, emit, L.sh_bc(),
-                                   L.sh_feat(), L.bits_feat, nd, tile, d_block, d_heads, res->d_bc, res->d_feature, tpos_b.as<uint32_t>());
+                                   L.sh_feat(), L.bits_feat, nd, tile, d_block, d_heads, res->d_bc, res->d_feature, tpos_b.as<uint32_t>(),
+                                   res->d_back);
             else
                 hipLaunchKernelGGL(k_mt_write<MolFlag>, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, flag_p, emit, L.sh_bc(), L.sh_feat(),
-                                   L.bits_feat, nd, tile, d_block, d_heads, res->d_bc, res->d_feature, tpos_b.as<uint32_t>());
+                                   L.bits_feat, nd, tile, d_block, d_heads, res->d_bc, res->d_feature, tpos_b.as<uint32_t>(), res->d_back);
             CR_HIP(ctx, hipGetLastError());
         }
         CR_TRY(read_u32(ctx, d_total, &nm32));
@@ -2128,12 +2189,12 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         CrTimer t(ctx, CRGPU_T_DEDUP);
         CR_HIP(ctx, hipMemsetAsync(res->d_corr_reads, 0, bytes, ctx->stream));
         hipLaunchKernelGGL(k_corrected_reads, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, st,
-                           ctx->n_canon, res->d_corr_reads);
+                           ctx->n_canon, res->d_corr_reads, res->d_back);
         if (tf.min_reads) {
             CR_TRY(cr_pool_alloc(ctx, (void **)&res->d_filt_reads, bytes));
             CR_HIP(ctx, hipMemsetAsync(res->d_filt_reads, 0, bytes, ctx->stream));
             hipLaunchKernelGGL(k_filtered_reads, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, upos, nd, n_keys, st,
-                               inc_all, tf, ctx->n_canon, res->d_filt_reads);
+                               inc_all, tf, ctx->n_canon, res->d_filt_reads, res->d_back);
         }
         CR_HIP(ctx, hipGetLastError());
     }
@@ -2163,7 +2224,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
                                res->d_count);
         else
             hipLaunchKernelGGL(k_triplets, dim3(cr_grid(nt, 256)), dim3(256), 0, ctx->stream, kl, mkeys_b.as<uint64_t>(),
-                               tpos_b.as<uint32_t>(), nt, nm, res->d_bc, res->d_feature, res->d_count);
+                               tpos_b.as<uint32_t>(), nt, nm, res->d_bc, res->d_feature, res->d_count, res->d_back);
         CR_HIP(ctx, hipGetLastError());
     }
     CR_TRY(fork2.join());
@@ -2349,6 +2410,52 @@ struct EmitCol {
     __device__ __forceinline__ Pre pre(uint64_t) const { return Pre(); }
     __device__ __forceinline__ void operator()(uint64_t r, uint32_t o, Pre) const { rank[o] = (uint32_t)r; }
 };
+
+// ---- CRGPU_OPT_DENSE_BARCODE_KEYS: the BarcodeIndex of the tables as they stand (cr_types/src/barcode_index.rs:20-53) ------
+__global__ __launch_bounds__(256) void k_dense_fwd(const uint32_t *__restrict__ back, uint32_t V, uint32_t *__restrict__ fwd) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < V; c += stride) fwd[back[c]] = c;
+}
+int cr_dense_ensure(crgpu_ctx *ctx) {
+    DenseIndex &D = ctx->dense;
+    if (!D.on || D.valid) return CRGPU_OK;
+    CR_REQUIRE(ctx, ctx->canon_set && ctx->layout.set, CRGPU_ESTATE, "dense barcode keys: whitelist and key layout first");
+    const uint32_t W = ctx->n_canon;
+    SeenFlag seen;
+    seen.ct.n = 0;
+    for (int l = 0; l < CRGPU_MAX_LIB; l++)
+        if (ctx->wl[l].set) {
+            seen.ct.t[seen.ct.n++] = ctx->wl[l].d_valid;
+            seen.ct.t[seen.ct.n++] = ctx->wl[l].d_corrected;
+        }
+    if (!D.d_fwd) CR_HIP(ctx, hipMalloc((void **)&D.d_fwd, (size_t)W * sizeof(uint32_t)));
+    if (!D.d_back) CR_HIP(ctx, hipMalloc((void **)&D.d_back, (size_t)W * sizeof(uint32_t)));
+    uint32_t *d_total = ctx->d_scalars + 16;
+    uint32_t V = 0;
+    {
+        CrTimer t(ctx, CRGPU_T_KEYS);
+        CR_TRY(compact(ctx, seen, EmitCol{D.d_back}, W, ctx->d_sort_hist, d_total));
+    }
+    CR_TRY(read_u32(ctx, d_total, &V));
+    KeyLayout L = ctx->layout;
+    L.bits_bc = V > 1 ? cr_ceil_log2(V) : 1u;
+    CR_REQUIRE(ctx, L.total_bits() <= 64, CRGPU_ERANGE,
+               "molecule key needs %u bits even with %u barcodes in the index (barcode %u + feature %u + library %u + umi %u + 1) > 64",
+               L.total_bits(), V, L.bits_bc, L.bits_feat, L.bits_lib, L.bits_umi + L.bits_ulen);
+    {
+        CrTimer t(ctx, CRGPU_T_KEYS);
+        CR_HIP(ctx, hipMemsetAsync(D.d_fwd, 0xFF, (size_t)W * sizeof(uint32_t), ctx->stream));
+        if (V) hipLaunchKernelGGL(k_dense_fwd, dim3(cr_grid(V, 256)), dim3(256), 0, ctx->stream, D.d_back, V, D.d_fwd);
+        CR_HIP(ctx, hipGetLastError());
+    }
+    D.h_back.resize(V);
+    if (V) CR_TRY(crgpu_memcpy_d2h(ctx, D.h_back.data(), D.d_back, (uint64_t)V * sizeof(uint32_t)));
+    D.V = V;
+    D.valid = true;
+    ctx->layout = L;
+    ctx->ghist.valid = false;
+    return CRGPU_OK;
+}
 
 __global__ __launch_bounds__(256) void k_csc(const uint32_t *__restrict__ col_rank, uint64_t n_cols,
                                              const uint32_t *__restrict__ t_bc, const uint32_t *__restrict__ t_feat,
@@ -2720,9 +2827,14 @@ extern "C" int crgpu_counts_molecules(crgpu_ctx *ctx, const crgpu_counts *c, uin
     CR_TRY(molecule_order(ctx, c, keys, reads, order));
     const KeyLayout &L = c->layout;
     auto fld = [&](uint64_t k, uint32_t sh, uint32_t bits) { return (uint32_t)((k >> sh) & (bits >= 64 ? ~0ull : ((1ull << bits) - 1))); };
+    std::vector<uint32_t> back;
+    if (c->d_back && bc_out) {
+        back.resize(c->n_back);
+        CR_TRY(crgpu_memcpy_d2h(ctx, back.data(), c->d_back, (uint64_t)c->n_back * sizeof(uint32_t)));
+    }
     for (uint64_t o = 0; o < nm; o++) {
         const uint64_t k = keys[order[o]];
-        if (bc_out) bc_out[o] = (uint32_t)(k >> L.sh_bc());
+        if (bc_out) bc_out[o] = back.empty() ? (uint32_t)(k >> L.sh_bc()) : back[(uint32_t)(k >> L.sh_bc())];
         if (lib_out) lib_out[o] = (uint8_t)fld(k, L.sh_libid(), L.bits_lib);
         if (feature_out) feature_out[o] = fld(k, L.sh_feat(), L.bits_feat);
         if (umi_out) umi_out[o] = fld(k, L.sh_umi(), L.bits_umi);
@@ -2781,7 +2893,7 @@ extern "C" int crgpu_counts_barcode_summary(crgpu_ctx *ctx, const crgpu_counts *
         CR_HIP(ctx, hipMemsetAsync(cand_b.p, 0, tab_bytes, ctx->stream));
         hipLaunchKernelGGL(k_molecule_sums, dim3(cr_grid((c->n_molecules + MS_ITEMS - 1) / MS_ITEMS, 256)), dim3(256), 0,
                            ctx->stream, kl, c->d_mkeys, c->d_mreads, c->n_molecules, W, umis_b.as<uint32_t>(),
-                           cand_b.as<uint32_t>());
+                           cand_b.as<uint32_t>(), c->d_back);
         CR_HIP(ctx, hipGetLastError());
     }
     const uint64_t span = rank_hi - rank_lo;
@@ -2825,6 +2937,7 @@ extern "C" void crgpu_counts_free(crgpu_ctx *ctx, crgpu_counts *c) {
     cr_pool_free(ctx, c->d_corr_reads);
     cr_pool_free(ctx, c->d_filt_reads);
     cr_pool_free(ctx, c->d_mprobe);
+    cr_pool_free(ctx, c->d_back);
     delete c;
 }
 

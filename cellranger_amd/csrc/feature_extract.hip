@@ -830,12 +830,12 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
             CrTimer t(ctx, CRGPU_T_FEATURE, n);
             if (X.t_n_feat <= 1024u) {
                 const size_t lds = (size_t)slots * 12 + (size_t)4 * 64 * P.pitch * 4 + 8 + 2 * 256 * sizeof(FxtPending);
-                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<256>, lds);
+                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<256>, 160 * 1024);
                 hipLaunchKernelGGL(k_extract_tethered_lds<256>, dim3(cr_grid(n, 256, 256u * 4u)), dim3(256), lds, ctx->stream, v, P,
                                    d_pe, R, n, d_feature_out, d_n_ids_out, d_capture_out);
             } else {
                 const size_t lds = (size_t)slots * 12 + (size_t)16 * 64 * P.pitch * 4 + 8 + 2 * 1024 * sizeof(FxtPending);
-                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<1024>, lds);
+                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<1024>, 160 * 1024);
                 hipLaunchKernelGGL(k_extract_tethered_lds<1024>, dim3(cr_grid(n, 1024, 256u)), dim3(1024), lds, ctx->stream, v, P, d_pe,
                                    R, n, d_feature_out, d_n_ids_out, d_capture_out);
             }

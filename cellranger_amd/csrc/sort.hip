@@ -19,6 +19,8 @@
 #include <vector>
 
 #include "block_utils.h"
+#include <algorithm>
+
 #include "common.h"
 
 // One workgroup of 1024 threads per CU with a 16 K-key chunk (128 KB of LDS).  What bounds the scatter is
@@ -1122,38 +1124,58 @@ __global__ __launch_bounds__(256) void k_find_descents(const uint64_t *__restric
     if (lane == 0 && set) atomicAdd(n_words_set, set);
 }
 
+// one descent: find the head of its run and, when it is the run's first descent, put the run in order
+template <bool HAS_VALS>
+__device__ __forceinline__ void repair_at(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low,
+                                          const unsigned long long *__restrict__ desc, uint64_t p, uint32_t *__restrict__ bad) {
+    // keys[p] < keys[p - 1], same top bits.  Walk back to the head of the run.  An earlier descent on the way means another
+    // lane owns the run.  Only things that no repair changes are looked at: the descent bits (read-only here) and the TOP
+    // bits of the keys (a repair permutes keys inside one run, whose top bits are all equal) -- the owner may already be
+    // rewriting this run.
+    const uint64_t top = keys[p] >> low;
+    uint64_t h = p;
+    for (;;) {
+        h--;  // keys[h] belongs to the run (p - 1 does by construction)
+        if ((desc[h >> 6] >> (h & 63u)) & 1ull) return;
+        if (h == 0 || (keys[h - 1] >> low) != top) break;  // h is the head
+        if (p - h > OR_MAX) {
+            atomicOr(bad, 1u);
+            return;
+        }
+    }
+    or_run_through_memory<HAS_VALS>(keys, vals, n, low, h, bad);
+}
+
+// The descents are few (a few per mille of the keys) and scattered: a lane that took them straight from its mask word
+// would work while its 63 neighbours wait.  A workgroup therefore collects the descents of RR_WORDS mask words in LDS and
+// hands them out one per thread.
+#define RR_WORDS 2048u
+#define RR_CAP 4096u
 template <bool HAS_VALS>
 __global__ __launch_bounds__(256) void k_repair_runs(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low,
                                                      const unsigned long long *__restrict__ desc, uint64_t n_words,
                                                      uint32_t *__restrict__ bad) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
-        unsigned long long m = desc[w];
-        while (m) {
-            const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
-            m &= m - 1ull;
-            const uint64_t p = w * 64 + b;  // keys[p] < keys[p - 1], same top bits
-            // Walk back to the head of the run.  An earlier descent on the way means another lane owns the run.  Only things
-            // that no repair changes are looked at: the descent bits (read-only here) and the TOP bits of the keys (a repair
-            // permutes keys inside one run, whose top bits are all equal) -- the owner may already be rewriting this run.
-            const uint64_t top = keys[p] >> low;
-            uint64_t h = p;
-            bool first = true;
-            for (;;) {
-                h--;  // keys[h] belongs to the run (p - 1 does by construction)
-                if ((desc[h >> 6] >> (h & 63u)) & 1ull) {
-                    first = false;
-                    break;
-                }
-                if (h == 0 || (keys[h - 1] >> low) != top) break;  // h is the head
-                if (p - h > OR_MAX) break;
+    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_pos[RR_CAP];  // position inside the tile (RR_WORDS * 64 keys: 17 bits)
+    const uint64_t n_tiles = (n_words + RR_WORDS - 1) / RR_WORDS;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t w0 = tile * RR_WORDS;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < RR_WORDS; j += 256) {
+            unsigned long long m = w0 + j < n_words ? desc[w0 + j] : 0ull;
+            while (m) {
+                const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
+                m &= m - 1ull;
+                const uint32_t slot = atomicAdd(&s_n, 1u);
+                if (slot < RR_CAP) s_pos[slot] = j * 64u + b;
+                else repair_at<HAS_VALS>(keys, vals, n, low, desc, (w0 + j) * 64 + b, bad);  // a tile full of descents: at once
             }
-            if (first && p - h > OR_MAX) {
-                atomicOr(bad, 1u);
-                continue;
-            }
-            if (first) or_run_through_memory<HAS_VALS>(keys, vals, n, low, h, bad);
         }
+        __syncthreads();
+        const uint32_t cnt = s_n < RR_CAP ? s_n : RR_CAP;
+        for (uint32_t t = threadIdx.x; t < cnt; t += 256) repair_at<HAS_VALS>(keys, vals, n, low, desc, w0 * 64 + s_pos[t], bad);
+        __syncthreads();
     }
 }
 
@@ -1175,7 +1197,7 @@ int cr_repair_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t 
         const uint64_t n_spans = (n + 64ull * FD_ITEMS - 1) / (64ull * FD_ITEMS);
         hipLaunchKernelGGL(k_find_descents, dim3(cr_grid(n_spans * 64u, 256, 256u * 8u)), dim3(256), 0, ctx->stream, d_keys, n, low_bits,
                            (unsigned long long *)d_desc, d_set);
-        const dim3 grid(cr_grid(n_words, 256, 256u * 8u));
+        const dim3 grid(cr_grid((n_words + RR_WORDS - 1) / RR_WORDS, 1, 256u * 8u));
         if (d_vals)
             hipLaunchKernelGGL(k_repair_runs<true>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits,
                                (const unsigned long long *)d_desc, n_words, d_flag);
@@ -1586,7 +1608,30 @@ int cr_partition_by_owner_kv(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_o
     CR_REQUIRE(ctx, n <= 0x7FFFFFFFull, CRGPU_ERANGE, "partition: at most 2^31-1 keys per call");
     for (uint32_t r = 0; r < n_ranks; r++) counts_out[r] = 0;
     if (n == 0) return CRGPU_OK;
-    if (bounds) {
+    std::vector<uint32_t> col_bounds;
+    if (ctx->dense.valid) {
+        // CRGPU_OPT_DENSE_BARCODE_KEYS: the keys hold columns of the BarcodeIndex, the owner ranges are whitelist ranks: the
+        // range [lo, hi) of ranks is the range of the columns whose rank lies in it (columns ascend with the ranks)
+        const std::vector<uint32_t> &back = ctx->dense.h_back;
+        const uint32_t width = (ctx->n_canon + n_ranks - 1) / n_ranks;
+        col_bounds.resize(n_ranks + 1);
+        for (uint32_t r = 0; r <= n_ranks; r++) {
+            const uint64_t lo = bounds ? bounds[r] : (uint64_t)r * (width ? width : 1u);
+            col_bounds[r] = (uint32_t)(std::lower_bound(back.begin(), back.end(), (uint32_t)std::min<uint64_t>(lo, 0xFFFFFFFFull)) - back.begin());
+        }
+        if (bounds) {
+            CR_REQUIRE(ctx, bounds[0] == 0 && bounds[n_ranks] >= ctx->n_canon, CRGPU_EINVAL,
+                       "partition: bounds must start at 0 and end at or beyond the whitelist size");
+            for (uint32_t r = 0; r < n_ranks; r++)
+                CR_REQUIRE(ctx, bounds[r] <= bounds[r + 1], CRGPU_EINVAL, "partition: bounds must be ascending");
+        }
+        col_bounds[0] = 0;
+        col_bounds[n_ranks] = ctx->dense.V;
+        uint32_t *d_bounds = ctx->d_scalars + 760;
+        CR_HIP(ctx, hipMemcpyAsync(d_bounds, col_bounds.data(), (n_ranks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CR_TRY((radix_pass<uint64_t, OwnerBounds>(ctx, d_in, d_out, d_vin, d_vout, n, OwnerBounds{sh_bc, n_ranks, d_bounds})));
+    } else if (bounds) {
         // rank r owns canonical barcode ranks [bounds[r], bounds[r+1])
         CR_REQUIRE(ctx, bounds[0] == 0 && bounds[n_ranks] >= ctx->n_canon, CRGPU_EINVAL,
                    "partition: bounds must start at 0 and end at or beyond the whitelist size");

@@ -44,6 +44,7 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
                                           const uint32_t *canon, uint32_t n_canon, const uint32_t *translate_to) {
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
+    cr_dense_drop(ctx);
     CR_REQUIRE(ctx, lib >= 0 && lib < CRGPU_MAX_LIB, CRGPU_EINVAL, "library id %d out of range", lib);
     CR_REQUIRE(ctx, keys && canon && n > 0 && n_canon > 0, CRGPU_EINVAL, "empty whitelist");
     CR_REQUIRE(ctx, len >= 1 && len <= 16, CRGPU_ERANGE,
@@ -202,6 +203,7 @@ extern "C" int crgpu_set_barcode_segments(crgpu_ctx *ctx, int lib, uint32_t n_se
                                           const uint32_t *seg_len, const uint32_t *const *seg_seqs) {
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
+    cr_dense_drop(ctx);
     CR_REQUIRE(ctx, lib >= 0 && lib < CRGPU_MAX_LIB, CRGPU_EINVAL, "library id %d out of range", lib);
     CR_REQUIRE(ctx, n_segments >= 1 && n_segments <= CRGPU_MAX_SEGMENTS && seg_n && seg_len && seg_seqs, CRGPU_EINVAL,
                "crgpu_set_barcode_segments: 1..%d segments", CRGPU_MAX_SEGMENTS);
@@ -302,6 +304,7 @@ extern "C" int crgpu_set_counts(crgpu_ctx *ctx, int lib, int which, const uint32
     CR_ENTER(ctx);
     uint32_t *d;
     CR_TRY(table_ptr(ctx, lib, which, true, &d));
+    cr_dense_drop(ctx);
     return crgpu_memcpy_h2d(ctx, d, counts, sizeof(uint32_t) * ctx->n_canon);
 }
 
@@ -315,6 +318,7 @@ extern "C" int crgpu_reset_counts(crgpu_ctx *ctx) {
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     cr_invalidate(ctx);
+    cr_dense_drop(ctx);
     for (auto &w : ctx->wl)
         if (w.set) {
             CR_HIP(ctx, hipMemsetAsync(w.d_valid, 0, sizeof(uint32_t) * ctx->n_canon, ctx->stream));

@@ -101,6 +101,18 @@ void crgpu_destroy(crgpu_ctx *ctx);
 int crgpu_comm_info(crgpu_ctx *ctx, uint32_t *n_ranks_out, uint32_t *rank_out);
 /* options (see the conventions above) */
 #define CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS 0
+/* 1: molecule keys carry the barcode's position in the BarcodeIndex (the matrix column: canonical barcodes with a
+ * non-zero VALID or CORRECTED count in any library, ascending -- cr_types/src/barcode_index.rs:20-53) instead of its rank
+ * on the whitelist.  ~2 * 10^5 columns need 18 bits where the 3M-february-2018 list needs 23 and a GelBeadAndProbe product
+ * space (737 K x 16) 24: the keys get shorter (one radix pass fewer on the 3M list) and layouts that need more than 64 bits
+ * with whitelist ranks fit (crgpu_set_key_layout accepts them; the first key-building call fails with CRGPU_ERANGE if the
+ * columns that occur do not fit either).  The index is taken from the tables when the first key is built, so the host
+ * promises the reference's stage order: every read of the well has been through pass A and pass B (and, on several GPUs,
+ * both tables have been all-reduced) BEFORE the first crgpu_build_keys_dev / crgpu_count_* call, and keys of one count call
+ * were all built after the last change of a table.  Every call that changes a table drops the index.  Set the option
+ * before crgpu_set_key_layout.  Outputs are unchanged: triplets, molecules and summaries report whitelist ranks.  A record
+ * whose barcode has no read in the tables makes the key-building call fail (CRGPU_ESTATE) instead of being dropped. */
+#define CRGPU_OPT_DENSE_BARCODE_KEYS 1
 int crgpu_set_option(crgpu_ctx *ctx, int option, int64_t value);
 int crgpu_invalidate(crgpu_ctx *ctx);
 /* counters since the context was made */

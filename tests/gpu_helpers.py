@@ -18,13 +18,20 @@ def ctx():
     return _ctx
 
 
-def fresh_ctx(trust=True):
+def fresh_ctx(trust=True, dense=None):
     """trust: CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS -- the tests write their buffers only through the context, so
     the by-product paths (K1's miss records for K2, the key histograms for the sort) are what most of them exercise;
-    tests/test_gpu_barcode.py covers the default (off) and the invalidation rules."""
+    tests/test_gpu_barcode.py covers the default (off) and the invalidation rules.
+    dense: CRGPU_OPT_DENSE_BARCODE_KEYS (keys carry BarcodeIndex columns instead of whitelist ranks); None = what the
+    environment says (CRGPU_TEST_DENSE=1 runs the whole suite that way; tests that hand-craft keys pass dense=False)."""
+    import os
     c = E.Context(0)
     if trust:
         c.trust_unchanged_buffers(True)
+    if dense is None:
+        dense = os.environ.get("CRGPU_TEST_DENSE") == "1"
+    if dense:
+        c.set_option(1, 1)
     return c
 
 

@@ -411,8 +411,8 @@ def test_random_key_layouts_bit_exact():
     assert len(seen_bits) >= 8 and max(seen_bits) >= 58 and min(seen_bits) <= 30
 
 
-@pytest.mark.parametrize("bad_pass", [0, 2, 5])
-def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, monkeypatch):
+@pytest.mark.parametrize("bad_pass,finish", [(0, "2"), (2, "2"), (4, "2"), (5, "0")])
+def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, finish, monkeypatch):
     """The look-back chain of one onesweep pass is stalled on purpose (CRGPU_SORT_FORCE_ABORT: chunk 0 never publishes).
     The watchdog raises the abort word, that pass and the ones queued behind it write nothing, and the host finishes the
     sort from the failed pass on with the classic histogram / scan / scatter passes inside the same call: the call
@@ -421,11 +421,14 @@ def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, monkeypatc
     import gpu_helpers as G
     from cellranger_amd import synth as S
 
+    monkeypatch.setenv("CRGPU_SORT_FINISH", finish)
     n = 400_000
     w = S.Workload(n_total=n, seed=58, n_wl=60_000, n_cells=150, n_ambient=5000, n_genes=500)
     c = G.fresh_ctx()
     c.set_whitelist(0, w.wl_packed, length=16)
-    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)   # 16 + 9 + 24 + 1 = 50 bits: six passes (8+8+8+8+9+9)
+    # 16 + 9 + 24 + 1 = 50 bits: six passes (8+8+8+8+9+9) on all bits (finish "0"), five 9-bit passes on the top 45 bits +
+    # k_repair_runs on the low 5 (the default, "2")
+    c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
     r = w.host_reads(0, n)
     _, _, _, dev = G.gpu_barcode_stage(c, r, n)
     d_umi, d_uq, d_ft = c.upload(r["umi"]), c.upload(r["umi_qualn"]), c.upload(r["feature"])

@@ -40,8 +40,11 @@ def _segment_stage(c, rows_s, rows_q, n, stride, offset, length):
     return d_idx_a, d_idx, d_fl
 
 
-@pytest.mark.parametrize("n_probe,seed", [(16, 1), (3, 2)])
-def test_gel_bead_and_probe_construct_matches_the_oracle(n_probe, seed, tmp_path):
+@pytest.mark.parametrize("n_probe,seed,big", [(16, 1, False), (3, 2, False), (16, 3, True)])
+def test_gel_bead_and_probe_construct_matches_the_oracle(n_probe, seed, big, tmp_path):
+    """big: the production shape of Flex -- 737 280 gel-bead barcodes x 16 probe barcodes, 36 601 features, 12-base UMIs.
+    With whitelist ranks the molecule key needs 24 + 16 + 24 + 1 = 65 bits (CRGPU_ERANGE); with
+    CRGPU_OPT_DENSE_BARCODE_KEYS the barcode field holds the BarcodeIndex column (the few thousand barcodes that occur)."""
     import gpu_helpers as G
     import oracle_lib as O
     from cellranger_amd import engine as E
@@ -49,7 +52,7 @@ def test_gel_bead_and_probe_construct_matches_the_oracle(n_probe, seed, tmp_path
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     LA, LB, LU = 16, 8, 12
-    n_gb, n_feat, n = 3000, 60, 80_000
+    n_gb, n_feat, n = (737_280, 36_601, 80_000) if big else (3000, 60, 80_000)
     wl_a = np.unique(rng.integers(0, 1 << 32, n_gb * 2, dtype=np.uint64).astype(np.uint32))[:n_gb]
     wl_b = np.unique(rng.integers(0, 1 << 16, n_probe * 8, dtype=np.uint64).astype(np.uint32))
     wl_b = np.sort(rng.permutation(wl_b)[:n_probe])
@@ -75,12 +78,18 @@ def test_gel_bead_and_probe_construct_matches_the_oracle(n_probe, seed, tmp_path
     rows_q[rng.random((n, stride)) < 0.03] = 33 + 2
 
     # ---- GPU: one context per segment, one for counting ----------------------------------------------------
-    ca, cb, cc = G.fresh_ctx(), G.fresh_ctx(), G.fresh_ctx()
+    ca, cb, cc = G.fresh_ctx(), G.fresh_ctx(), G.fresh_ctx(dense=True if big else None)
     ca.set_whitelist(0, wl_a, length=LA)
     cb.set_whitelist(0, wl_b, length=LB)
     _, a_sorted = ca.canon_order()
     _, b_sorted = cb.canon_order()
     cc.set_barcode_segments(0, [a_sorted, b_sorted], [LA, LB])
+    if big:   # whitelist ranks do not fit: 65 bits
+        c0 = G.fresh_ctx(dense=False)
+        c0.set_barcode_segments(0, [a_sorted, b_sorted], [LA, LB])
+        with pytest.raises(E.CrgpuError, match="65 bits"):
+            c0.set_key_layout(n_feat, LU, 1, 0)
+        c0.close()
     with pytest.raises(E.CrgpuError, match="segment contexts"):
         cc.match_and_count(cc.empty(4, np.uint32), None, 4, cc.empty(4, np.uint32))
     with pytest.raises(E.CrgpuError):
