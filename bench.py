@@ -631,8 +631,12 @@ def main():
         }
         if world > 1 and ledger.get("comm", (0, 0, 0))[1]:
             cm = ledger["comm"]
+            total_steps = args.warmup + args.steps + (0 if args.no_default_options else 1 + max(1, min(2, args.steps)))
             line["comm"] = {"ms_per_step": cm[0] / args.steps, "collectives_per_step": cm[1] / args.steps,
-                            "note": "rank 0's C1 / C2 / C3 spans incl. waiting for the other ranks (HIP events around each collective)"}
+                            "bytes_per_step_rank0": {"C1_table_allreduce": ctx.stat(5) / total_steps, "C2_key_exchange": ctx.stat(6) / total_steps,
+                                                     "C3_triplet_gather": ctx.stat(7) / total_steps},
+                            "note": "rank 0's C1 / C2 / C3 spans incl. waiting for the other ranks (HIP events around each collective); "
+                                    "bytes = what rank 0 put into each collective per step (C2: its keys, own share included)"}
         if world == 1 and workload == "cfg3" and not args.no_verify and dup_out is None:
             # not timed: the laws of cellranger_amd/selfcheck.py on this very workload at its full size
             from cellranger_amd import selfcheck

@@ -104,10 +104,17 @@ __device__ __forceinline__ uint32_t wave_multisplit_rank(uint32_t d, bool ok, C 
 // Returns the sum of the counts of all tiles before `tile`.  64 predecessors are read per round trip -- a single lane
 // walking back one word at a time falls behind as soon as a walk takes longer than the stagger between tiles, and then
 // every walk gets long (measured: 60 us per 2048-key tile).
-__device__ __forceinline__ unsigned long long wave_lookback(const unsigned long long *status, uint64_t tile) {
+// Watchdog (abort_word nullable): tiles are handed out by tickets, so every predecessor is held by a workgroup that is running
+// or done and the chain always moves on -- as long as the device schedules those workgroups.  Should that ever not hold (CU
+// masking, a shared device), a waiter gives up after ~2^22 polls, raises *abort_word and returns WAVE_LOOKBACK_ABORTED; every
+// other waiter sees the word within 4096 polls and leaves, too: no hung GPU, the host reports an error.
+#define WAVE_LOOKBACK_ABORTED (~0ull)
+__device__ __forceinline__ unsigned long long wave_lookback(const unsigned long long *status, uint64_t tile,
+                                                            uint32_t *abort_word = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long excl = 0;
     uint64_t end = tile;  // predecessors [.., end) are still to be added
+    uint32_t polls = 0;
     for (;;) {
         const bool valid = end > lane;
         unsigned long long sv = 2ull << 62;  // before tile 0: an inclusive prefix of 0
@@ -118,6 +125,10 @@ __device__ __forceinline__ unsigned long long wave_lookback(const unsigned long 
         const unsigned long long need = first >= 63u ? ~0ull : ((2ull << first) - 1ull);  // lanes 0 .. first
         if (pending & need) {
             __builtin_amdgcn_s_sleep(1);
+            if (abort_word && (++polls & 0xFFFu) == 0u) {  // uniform: every lane counts the same polls
+                if (polls >= (1u << 22) && lane == 0) atomicExch(abort_word, 1u);
+                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return WAVE_LOOKBACK_ABORTED;
+            }
             continue;  // somebody in front of the first inclusive prefix has not published yet: same window again
         }
         unsigned long long v = lane <= first ? (sv & ((1ull << 62) - 1ull)) : 0ull;

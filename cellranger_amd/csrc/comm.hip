@@ -42,6 +42,7 @@ struct LocalGroup {
     // what a rank publishes for the collective in flight
     const void *ptr[CR_MAX_RANKS] = {nullptr};
     int device[CR_MAX_RANKS] = {0};
+    bool has_rank[CR_MAX_RANKS] = {false};
     std::vector<uint64_t> nums[CR_MAX_RANKS];
     double dbl[CR_MAX_RANKS] = {0};
 
@@ -118,6 +119,9 @@ extern "C" int crgpu_local_group_id(uint32_t n_ranks, void *id_out) {
 }
 
 int cr_comm_init(crgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id) {
+    // the collectives keep per-rank words in arrays of CR_MAX_RANKS entries
+    CR_REQUIRE(ctx, n_ranks >= 1 && n_ranks <= CR_MAX_RANKS, CRGPU_EINVAL, "crgpu_create: at most %d ranks per communicator (%d asked)",
+               CR_MAX_RANKS, n_ranks);
     CrComm *c = new (std::nothrow) CrComm();
     if (!c) return cr_fail(ctx, CRGPU_ENOMEM, "out of host memory");
     ctx->n_ranks = n_ranks;
@@ -130,24 +134,47 @@ int cr_comm_init(crgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id) {
             return cr_fail(ctx, CRGPU_EINVAL, "crgpu_create: the local group id was made for %u ranks, not %d", lid.n_ranks, n_ranks);
         }
         c->local = lid.group;
-        ctx->comm = c;
+        ctx->comm = c;  // from here on crgpu_destroy releases this context's reference to the group
+        bool dup = false;
         {
             std::lock_guard<std::mutex> lk(c->local->m);
-            c->local->device[rank] = ctx->device;
-            c->local->joined++;
+            dup = c->local->has_rank[rank];
+            if (!dup) {
+                c->local->has_rank[rank] = true;
+                c->local->device[rank] = ctx->device;
+                c->local->joined++;
+            }
+        }
+        if (dup) {  // two contexts with one rank: the group can never be complete
+            c->local->abort();
+            return cr_fail(ctx, CRGPU_EINVAL, "crgpu_create: rank %d joined the local group twice", rank);
         }
         if (!c->local->barrier()) return cr_fail(ctx, CRGPU_ECOMM, "crgpu_create: the other ranks of the local group did not arrive");
-        // peer access for the device-to-device copies between different GPUs of the process
-        for (int r = 0; r < n_ranks; r++) {
+        // peer access for the device-to-device copies (and the table sums, which dereference the other ranks' pointers)
+        // between different GPUs of the process: a peer that cannot be reached fails the create instead of a later kernel
+        int peer_fail = -1;
+        for (int r = 0; r < n_ranks && peer_fail < 0; r++) {
             const int d = c->local->device[r];
             if (d == ctx->device) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, ctx->device, d) == hipSuccess && can) {
-                hipError_t e = hipDeviceEnablePeerAccess(d, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-                (void)hipGetLastError();
+            if (hipDeviceCanAccessPeer(&can, ctx->device, d) != hipSuccess || !can) {
+                peer_fail = d;
+                break;
             }
+            hipError_t e = hipDeviceEnablePeerAccess(d, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peer_fail = d;
+            (void)hipGetLastError();
         }
+        // every rank learns whether all of them reach their peers (one more rendezvous with the verdicts)
+        c->local->nums[rank].assign(1, peer_fail >= 0 ? 1u : 0u);
+        if (!c->local->barrier()) return cr_fail(ctx, CRGPU_ECOMM, "crgpu_create: the local group broke during setup");
+        bool any_fail = false;
+        for (int r = 0; r < n_ranks; r++) any_fail |= c->local->nums[r].size() == 1 && c->local->nums[r][0] != 0;
+        if (!c->local->barrier()) return cr_fail(ctx, CRGPU_ECOMM, "crgpu_create: the local group broke during setup");
+        if (peer_fail >= 0)
+            return cr_fail(ctx, CRGPU_ECOMM, "crgpu_create: device %d cannot access its peer device %d (no xGMI / PCIe peer path)", ctx->device,
+                           peer_fail);
+        if (any_fail) return cr_fail(ctx, CRGPU_ECOMM, "crgpu_create: another rank of the local group cannot reach its peer devices");
         return CRGPU_OK;
     }
     ncclUniqueId id;
@@ -303,6 +330,67 @@ static int comm_alltoallv(crgpu_ctx *ctx, const void *d_send, const uint64_t *se
     return CRGPU_OK;
 }
 
+// ---- agreement on failure ----------------------------------------------------------------------------------------------------
+// RCCL has no timeout: a rank that returns with a local error (out of memory, a launch failure, a limit) between two
+// collectives leaves its peers waiting in the next one for ever.  So every local step in front of a data exchange only
+// RECORDS its status; the status travels with the count exchange (or a one-word all-gather of its own), and all ranks leave
+// together: the failing rank with its own error, the others with CRGPU_ECOMM naming it.
+int cr_comm_agree(crgpu_ctx *ctx, int local_rc, const char *where) {
+    const int W = ctx->n_ranks;
+    if (W == 1 || !ctx->comm) return local_rc;
+    const std::string own = ctx->err;  // the allgather below may overwrite the message
+    uint64_t mine = (uint64_t)(uint32_t)local_rc;
+    std::vector<uint64_t> all(W);
+    const int rc = comm_allgather_u64(ctx, &mine, 1, all.data());
+    if (rc != CRGPU_OK) return rc;  // the transport itself failed: every rank sees that
+    if (local_rc != CRGPU_OK) {
+        ctx->err = own;
+        return local_rc;
+    }
+    for (int r = 0; r < W; r++)
+        if ((int32_t)(uint32_t)all[r] != CRGPU_OK)
+            return cr_fail(ctx, CRGPU_ECOMM, "%s: rank %d failed (error %d); the collective was abandoned on every rank", where, r,
+                           (int)(int32_t)(uint32_t)all[r]);
+    return CRGPU_OK;
+}
+// The W x W matrix of send counts (all[p * W + r] = what p sends to r) together with every rank's status.  On return all
+// ranks agree: CRGPU_OK, the local error of a failing rank (CRGPU_ECOMM on the others), or CRGPU_ERANGE on every rank when
+// some rank would receive more than max_recv elements.
+int cr_comm_exchange_counts(crgpu_ctx *ctx, int local_rc, const uint64_t *send_cnt, uint64_t *all, uint64_t max_recv, const char *where) {
+    const int W = ctx->n_ranks;
+    const std::string own = ctx->err;
+    std::vector<uint64_t> mine(W + 1), got((size_t)W * (W + 1));
+    for (int p = 0; p < W; p++) mine[p] = local_rc == CRGPU_OK ? send_cnt[p] : 0;
+    mine[W] = (uint64_t)(uint32_t)local_rc;
+    const int rc = comm_allgather_u64(ctx, mine.data(), (uint32_t)(W + 1), got.data());
+    if (rc != CRGPU_OK) return rc;
+    if (local_rc != CRGPU_OK) {
+        ctx->err = own;
+        return local_rc;
+    }
+    for (int r = 0; r < W; r++) {
+        const int32_t st = (int32_t)(uint32_t)got[(size_t)r * (W + 1) + W];
+        if (st != CRGPU_OK)
+            return cr_fail(ctx, CRGPU_ECOMM, "%s: rank %d failed (error %d); the collective was abandoned on every rank", where, r, (int)st);
+        for (int p = 0; p < W; p++) all[(size_t)r * W + p] = got[(size_t)r * (W + 1) + p];
+    }
+    for (int r = 0; r < W; r++) {  // every rank holds the whole matrix: the limit is checked for all of them, by all of them
+        uint64_t n_recv = 0;
+        for (int p = 0; p < W; p++) n_recv += all[(size_t)p * W + r];
+        if (n_recv > max_recv)
+            return cr_fail(ctx, CRGPU_ERANGE, "%s: rank %d would own %llu keys (> %llu per call); split the well over more ranks", where, r,
+                           (unsigned long long)n_recv, (unsigned long long)max_recv);
+    }
+    return CRGPU_OK;
+}
+// test hook: CRGPU_TEST_FAIL_EXCHANGE_RANK=<r> makes rank r's preparation of the key exchange fail
+int cr_comm_test_failure(crgpu_ctx *ctx) {
+    const char *e = getenv("CRGPU_TEST_FAIL_EXCHANGE_RANK");
+    if (e && ctx->n_ranks > 1 && atoi(e) == ctx->rank)
+        return cr_fail(ctx, CRGPU_ENOMEM, "forced failure of rank %d in front of the key exchange (CRGPU_TEST_FAIL_EXCHANGE_RANK)", ctx->rank);
+    return CRGPU_OK;
+}
+
 int cr_comm_allgather_u64(crgpu_ctx *ctx, const uint64_t *mine, uint32_t k, uint64_t *all_out) {
     return comm_allgather_u64(ctx, mine, k, all_out);
 }
@@ -369,6 +457,7 @@ extern "C" int crgpu_allreduce_counts(crgpu_ctx *ctx, int lib, int which) {
         if ((lib >= 0 && l != lib) || !ctx->wl[l].set) continue;
         uint32_t *tab = which == CRGPU_COUNTS_VALID ? ctx->wl[l].d_valid : ctx->wl[l].d_corrected;
         CR_TRY(comm_allreduce_u32(ctx, tab, ctx->n_canon));
+        ctx->comm_bytes[0] += (uint64_t)ctx->n_canon * sizeof(uint32_t);
     }
     return CRGPU_OK;
 }
@@ -384,16 +473,19 @@ extern "C" int crgpu_exchange_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, u
     cr_invalidate(ctx);
     CR_TRY(cr_dense_ensure(ctx));
     const int W = ctx->n_ranks;
+    // local preparation: nothing here returns early (cr_comm_exchange_counts carries the status to every rank)
     std::vector<uint32_t> bounds(W + 1);
-    CR_TRY(crgpu_balanced_bounds(ctx, (uint32_t)W, bounds.data()));
-    if (bounds_out) memcpy(bounds_out, bounds.data(), (W + 1) * sizeof(uint32_t));
+    int rc = crgpu_balanced_bounds(ctx, (uint32_t)W, bounds.data());
+    if (rc == CRGPU_OK && bounds_out) memcpy(bounds_out, bounds.data(), (W + 1) * sizeof(uint32_t));
     // stable partition of my keys by owner
     uint64_t *d_part = nullptr;
-    CR_TRY(cr_pool_alloc(ctx, (void **)&d_part, (n_keys ? n_keys : 1) * sizeof(uint64_t)));
+    if (rc == CRGPU_OK) rc = cr_pool_alloc(ctx, (void **)&d_part, (n_keys ? n_keys : 1) * sizeof(uint64_t));
     std::vector<uint64_t> send_cnt(W, 0), all(W * (size_t)W, 0);
-    int rc = cr_partition_by_owner(ctx, d_keys, d_part, n_keys, ctx->layout.sh_bc(), (uint32_t)W, bounds.data(), send_cnt.data());
+    if (rc == CRGPU_OK) rc = cr_comm_test_failure(ctx);
+    if (rc == CRGPU_OK)
+        rc = cr_partition_by_owner(ctx, d_keys, d_part, n_keys, ctx->layout.sh_bc(), (uint32_t)W, bounds.data(), send_cnt.data());
     CrTimer t(ctx, CRGPU_T_COMM, n_keys);
-    if (rc == CRGPU_OK) rc = comm_allgather_u64(ctx, send_cnt.data(), (uint32_t)W, all.data());
+    rc = cr_comm_exchange_counts(ctx, rc, send_cnt.data(), all.data(), 0x7FFFFFFFull, "crgpu_exchange_keys");
     uint64_t *d_recv = nullptr;
     uint64_t n_recv = 0;
     std::vector<uint64_t> soff(W), sbytes(W), roff(W), rbytes(W);
@@ -408,11 +500,9 @@ extern "C" int crgpu_exchange_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, u
             rbytes[p] = from_p * sizeof(uint64_t);
             n_recv += from_p;
         }
-        if (n_recv > 0x7FFFFFFFull)
-            rc = cr_fail(ctx, CRGPU_ERANGE, "crgpu_exchange_keys: this rank would own %llu keys (> 2^31-1 per call)",
-                         (unsigned long long)n_recv);
+        // the receive buffer is a local allocation: agree on it before anybody posts a transfer
+        rc = cr_comm_agree(ctx, cr_pool_alloc(ctx, (void **)&d_recv, (n_recv ? n_recv : 1) * sizeof(uint64_t)), "crgpu_exchange_keys");
     }
-    if (rc == CRGPU_OK) rc = cr_pool_alloc(ctx, (void **)&d_recv, (n_recv ? n_recv : 1) * sizeof(uint64_t));
     if (rc == CRGPU_OK) rc = comm_alltoallv(ctx, d_part, soff.data(), sbytes.data(), d_recv, roff.data(), rbytes.data());
     if (rc == CRGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "crgpu_exchange_keys: sync failed");
     cr_pool_free(ctx, d_part);
@@ -420,6 +510,7 @@ extern "C" int crgpu_exchange_keys_dev(crgpu_ctx *ctx, const uint64_t *d_keys, u
         cr_pool_free(ctx, d_recv);
         return rc;
     }
+    ctx->comm_bytes[1] += (uint64_t)n_keys * sizeof(uint64_t);
     *d_recv_out = d_recv;
     *n_recv_out = n_recv;
     return CRGPU_OK;
@@ -458,30 +549,95 @@ extern "C" int crgpu_gatherv_dev(crgpu_ctx *ctx, const void *d_src, uint64_t byt
     return CRGPU_OK;
 }
 
+// C3 in one exchange: ONE all-gather of the triplet counts, then the three arrays of every rank travel to root inside one
+// grouped send / receive (3 (n - 1) point-to-point transfers in flight on root's links at once) and one stream
+// synchronisation -- instead of three gathers with an all-gather and a synchronisation each.
 extern "C" int crgpu_gather_triplets_dev(crgpu_ctx *ctx, const crgpu_counts *c, int root, uint32_t **d_bc_out,
                                          uint32_t **d_feature_out, uint32_t **d_count_out, uint64_t *n_total_out) {
     if (!ctx || !c || !d_bc_out || !d_feature_out || !d_count_out || !n_total_out) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     *d_bc_out = *d_feature_out = *d_count_out = nullptr;
     *n_total_out = 0;
+    const int W = ctx->n_ranks;
+    CR_REQUIRE(ctx, root >= 0 && root < W, CRGPU_EINVAL, "crgpu_gather_triplets: root %d of %d ranks", root, W);
     uint64_t nt = 0;
     uint32_t *src[3] = {nullptr, nullptr, nullptr};
-    CR_TRY(crgpu_counts_info(ctx, c, &nt, nullptr));
-    CR_TRY(crgpu_counts_triplets_dev(ctx, c, &src[0], &src[1], &src[2]));
-    void *out[3] = {nullptr, nullptr, nullptr};
-    std::vector<uint64_t> per(ctx->n_ranks, 0);
-    for (int a = 0; a < 3; a++) {
-        const int rc = crgpu_gatherv_dev(ctx, src[a], nt * sizeof(uint32_t), root, &out[a], per.data());
+    int rc = crgpu_counts_info(ctx, c, &nt, nullptr);
+    if (rc == CRGPU_OK) rc = crgpu_counts_triplets_dev(ctx, c, &src[0], &src[1], &src[2]);
+    cr_invalidate(ctx);
+    CrTimer t(ctx, CRGPU_T_COMM, nt);
+    std::vector<uint64_t> all(W, 0);
+    {   // counts + status of every rank
+        std::vector<uint64_t> mine = {nt, (uint64_t)(uint32_t)rc}, got((size_t)W * 2);
+        const std::string own = ctx->err;
+        const int rc2 = comm_allgather_u64(ctx, mine.data(), 2, got.data());
+        if (rc2 != CRGPU_OK) return rc2;
         if (rc != CRGPU_OK) {
-            for (int b = 0; b < a; b++) cr_pool_free(ctx, out[b]);
+            ctx->err = own;
             return rc;
         }
+        for (int r = 0; r < W; r++) {
+            if ((int32_t)(uint32_t)got[2 * r + 1] != CRGPU_OK)
+                return cr_fail(ctx, CRGPU_ECOMM, "crgpu_gather_triplets: rank %d failed (error %d); abandoned on every rank", r,
+                               (int)(int32_t)(uint32_t)got[2 * r + 1]);
+            all[r] = got[2 * r];
+        }
     }
-    if (ctx->rank == root) {
-        uint64_t total = 0;
-        for (int p = 0; p < ctx->n_ranks; p++) total += per[p] / sizeof(uint32_t);
-        *n_total_out = total;
+    uint64_t total = 0;
+    for (int p = 0; p < W; p++) total += all[p];
+    void *out[3] = {nullptr, nullptr, nullptr};
+    rc = CRGPU_OK;
+    if (ctx->rank == root)
+        for (int a = 0; a < 3 && rc == CRGPU_OK; a++) rc = cr_pool_alloc(ctx, &out[a], (total ? total : 1) * sizeof(uint32_t));
+    rc = cr_comm_agree(ctx, rc, "crgpu_gather_triplets");
+    CrComm *cm = ctx->comm;
+    if (rc == CRGPU_OK) {
+        if (!cm || W == 1) {
+            for (int a = 0; a < 3 && nt; a++)
+                if (hipMemcpyAsync(out[a], src[a], nt * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                    rc = cr_fail(ctx, CRGPU_EHIP, "crgpu_gather_triplets: copy failed");
+        } else if (cm->nccl) {
+            ncclResult_t r = ncclGroupStart();
+            for (int a = 0; a < 3 && r == ncclSuccess; a++) {
+                if (nt) r = ncclSend(src[a], nt * sizeof(uint32_t), ncclInt8, root, cm->nccl, ctx->stream);
+                if (ctx->rank == root) {
+                    uint64_t off = 0;
+                    for (int p = 0; p < W && r == ncclSuccess; p++) {
+                        if (all[p]) r = ncclRecv((char *)out[a] + off * sizeof(uint32_t), all[p] * sizeof(uint32_t), ncclInt8, p, cm->nccl, ctx->stream);
+                        off += all[p];
+                    }
+                }
+            }
+            const ncclResult_t r2 = ncclGroupEnd();
+            if (r != ncclSuccess) rc = nccl_fail(ctx, r, "ncclSend/ncclRecv (triplets)");
+            else if (r2 != ncclSuccess) rc = nccl_fail(ctx, r2, "ncclGroupEnd (triplets)");
+        } else {
+            LocalGroup *g = cm->local;
+            hipError_t e = hipStreamSynchronize(ctx->stream);  // my triplets are final
+            g->nums[ctx->rank].assign({(uint64_t)(uintptr_t)src[0], (uint64_t)(uintptr_t)src[1], (uint64_t)(uintptr_t)src[2]});
+            bool ok = g->barrier();
+            if (ok && e == hipSuccess && ctx->rank == root) {
+                uint64_t off = 0;
+                for (int p = 0; p < W && e == hipSuccess; p++) {
+                    for (int a = 0; a < 3 && e == hipSuccess && all[p]; a++)
+                        e = hipMemcpyAsync((char *)out[a] + off * sizeof(uint32_t), (const void *)(uintptr_t)g->nums[p][a],
+                                           all[p] * sizeof(uint32_t), hipMemcpyDefault, ctx->stream);
+                    off += all[p];
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            }
+            ok = g->barrier() && ok;  // the senders may free their triplets
+            if (!ok) rc = cr_fail(ctx, CRGPU_ECOMM, "local group: a rank went away");
+            else if (e != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "crgpu_gather_triplets: %s", hipGetErrorString(e));
+        }
     }
+    if (rc == CRGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "crgpu_gather_triplets: sync failed");
+    if (rc != CRGPU_OK) {
+        for (int a = 0; a < 3; a++) cr_pool_free(ctx, out[a]);
+        return rc;
+    }
+    ctx->comm_bytes[2] += 3ull * nt * sizeof(uint32_t);
+    if (ctx->rank == root) *n_total_out = total;
     *d_bc_out = (uint32_t *)out[0];
     *d_feature_out = (uint32_t *)out[1];
     *d_count_out = (uint32_t *)out[2];

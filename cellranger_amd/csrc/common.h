@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <set>
 #include <string>
@@ -173,12 +174,13 @@ struct crgpu_ctx {
     unsigned long long *d_hot_image = nullptr;  // K1's hot-barcode table (HOT_SLOTS entries) + 256 u32 of scratch
     MissRecords rec;
     KeyHistograms ghist;
-    std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device
+    std::map<const void *, size_t> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device (to how much)
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
     uint64_t sort_refinished = 0;          // sorts whose finishing pass met a run too long for it and that were redone on all bits
     uint64_t k1_split_rounds = 0;          // table rounds of K1 whose histogram was split (table slots in LDS + staged cold hits)
     uint64_t feature_fast_launches = 0;    // crgpu_extract_features_dev calls that took k_extract_tethered_lds
     uint64_t feature_reads_requeued = 0;   // reads k_extract_features handed to the wide-map launch
+    uint64_t comm_bytes[3] = {0, 0, 0};    // bytes this rank put into C1 (table all-reduce), C2 (key exchange), C3 (triplet gather)
     uint64_t sort_fallbacks = 0;           // sorts whose look-back watchdog fired and that were finished by the classic passes
 
     double max_expected_errors = 1.7976931348623157e308;  // corrector.rs:104 (f64::MAX)
@@ -250,6 +252,10 @@ void cr_comm_destroy(crgpu_ctx *ctx);
 int cr_comm_init(crgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id);
 // comm.hip transports (host arrays of n_ranks entries; offsets / sizes in bytes)
 int cr_comm_allgather_u64(crgpu_ctx *ctx, const uint64_t *mine, uint32_t k, uint64_t *all_out);
+// failure-symmetric steps of a collective (comm.hip): all ranks return together, with the failing rank's error or CRGPU_ECOMM
+int cr_comm_agree(crgpu_ctx *ctx, int local_rc, const char *where);
+int cr_comm_exchange_counts(crgpu_ctx *ctx, int local_rc, const uint64_t *send_cnt, uint64_t *all, uint64_t max_recv, const char *where);
+int cr_comm_test_failure(crgpu_ctx *ctx);
 int cr_comm_alltoallv(crgpu_ctx *ctx, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes, void *d_recv,
                       const uint64_t *recv_off, const uint64_t *recv_bytes);
 int cr_partition_by_payload(crgpu_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, const uint32_t *d_vin, uint32_t *d_vout,
@@ -288,8 +294,11 @@ bool cr_sort_finish_experiment();  // CRGPU_SORT_FINISH=1: the 16-bit finishing 
 int cr_order_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel): the attribute is per device
 static inline void cr_allow_lds(crgpu_ctx *ctx, const void *kernel, size_t bytes) {
-    if (ctx->lds_attr_done.insert(kernel).second)
+    size_t &have = ctx->lds_attr_done[kernel];
+    if (bytes > have) {  // a later launch of the same kernel may need more than the first one did
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        have = bytes;
+    }
 }  // barcode.hip: forget (and release) the K1 -> K2 miss records
 
 // Caching device pool for the per-step temporaries and results of the count stage.  hipMalloc /

@@ -210,6 +210,11 @@ extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
         case CRGPU_STAT_K1_SPLIT_ROUNDS:
             *value_out = ctx->k1_split_rounds;
             return CRGPU_OK;
+        case CRGPU_STAT_COMM_BYTES_C1:
+        case CRGPU_STAT_COMM_BYTES_C2:
+        case CRGPU_STAT_COMM_BYTES_C3:
+            *value_out = ctx->comm_bytes[which - CRGPU_STAT_COMM_BYTES_C1];
+            return CRGPU_OK;
         case CRGPU_STAT_FEATURE_FAST_LAUNCHES:
             *value_out = ctx->feature_fast_launches;
             return CRGPU_OK;

@@ -167,7 +167,9 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                                                     unsigned long long *__restrict__ n_out, const SweepPlan plan,
                                                     uint32_t *__restrict__ ghist, unsigned long long *__restrict__ status,
                                                     uint32_t *__restrict__ ticket, const uint8_t *__restrict__ ulen,
-                                                    const uint32_t *__restrict__ dense_fwd, uint32_t *__restrict__ n_unknown) {
+                                                    const uint32_t *__restrict__ dense_fwd, uint32_t *__restrict__ n_unknown,
+                                                    uint32_t *__restrict__ lb_abort) {
+    // lb_abort: the watchdog word of the ORDERED look-back (block_utils.h)
     // dense_fwd (nullable): barcode rank -> column of the BarcodeIndex (CRGPU_OPT_DENSE_BARCODE_KEYS)
     // ulen (nullable, byte path LQW == 0 only): the UMI length of every read, umi_min_len .. umi_len
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
@@ -283,15 +285,18 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
               if (threadIdx.x == 0 && c > 0)
                   __hip_atomic_store(&status[c], BK_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               // every lower ticket is held by a workgroup that is running or done: the chain always moves on
-              const unsigned long long excl = wave_lookback(status, c);
+              const unsigned long long excl = wave_lookback(status, c, lb_abort);
               if (threadIdx.x == 0) {
-                  __hip_atomic_store(&status[c], BK_INC | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if (c + 1 == n_chunks) *n_out = excl + total;
+                  if (excl != WAVE_LOOKBACK_ABORTED) {
+                      __hip_atomic_store(&status[c], BK_INC | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      if (c + 1 == n_chunks) *n_out = excl + total;
+                  }
                   s_c = excl;
               }
           }
           __syncthreads();
           const unsigned long long base = s_c;
+          if (base == WAVE_LOOKBACK_ABORTED) break;  // uniform: the host reports the stall (lb_abort is set)
 #pragma unroll
           for (int j = 0; j < KEY_ITEMS; j++)
               if (mask & (1u << j)) {
@@ -469,11 +474,11 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
     CR_TRY(cr_dense_ensure(ctx));  // CRGPU_OPT_DENSE_BARCODE_KEYS: the BarcodeIndex of the tables as they stand (else nothing)
     const uint32_t *d_fwd = ctx->dense.valid ? ctx->dense.d_fwd : nullptr;
-    uint32_t *d_unknown = ctx->d_scalars + 60;
+    uint32_t *d_unknown = ctx->d_scalars + 60, *d_lb_abort = ctx->d_scalars + 61;
     {
         CrTimer t(ctx, CRGPU_T_KEYS, recs->n);
         CR_HIP(ctx, hipMemsetAsync(d_n, 0, sizeof(*d_n), ctx->stream));
-        CR_HIP(ctx, hipMemsetAsync(d_unknown, 0, sizeof(uint32_t), ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(d_unknown, 0, 2 * sizeof(uint32_t), ctx->stream));
         const KL kl = make_kl(ctx->layout);
         // keys only (no read ordinals): count the sort's digit histograms on the way (1024 workgroups keep the
         // flush at a few million atomics)
@@ -507,19 +512,19 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     if (d_vals_out && d_hist)                                                                                               \
         hipLaunchKernelGGL((k_build_keys<LQW, true, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown);                                          \
+                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown, d_lb_abort);                                          \
     else if (d_vals_out)                                                                                                    \
         hipLaunchKernelGGL((k_build_keys<LQW, false, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi, \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown);                                          \
+                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown, d_lb_abort);                                          \
     else if (d_hist)                                                                                                        \
         hipLaunchKernelGGL((k_build_keys<LQW, true>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,     \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown);                                          \
+                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown, d_lb_abort);                                          \
     else                                                                                                                    \
         hipLaunchKernelGGL((k_build_keys<LQW, false>), grid, dim3(256), 0, ctx->stream, kl, recs->d_bc_idx, recs->d_umi,    \
                            recs->d_umi_qualn, recs->d_feature, recs->d_flags, recs->n, d_keys_out, d_vals_out, d_n, plan, d_hist, \
-                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown)
+                           d_status, d_ticket, recs->d_umi_len, d_fwd, d_unknown, d_lb_abort)
         // four reads per lane with 16-byte loads where the layout allows it (see k_build_keys_v4); the 1 - 3 reads behind the
         // last multiple of four go through the scalar kernel, appended by the same counter
         const bool aligned16 = ((uintptr_t)recs->d_bc_idx | (uintptr_t)recs->d_umi | (uintptr_t)recs->d_feature |
@@ -547,11 +552,11 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
                 if (d_hist)
                     hipLaunchKernelGGL((k_build_keys<0, true>), dim3(1), dim3(256), 0, ctx->stream, kl, recs->d_bc_idx + n4, recs->d_umi + n4,
                                        recs->d_umi_qualn + n4 * recs->umi_len, recs->d_feature + n4, tail_flags, rest, d_keys_out,
-                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr, d_fwd, d_unknown);
+                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr, d_fwd, d_unknown, d_lb_abort);
                 else
                     hipLaunchKernelGGL((k_build_keys<0, false>), dim3(1), dim3(256), 0, ctx->stream, kl, recs->d_bc_idx + n4, recs->d_umi + n4,
                                        recs->d_umi_qualn + n4 * recs->umi_len, recs->d_feature + n4, tail_flags, rest, d_keys_out,
-                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr, d_fwd, d_unknown);
+                                       (uint32_t *)nullptr, d_n, plan, d_hist, d_status, d_ticket, (const uint8_t *)nullptr, d_fwd, d_unknown, d_lb_abort);
             }
         } else
         switch (recs->d_umi_len ? 0u : recs->umi_len) {  // per-read lengths: the byte path
@@ -571,6 +576,15 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     }
     unsigned long long h = 0;
     CR_TRY(crgpu_memcpy_d2h(ctx, &h, d_n, sizeof(h)));
+    if (d_vals_out) {
+        uint32_t stalled = 0;
+        CR_TRY(crgpu_memcpy_d2h(ctx, &stalled, d_lb_abort, sizeof(stalled)));
+        if (stalled) {
+            ctx->ghist.valid = false;
+            return cr_fail(ctx, CRGPU_EHIP, "crgpu_build_keys: the look-back of the order-preserving compaction stalled (watchdog); "
+                                            "nothing was hung, the keys of this call are incomplete");
+        }
+    }
     if (d_fwd) {
         uint32_t unknown = 0;
         CR_TRY(crgpu_memcpy_d2h(ctx, &unknown, d_unknown, sizeof(unknown)));
@@ -2316,19 +2330,24 @@ extern "C" int crgpu_count_records_sharded_dev(crgpu_ctx *ctx, const crgpu_recor
     const uint64_t n = recs->n;
     const int W = ctx->n_ranks;
     DevBuf keys_b, vals_b, pkeys_b, pvals_b, recv_b, rrec_b, brec_b, iota_b;
-    CR_TRY(dmalloc(ctx, keys_b, (n ? n : 1) * sizeof(uint64_t)));
-    CR_TRY(dmalloc(ctx, vals_b, (n ? n : 1) * sizeof(uint32_t)));
+    // Local steps only RECORD their status in front of a collective; the status travels with the count exchange and all ranks
+    // leave together (a rank that returned early would leave its peers waiting inside RCCL for ever: comm.hip)
     uint64_t n_keys = 0;
-    CR_TRY(build_keys_impl(ctx, recs, keys_b.as<uint64_t>(), vals_b.as<uint32_t>(), &n_keys));
-    // C2 with the ordinals kept at home
     std::vector<uint32_t> bounds(W + 1);
-    CR_TRY(crgpu_balanced_bounds(ctx, (uint32_t)W, bounds.data()));
-    CR_TRY(dmalloc(ctx, pkeys_b, (n_keys ? n_keys : 1) * sizeof(uint64_t)));
-    CR_TRY(dmalloc(ctx, pvals_b, (n_keys ? n_keys : 1) * sizeof(uint32_t)));
     std::vector<uint64_t> send_cnt(W, 0), all((size_t)W * W, 0);
-    CR_TRY(cr_partition_by_owner_kv(ctx, keys_b.as<uint64_t>(), pkeys_b.as<uint64_t>(), vals_b.as<uint32_t>(), pvals_b.as<uint32_t>(),
-                                    n_keys, ctx->layout.sh_bc(), (uint32_t)W, bounds.data(), send_cnt.data()));
-    CR_TRY(cr_comm_allgather_u64(ctx, send_cnt.data(), (uint32_t)W, all.data()));
+    auto prepare = [&]() -> int {
+        CR_TRY(dmalloc(ctx, keys_b, (n ? n : 1) * sizeof(uint64_t)));
+        CR_TRY(dmalloc(ctx, vals_b, (n ? n : 1) * sizeof(uint32_t)));
+        CR_TRY(build_keys_impl(ctx, recs, keys_b.as<uint64_t>(), vals_b.as<uint32_t>(), &n_keys));
+        // C2 with the ordinals kept at home
+        CR_TRY(crgpu_balanced_bounds(ctx, (uint32_t)W, bounds.data()));
+        CR_TRY(dmalloc(ctx, pkeys_b, (n_keys ? n_keys : 1) * sizeof(uint64_t)));
+        CR_TRY(dmalloc(ctx, pvals_b, (n_keys ? n_keys : 1) * sizeof(uint32_t)));
+        CR_TRY(cr_comm_test_failure(ctx));
+        return cr_partition_by_owner_kv(ctx, keys_b.as<uint64_t>(), pkeys_b.as<uint64_t>(), vals_b.as<uint32_t>(), pvals_b.as<uint32_t>(),
+                                        n_keys, ctx->layout.sh_bc(), (uint32_t)W, bounds.data(), send_cnt.data());
+    };
+    CR_TRY(cr_comm_exchange_counts(ctx, prepare(), send_cnt.data(), all.data(), 0x7FFFFFFFull, "crgpu_count_records_sharded"));
     std::vector<uint64_t> soff(W), sbytes(W), roff(W), rbytes(W);
     uint64_t n_recv = 0, so = 0;
     for (int p = 0; p < W; p++) {
@@ -2339,40 +2358,44 @@ extern "C" int crgpu_count_records_sharded_dev(crgpu_ctx *ctx, const crgpu_recor
         rbytes[p] = all[(size_t)p * W + ctx->rank];
         n_recv += rbytes[p];
     }
-    CR_REQUIRE(ctx, n_recv <= 0x7FFFFFFFull, CRGPU_ERANGE, "crgpu_count_records_sharded: this rank would own %llu keys (> 2^31-1)",
-               (unsigned long long)n_recv);
     auto scaled = [&](const std::vector<uint64_t> &v, uint64_t f) {
         std::vector<uint64_t> o(v.size());
         for (size_t i = 0; i < v.size(); i++) o[i] = v[i] * f;
         return o;
     };
-    CR_TRY(dmalloc(ctx, recv_b, (n_recv ? n_recv : 1) * sizeof(uint64_t)));
+    CR_TRY(cr_comm_agree(ctx, dmalloc(ctx, recv_b, (n_recv ? n_recv : 1) * sizeof(uint64_t)), "crgpu_count_records_sharded"));
     {
         CrTimer t(ctx, CRGPU_T_COMM, n_keys);
         CR_TRY(cr_comm_alltoallv(ctx, pkeys_b.p, scaled(soff, 8).data(), scaled(sbytes, 8).data(), recv_b.p, scaled(roff, 8).data(),
                                  scaled(rbytes, 8).data()));
         CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->comm_bytes[1] += n_keys * sizeof(uint64_t);
     }
     // dedup of the owned range; the records of the received keys come back packed, in receive order
-    CR_TRY(dmalloc(ctx, rrec_b, (n_recv ? n_recv : 1) * sizeof(DupRec)));
-    CR_TRY(dmalloc(ctx, iota_b, (n_recv ? n_recv : 1) * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_iota_u32, dim3(cr_grid(n_recv ? n_recv : 1, 256)), dim3(256), 0, ctx->stream, iota_b.as<uint32_t>(), n_recv);
-    PerRead pr;
-    pr.summary = true;
-    pr.n_reads = n_recv;
-    pr.d_vals = iota_b.as<uint32_t>();
-    pr.packed_out = rrec_b.as<DupRec>();
-    CR_TRY(count_keys_impl(ctx, recv_b.as<uint64_t>(), n_recv, out, pr));
-    // the records travel home along the reversed routes
-    CR_TRY(dmalloc(ctx, brec_b, (n_keys ? n_keys : 1) * sizeof(DupRec)));
+    auto dedup_owned = [&]() -> int {
+        CR_TRY(dmalloc(ctx, rrec_b, (n_recv ? n_recv : 1) * sizeof(DupRec)));
+        CR_TRY(dmalloc(ctx, iota_b, (n_recv ? n_recv : 1) * sizeof(uint32_t)));
+        hipLaunchKernelGGL(k_iota_u32, dim3(cr_grid(n_recv ? n_recv : 1, 256)), dim3(256), 0, ctx->stream, iota_b.as<uint32_t>(), n_recv);
+        PerRead pr;
+        pr.summary = true;
+        pr.n_reads = n_recv;
+        pr.d_vals = iota_b.as<uint32_t>();
+        pr.packed_out = rrec_b.as<DupRec>();
+        CR_TRY(count_keys_impl(ctx, recv_b.as<uint64_t>(), n_recv, out, pr));
+        // the records travel home along the reversed routes
+        return dmalloc(ctx, brec_b, (n_keys ? n_keys : 1) * sizeof(DupRec));
+    };
     {
-        CrTimer t(ctx, CRGPU_T_COMM, n_recv);
-        const uint64_t rs = sizeof(DupRec);
-        int rc = cr_comm_alltoallv(ctx, rrec_b.p, scaled(roff, rs).data(), scaled(rbytes, rs).data(), brec_b.p, scaled(soff, rs).data(),
+        int rc = cr_comm_agree(ctx, dedup_owned(), "crgpu_count_records_sharded");
+        if (rc == CRGPU_OK) {
+            CrTimer t(ctx, CRGPU_T_COMM, n_recv);
+            const uint64_t rs = sizeof(DupRec);
+            rc = cr_comm_alltoallv(ctx, rrec_b.p, scaled(roff, rs).data(), scaled(rbytes, rs).data(), brec_b.p, scaled(soff, rs).data(),
                                    scaled(sbytes, rs).data());
-        if (rc == CRGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "sync failed");
+            if (rc == CRGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "sync failed");
+        }
         if (rc != CRGPU_OK) {
-            crgpu_counts_free(ctx, *out);
+            if (*out) crgpu_counts_free(ctx, *out);
             *out = nullptr;
             return rc;
         }

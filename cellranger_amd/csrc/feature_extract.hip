@@ -317,6 +317,7 @@ struct FxtParams {
     uint32_t lanes_per_row;       // power of two >= win_dw, <= 64
     uint32_t pitch;               // LDS dwords per row (odd)
     uint32_t slot_mask;
+    uint32_t halves;              // 1: the sorted half-key tables of the features are staged in LDS (posterior by pigeonhole)
 };
 struct FxtPending {
     unsigned long long key;
@@ -342,10 +343,16 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
                                                                   uint32_t *__restrict__ n_ids_out, uint32_t *__restrict__ capture_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
     const uint32_t slots = P.slot_mask + 1u;
-    uint32_t *s_val = reinterpret_cast<uint32_t *>(s_key + slots);
-    uint32_t *s_rows = s_val + slots + (threadIdx.x >> 6) * (64u * P.pitch);
-    FxtPending *s_pend = reinterpret_cast<FxtPending *>(s_val + slots + (THREADS / 64u) * (64u * P.pitch) +
-                                                        ((slots + (THREADS / 64u) * 64u * P.pitch) & 1u));  // 8-byte aligned
+    // LDS: [hash keys u64 x slots][feature keys u64 x n_feat (halves)][hash values u32 x slots][half tables 4 x n_feat u32 (halves)]
+    //      [row windows][pending captures]
+    unsigned long long *s_fkey = s_key + slots;
+    const uint32_t nfh = P.halves ? P.n_feat : 0u;
+    uint32_t *s_val = reinterpret_cast<uint32_t *>(s_fkey + nfh);
+    uint32_t *s_ha_key = s_val + slots, *s_ha_f = s_ha_key + nfh, *s_hb_key = s_ha_f + nfh, *s_hb_f = s_hb_key + nfh;
+    uint32_t *s_rows_all = s_hb_f + nfh;
+    uint32_t *s_rows = s_rows_all + (threadIdx.x >> 6) * (64u * P.pitch);
+    const uint32_t words_before_pend = slots + 4u * nfh + (THREADS / 64u) * 64u * P.pitch;
+    FxtPending *s_pend = reinterpret_cast<FxtPending *>(s_val + words_before_pend + (words_before_pend & 1u));  // 8-byte aligned
     __shared__ uint32_t s_npend;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t L = P.L;
@@ -358,12 +365,27 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
         uint32_t t = fxt_hash(k, P.slot_mask);
         while (atomicCAS(&s_key[t], FXT_EMPTY, k) != FXT_EMPTY) t = (t + 1u) & P.slot_mask;
         s_val[t] = f;
+        if (P.halves) {
+            s_fkey[f] = k;
+            s_ha_key[f] = v.ha_key[f];
+            s_ha_f[f] = v.ha_f[f];
+            s_hb_key[f] = v.hb_key[f];
+            s_hb_f[f] = v.hb_f[f];
+        }
     }
     __syncthreads();
     const char *pre = v.chars + v.pat[0].pre_off, *suf = v.chars + v.pat[0].suf_off;
     const uint32_t need = P.pre_len + L + P.suf_len;
     const uint32_t tag = P.read << 30;
+    const uint32_t hb = L >> 1;  // bases of the last half (the split of the host's half-key tables)
+    const unsigned long long low_mask = hb ? (~0ull >> (64u - 2u * hb)) : 0ull;
 
+    // The 1-mismatch posterior of one capture (correct_feature_barcode, :34-117; one capture: every candidate feature enters
+    // the map once, so the map is a running sum and a first maximum in (position, A<C<G<T) order).
+    // halves: a feature one substitution away agrees with the capture on its whole first half or on its whole last half, so
+    // two searches in the sorted half-key tables (LDS) list every candidate -- instead of 3 L hash probes -- and the few
+    // candidates are then put into the reference's order.  More than FXT_MAXC candidates (dense feature families): the probes.
+    constexpr uint32_t FXT_MAXC = 8;
     auto drain = [&](uint32_t first, uint32_t count) {  // pending captures [first, first + count), count <= THREADS
         if (tid < count) {
             const FxtPending e = s_pend[first + tid];
@@ -371,21 +393,84 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
             const uint8_t *q = R.qual + i * R.stride + e.start;
             double sum = 0.0, mx = -1.0;
             int best = -1;
-            for (uint32_t pos = 0; pos < L; pos++) {
-                if (e.npos && e.npos != pos + 1u) continue;  // the other positions keep the N: no candidate there is a feature
-                const uint32_t sh = 2u * (L - 1u - pos);
-                const uint32_t orig = (uint32_t)(e.key >> sh) & 3u;
-                for (uint32_t b = 0; b < 4; b++) {
-                    if (!e.npos && b == orig) continue;
-                    const int f = fxt_find(s_key, s_val, P.slot_mask, (e.key & ~(3ull << sh)) | ((unsigned long long)b << sh));
-                    if (f < 0) continue;
-                    uint32_t qv = (uint8_t)(q[pos] - 33u);  // u8 arithmetic as in feature_extraction.rs:43
-                    qv = qv < 33u ? qv : 33u;
-                    const double like = v.dist[f] * pedit[qv];
-                    sum += like;
-                    if (like > mx) {
-                        mx = like;
-                        best = f;
+            bool done = false;
+            if (P.halves) {
+                uint32_t cf[FXT_MAXC], ck[FXT_MAXC];  // candidate feature, order key = position * 4 + base
+                uint32_t nc = 0;
+                bool overflow = false;
+                const uint32_t nsh = e.npos ? 2u * (L - e.npos) : 0u;                    // bit position of the N's pair
+                const unsigned long long nm = e.npos ? (1ull << nsh) : 0ull;
+                auto consider = [&](uint32_t f) {
+                    const unsigned long long d = e.key ^ s_fkey[f];
+                    const unsigned long long y = ((d | (d >> 1)) & 0x5555555555555555ull) | nm;
+                    if (__popcll(y) != 1) return;
+                    const uint32_t sh = (uint32_t)__ffsll((long long)y) - 1u;             // even: the pair that differs
+                    const uint32_t pos = L - 1u - (sh >> 1);
+                    const uint32_t b = (uint32_t)(s_fkey[f] >> sh) & 3u;
+                    if (nc < FXT_MAXC) {
+                        cf[nc] = f;
+                        ck[nc] = pos * 4u + b;
+                        nc++;
+                    } else {
+                        overflow = true;
+                    }
+                };
+                auto search = [&](const uint32_t *hk, const uint32_t *hf, uint32_t k32) {
+                    uint32_t lo = 0, hi = P.n_feat;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (hk[mid] < k32) lo = mid + 1; else hi = mid;
+                    }
+                    for (; lo < P.n_feat && hk[lo] == k32; lo++) consider(hf[lo]);
+                };
+                // the half that holds the N (if any) cannot be the one that agrees
+                if ((nm >> (2u * hb)) == 0ull) search(s_ha_key, s_ha_f, (uint32_t)(e.key >> (2u * hb)));
+                if ((nm & low_mask) == 0ull && hb) search(s_hb_key, s_hb_f, (uint32_t)(e.key & low_mask));
+                if (!overflow) {
+                    done = true;
+                    for (uint32_t a = 1; a < nc; a++) {  // insertion sort by (position, base): the reference's order
+                        const uint32_t kf = cf[a], kk = ck[a];
+                        uint32_t b = a;
+                        while (b > 0 && ck[b - 1] > kk) {
+                            cf[b] = cf[b - 1];
+                            ck[b] = ck[b - 1];
+                            b--;
+                        }
+                        cf[b] = kf;
+                        ck[b] = kk;
+                    }
+                    for (uint32_t a = 0; a < nc; a++) {
+                        uint32_t qv = (uint8_t)(q[ck[a] >> 2] - 33u);  // u8 arithmetic as in feature_extraction.rs:43
+                        qv = qv < 33u ? qv : 33u;
+                        const double like = v.dist[cf[a]] * pedit[qv];
+                        sum += like;
+                        if (like > mx) {
+                            mx = like;
+                            best = (int)cf[a];
+                        }
+                    }
+                }
+            }
+            if (!done) {
+                sum = 0.0;
+                mx = -1.0;
+                best = -1;
+                for (uint32_t pos = 0; pos < L; pos++) {
+                    if (e.npos && e.npos != pos + 1u) continue;  // the other positions keep the N: no candidate there is a feature
+                    const uint32_t sh = 2u * (L - 1u - pos);
+                    const uint32_t orig = (uint32_t)(e.key >> sh) & 3u;
+                    for (uint32_t b = 0; b < 4; b++) {
+                        if (!e.npos && b == orig) continue;
+                        const int f = fxt_find(s_key, s_val, P.slot_mask, (e.key & ~(3ull << sh)) | ((unsigned long long)b << sh));
+                        if (f < 0) continue;
+                        uint32_t qv = (uint8_t)(q[pos] - 33u);
+                        qv = qv < 33u ? qv : 33u;
+                        const double like = v.dist[f] * pedit[qv];
+                        sum += like;
+                        if (like > mx) {
+                            mx = like;
+                            best = f;
+                        }
                     }
                 }
             }
@@ -827,15 +912,17 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
             uint32_t slots = 64;
             while (slots < 2u * X.t_n_feat) slots <<= 1;  // load factor <= 0.5
             P.slot_mask = slots - 1u;
+            P.halves = X.has_dist && X.t_n_feat <= 1024u && X.t_L >= 2 && !getenv("CRGPU_FXT_PROBES");
+            const size_t half_bytes = P.halves ? (size_t)X.t_n_feat * 24 : 0;
             CrTimer t(ctx, CRGPU_T_FEATURE, n);
             if (X.t_n_feat <= 1024u) {
-                const size_t lds = (size_t)slots * 12 + (size_t)4 * 64 * P.pitch * 4 + 8 + 2 * 256 * sizeof(FxtPending);
-                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<256>, 160 * 1024);
+                const size_t lds = (size_t)slots * 12 + half_bytes + (size_t)4 * 64 * P.pitch * 4 + 8 + 2 * 256 * sizeof(FxtPending);
+                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<256>, lds);
                 hipLaunchKernelGGL(k_extract_tethered_lds<256>, dim3(cr_grid(n, 256, 256u * 4u)), dim3(256), lds, ctx->stream, v, P,
                                    d_pe, R, n, d_feature_out, d_n_ids_out, d_capture_out);
             } else {
                 const size_t lds = (size_t)slots * 12 + (size_t)16 * 64 * P.pitch * 4 + 8 + 2 * 1024 * sizeof(FxtPending);
-                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<1024>, 160 * 1024);
+                cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<1024>, lds);
                 hipLaunchKernelGGL(k_extract_tethered_lds<1024>, dim3(cr_grid(n, 1024, 256u)), dim3(1024), lds, ctx->stream, v, P, d_pe,
                                    R, n, d_feature_out, d_n_ids_out, d_capture_out);
             }

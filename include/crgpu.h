@@ -120,6 +120,9 @@ int crgpu_invalidate(crgpu_ctx *ctx);
 #define CRGPU_STAT_K1_SPLIT_ROUNDS 3 /* table rounds of pass A whose histogram was split: table hits counted per slot in LDS, the other hits staged */
 #define CRGPU_STAT_FEATURE_READS_REQUEUED 2 /* reads of crgpu_extract_features_dev redone with the wide correction map */
 #define CRGPU_STAT_FEATURE_FAST_LAUNCHES 4 /* crgpu_extract_features_dev calls served by the one-tethered-pattern LDS kernel */
+#define CRGPU_STAT_COMM_BYTES_C1 5  /* bytes this rank contributed to the table all-reduces (C1) */
+#define CRGPU_STAT_COMM_BYTES_C2 6  /* bytes of molecule keys this rank put into key exchanges (C2; its own share included) */
+#define CRGPU_STAT_COMM_BYTES_C3 7  /* bytes of triplets this rank sent to the root of gathers (C3) */
 #define CRGPU_STAT_SORT_REFINISHED 1 /* sorts redone on all key bits because a run of equal top bits was too long for the finishing pass */
 int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out);
 /* ctx may be NULL: returns the message of the last failed crgpu_create on this thread. */

@@ -134,7 +134,7 @@ def test_radix_sort_matches_numpy():
 
     from cellranger_amd import synth as S
 
-    c = G.fresh_ctx()
+    c = G.fresh_ctx(dense=False)   # hand-made keys in the whitelist-rank layout
     w = S.Workload(n_total=1000, seed=1, n_wl=1000, n_cells=10, n_ambient=10)
     c.set_whitelist(0, w.wl_packed, length=16)
     c.set_key_layout(1000, 12, 1, 0)
@@ -353,7 +353,7 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, mo
     n = 260_000
     w = S.Workload(n_total=n, seed=31, n_wl=2000, n_cells=40, n_ambient=200, n_genes=40, umi_len=12, umi_err=0.0, cb_err=0.01,
                    n_rate=0.001, no_feature_frac=0.05, reads_per_umi=1)
-    c = G.fresh_ctx()
+    c = G.fresh_ctx(dense=False)   # the run lengths this test plants belong to the 42-bit whitelist-rank layout
     c.set_whitelist(0, w.wl_packed, length=16)
     r = w.host_reads(0, n)
     rng = np.random.default_rng(31)
@@ -489,7 +489,7 @@ def test_finishing_pass_hands_long_runs_back_to_the_full_sort(monkeypatch):
     rng = np.random.default_rng(5)
     n = 60_000
     wl = ["ACGTACGTACGTACGT", "TTTTACGTACGTACGA", "GGGGACGTACGTACCC"]
-    c = G.fresh_ctx()
+    c = G.fresh_ctx(dense=False)   # records without a barcode stage: no tables to take a BarcodeIndex from
     c.set_whitelist_ascii(0, wl)
     c.set_key_layout(40_000, 12, 1, 0)   # 2 + 16 + 24 + 1 = 43 bits: three passes + 16 low bits
     # every UMI = 4 fixed leading bases + 8 random ones: 65 536 possible keys share the top bits of one run

@@ -1,6 +1,8 @@
 """GPU tests of the call sequence with the product backend (HipBackend -> libcrgpu): the plain single-GPU path, the
 collective path (C1/C2/C3 = comm.hip) on a 1-rank RCCL communicator, and on 3 and 4 thread-ranks joined by the in-process
 group (the same orchestration code the 8-GPU RCCL run uses; only the transport differs)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -300,3 +302,75 @@ def test_sharded_well_returns_every_reads_dupinfo_to_its_rank():
     assert np.array_equal(indptr, res.indptr) and np.array_equal(indices, res.indices) and np.array_equal(data, res.data)
     for o in outs:
         o[0].close()
+
+
+@pytest.mark.parametrize("dupinfo", [False, True])
+def test_a_rank_that_fails_in_front_of_the_key_exchange_fails_everywhere(dupinfo, monkeypatch):
+    """collectives must be failure-symmetric.  Rank 1's preparation of the key exchange is made to fail
+    (CRGPU_TEST_FAIL_EXCHANGE_RANK): it still takes part in the count exchange, which carries its status, so rank 1 returns
+    its own error (CRGPU_ENOMEM) and ranks 0 and 2 return CRGPU_ECOMM naming it -- nobody enters the data exchange and waits
+    there for ever (RCCL has no timeout).  Afterwards the same contexts run the whole pipeline successfully: the failure left
+    the group usable.  Both exchanges: crgpu_exchange_keys_dev and crgpu_count_records_sharded_dev."""
+    import threading
+
+    import gpu_helpers as G
+    from cellranger_amd import engine as E
+    from cellranger_amd import synth as S
+    from cellranger_amd._lib import CrgpuError
+    from cellranger_amd.pipeline import CountPipeline, HipBackend
+
+    world, per = 3, 60_000
+    n = world * per
+    w = S.Workload(n_total=n, seed=47, n_wl=30_000, n_cells=100, n_ambient=3000, n_genes=300)
+    r_all = w.host_reads(0, n)
+    gid = E.local_group_id(world)
+    codes, results, errors = [None] * world, [None] * world, []
+    gate = threading.Barrier(world)
+
+    def worker(rank):
+        c = None
+        try:
+            c = E.Context(0, n_ranks=world, rank=rank, unique_id=gid)
+            c.set_whitelist(0, w.wl_packed, length=16)
+            c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+            r = {k: v[rank * per:(rank + 1) * per] for k, v in r_all.items()}
+            shard = _make_shard(c, w, r, per)
+            be = HipBackend(c, 0)
+            pipe = CountPipeline(be)
+            dup = (c.empty(per, np.uint32), c.empty(per, np.uint32), c.empty(per, np.uint8)) if dupinfo else None
+            gate.wait()
+            if rank == 0:
+                os.environ["CRGPU_TEST_FAIL_EXCHANGE_RANK"] = "1"
+            gate.wait()
+            try:
+                be.reset()
+                pipe.run(shard, dupinfo=dup)
+                codes[rank] = 0
+            except CrgpuError as e:
+                codes[rank] = (e.code, str(e))
+            gate.wait()
+            if rank == 0:
+                del os.environ["CRGPU_TEST_FAIL_EXCHANGE_RANK"]
+            gate.wait()
+            be.reset()
+            m = pipe.run(shard, dupinfo=dup)     # the group still works
+            results[rank] = (c, m)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            gate.abort()
+            if c is not None:
+                c.close()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a rank is still waiting in a collective"
+    assert not errors, errors
+    assert codes[1][0] == -4 and "forced failure" in codes[1][1], codes          # its own error
+    assert codes[0][0] == -7 and codes[2][0] == -7 and "rank 1 failed" in codes[0][1], codes   # CRGPU_ECOMM on the others
+    c0, m0 = results[0]
+    _check_against_oracle(c0, w, r_all, m0)
+    for c, _ in results:
+        c.close()
