@@ -71,6 +71,8 @@ struct FeatureExtractorSet {
     bool one_tethered = false;
     uint32_t t_read = 0, t_anchor5 = 0, t_anchor3 = 0, t_pre_len = 0, t_suf_len = 0, t_L = 0, t_n_feat = 0;
     bool t_pre_dots = false, t_suf_dots = false;  // prefix / suffix are wildcards only
+    // up to four leading literal characters of the suffix (else of the prefix): a floating pattern is first looked for by them
+    uint32_t t_needle = 0, t_needle_len = 0, t_needle_off = 0;
 };
 
 struct TimedSpan {

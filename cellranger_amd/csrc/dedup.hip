@@ -1316,18 +1316,34 @@ __device__ __forceinline__ uint64_t mix64(uint64_t g) {
 }
 #define LF_THREADS 1024u  // a workgroup may own one giant barcode: many threads + batched loads keep that pole short
 #define LF_BATCH 4
+// EMIT (the default since round 3): instead of a flag per key -- which a count + write compaction then turned into the list of
+// (hash, index) pairs with two more reads of the flags and one of the keys -- the second pass writes the pairs of its
+// candidates itself: a workgroup counts them, reserves its stretch of the list with ONE atomic per tile and appends.  The
+// list is sorted by hash afterwards, so the order of the tiles in it does not matter.
+#define LS_HASH_BITS 32u
+struct CandEmit {
+    uint32_t *hash, *val;       // the list (room for every key)
+    unsigned long long *n_out;  // its length (device counter, zeroed by the host)
+    uint32_t vbits;
+};
+template <bool EMIT>
 __global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
-                                                                 uint8_t *__restrict__ cand) {
+                                                                 uint8_t *__restrict__ cand, const CandEmit em) {
     __shared__ uint32_t bm[LF_WORDS];
     __shared__ uint32_t s_first;
     __shared__ unsigned long long s_end;
+    __shared__ uint32_t s_cnt;                 // EMIT: candidates of the tile so far
+    __shared__ unsigned long long s_base;      // EMIT: the tile's stretch of the list
     const uint32_t tid = threadIdx.x;
     const uint64_t n_tiles = (nd + LF_TILE - 1) / LF_TILE;
     const uint32_t emask = (1u << LF_ENTRY_BITS) - 1u;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t t0 = tile * LF_TILE;
         const uint64_t t1 = t0 + LF_TILE < nd ? t0 + LF_TILE : nd;
-        if (tid == 0) s_first = 0xFFFFFFFFu;
+        if (tid == 0) {
+            s_first = 0xFFFFFFFFu;
+            s_cnt = 0u;
+        }
         for (uint32_t w = tid; w < LF_WORDS; w += LF_THREADS) bm[w] = 0u;
         __syncthreads();
         // first barcode head of the tile
@@ -1382,19 +1398,64 @@ __global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, co
             }
         }
         __syncthreads();
-        for (uint64_t k0 = a + tid; k0 < b; k0 += (uint64_t)LF_THREADS * LF_BATCH) {
-            uint64_t key[LF_BATCH];
+        if (!EMIT) {
+            for (uint64_t k0 = a + tid; k0 < b; k0 += (uint64_t)LF_THREADS * LF_BATCH) {
+                uint64_t key[LF_BATCH];
 #pragma unroll
-            for (int j = 0; j < LF_BATCH; j++) {
-                const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
-                key[j] = k < b ? ukey[k] : 0ull;
+                for (int j = 0; j < LF_BATCH; j++) {
+                    const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
+                    key[j] = k < b ? ukey[k] : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < LF_BATCH; j++) {
+                    const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
+                    if (k >= b) break;
+                    const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
+                    cand[k] = (uint8_t)((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u);
+                }
             }
+        } else {
+            // rounds of LF_THREADS * LF_BATCH keys: count the round's candidates (wave ballots + one LDS atomic per wave), reserve
+            // the round's stretch of the list with one global atomic, append.  Every thread takes part in every round's barriers.
+            const uint64_t round_keys = (uint64_t)LF_THREADS * LF_BATCH;
+            const uint32_t lane = tid & 63u;
+            for (uint64_t r0 = a; r0 < b; r0 += round_keys) {
+                uint64_t key[LF_BATCH];
+                bool is_c[LF_BATCH];
+                uint32_t slot[LF_BATCH];
 #pragma unroll
-            for (int j = 0; j < LF_BATCH; j++) {
-                const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
-                if (k >= b) break;
-                const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
-                cand[k] = (uint8_t)((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u);
+                for (int j = 0; j < LF_BATCH; j++) {
+                    const uint64_t k = r0 + (uint64_t)j * LF_THREADS + tid;
+                    key[j] = k < b ? ukey[k] : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < LF_BATCH; j++) {
+                    const uint64_t k = r0 + (uint64_t)j * LF_THREADS + tid;
+                    const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
+                    is_c[j] = k < b && ((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u);
+                    const unsigned long long m = __ballot(is_c[j]);
+                    uint32_t wbase = 0;
+                    if (lane == 0 && m) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+                    wbase = __shfl(wbase, 0);
+                    slot[j] = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    s_base = s_cnt ? atomicAdd(em.n_out, (unsigned long long)s_cnt) : 0ull;
+                    s_cnt = 0u;
+                }
+                __syncthreads();
+                const unsigned long long base = s_base;
+#pragma unroll
+                for (int j = 0; j < LF_BATCH; j++)
+                    if (is_c[j]) {
+                        const uint64_t k = r0 + (uint64_t)j * LF_THREADS + tid;
+                        // the high half of the mix: independent of the low bits the filter consumed (as EmitHash)
+                        const uint64_t g = mix64(group_id(kl, key[j]) ^ 0x9E3779B97F4A7C15ull);
+                        em.hash[base + slot[j]] = LS_HASH_BITS >= 32u ? (uint32_t)g : ((uint32_t)g & ((1u << (LS_HASH_BITS & 31u)) - 1u));
+                        em.val[base + slot[j]] = (em.vbits >= 32u ? 0u : ((uint32_t)(g >> 32) << em.vbits)) | (uint32_t)k;
+                    }
+                __syncthreads();  // s_base is rewritten by the next round
             }
         }
         __syncthreads();
@@ -1409,7 +1470,6 @@ struct CandFlag {
 // k_low_support 0.6 ms slower on its longer runs).  val = (extra hash bits << vbits) | index: the bits of the u32 payload the
 // index does not need carry more hash bits, so that most false collisions of the sort key are rejected without touching
 // ukey; every comparison re-checks the exact (barcode, library, UMI) anyway.
-#define LS_HASH_BITS 32u
 struct EmitHash {  // emit of the candidate compaction: (hash, val) of candidate k straight from its key
     KL kl;
     const uint64_t *ukey;
@@ -1860,6 +1920,34 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
                                    ctx->stream));
     }
 
+    // 0. the per-key state of the UMI correction (section "per-key state") has to start out zeroed: 10 bytes per distinct key.
+    //    The number of distinct keys is not known yet, but it is at most n_keys: the arrays are sized by that and zeroed NOW on
+    //    the second stream, in the shadow of the sort (which is bound by the latency of its chunks, not by bandwidth) instead
+    //    of 0.8 ms on the critical path behind the run lengths.  CRGPU_NO_PREZERO=1: as before.
+    DevBuf corr_b, incall_b, st_b, minidx_b;
+    const bool prezero = ctx->stream2 && n_keys >= (1u << 20) && !getenv("CRGPU_NO_PREZERO");
+    const uint64_t st_cap = prezero ? n_keys : 0;
+    if (prezero) {
+        CR_TRY(dmalloc(ctx, minidx_b, st_cap * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, corr_b, st_cap * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, incall_b, st_cap * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, st_b, ((st_cap + 1) & ~1ull) * sizeof(uint16_t) + 4));
+        // the blocks may have been in use by work queued on the main stream: the second stream starts behind it
+        CR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        CR_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        CR_HIP(ctx, hipMemsetAsync(incall_b.p, 0, st_cap * sizeof(uint32_t), ctx->stream2));
+        CR_HIP(ctx, hipMemsetAsync(st_b.p, 0, ((st_cap + 1) & ~1ull) * sizeof(uint16_t) + 4, ctx->stream2));
+        CR_HIP(ctx, hipMemsetAsync(minidx_b.p, 0xFF, st_cap * sizeof(uint32_t), ctx->stream2));
+        CR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    }
+    struct PrezeroGuard {  // an error return in between must not leave the second stream writing into blocks the pool hands out again
+        crgpu_ctx *c;
+        bool armed;
+        ~PrezeroGuard() {
+            if (armed) (void)hipStreamSynchronize(c->stream2);
+        }
+    } prezero_guard{ctx, prezero};
+
     // 1. sort the keys: fully, or on their top bits with the finishing left to the run-length pass (CRGPU_SORT_FINISH)
     DevBuf tmp, vtmp;
     CR_TRY(dmalloc(ctx, tmp, n_keys * sizeof(uint64_t)));
@@ -1916,12 +2004,16 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     }
 
     // 3. UMI correction + the read moves (state layout: umi_correct.h)
-    DevBuf corr_b, incall_b, st_b, minidx_b;
     const uint64_t st_bytes = ((nd + 1) & ~1ull) * sizeof(uint16_t) + 4;
-    CR_TRY(dmalloc(ctx, minidx_b, nd * sizeof(uint32_t)));
-    CR_TRY(dmalloc(ctx, corr_b, nd * sizeof(uint32_t)));   // written (and valid) only where st says "corrected"
-    CR_TRY(dmalloc(ctx, incall_b, nd * sizeof(uint32_t)));
-    CR_TRY(dmalloc(ctx, st_b, st_bytes));
+    if (!prezero) {
+        CR_TRY(dmalloc(ctx, minidx_b, nd * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, corr_b, nd * sizeof(uint32_t)));   // written (and valid) only where st says "corrected"
+        CR_TRY(dmalloc(ctx, incall_b, nd * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, st_b, st_bytes));
+    } else {
+        CR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));  // the zeroing of step 0
+        prezero_guard.armed = false;
+    }
     uint32_t *corr = corr_b.as<uint32_t>(), *inc_all = incall_b.as<uint32_t>(), *minidx = minidx_b.as<uint32_t>();
     uint16_t *st = st_b.as<uint16_t>();
     // the candidate search of step 4 needs nothing of step 3: it runs beside it on the second stream (CrFork)
@@ -1945,9 +2037,11 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             ~TimingBack() { c->timing = v; }
         } timing_back{ctx, timing_was};
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        CR_HIP(ctx, hipMemsetAsync(inc_all, 0, nd * sizeof(uint32_t), ctx->stream));
-        CR_HIP(ctx, hipMemsetAsync(st, 0, st_bytes, ctx->stream));
-        CR_HIP(ctx, hipMemsetAsync(minidx, 0xFF, nd * sizeof(uint32_t), ctx->stream));
+        if (!prezero) {
+            CR_HIP(ctx, hipMemsetAsync(inc_all, 0, nd * sizeof(uint32_t), ctx->stream));
+            CR_HIP(ctx, hipMemsetAsync(st, 0, st_bytes, ctx->stream));
+            CR_HIP(ctx, hipMemsetAsync(minidx, 0xFF, nd * sizeof(uint32_t), ctx->stream));
+        }
         const uint64_t n_tiles = (nd + UC_TILE - 1) / UC_TILE;
         CR_TRY(dmalloc(ctx, heads_b, 2 * n_tiles * sizeof(uint32_t)));  // per tile: first / last segment head
         uint32_t *tile_first = heads_b.as<uint32_t>(), *tile_last = tile_first + n_tiles;
@@ -1990,21 +2084,35 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     //    (barcode, library, UMI) through a 32-bit hash sort -> exact comparison of the phase-1 counts
     {
         DevBuf cand_b, h_b, v_b;
-        CR_TRY(dmalloc(ctx, cand_b, nd));
+        if (getenv("CRGPU_CAND_FLAGS")) CR_TRY(dmalloc(ctx, cand_b, nd));
         CR_TRY(dmalloc(ctx, h_b, nd * sizeof(uint32_t)));   // room for every key; the candidates are ~1/5 of them
         CR_TRY(dmalloc(ctx, v_b, nd * sizeof(uint32_t)));
         const uint32_t vbits = cr_ceil_log2(nd ? nd : 1);  // bits the distinct-key index needs inside the payload
         uint32_t n_cand32 = 0;
         if (overlap) CR_TRY(fork.side(fork.t0));  // from here to join(): ctx->stream is the second stream
+        const bool cand_flags = getenv("CRGPU_CAND_FLAGS") != nullptr;  // A/B: round 2's flag array + count / write compaction
+        unsigned long long *d_ncand = (unsigned long long *)(ctx->d_scalars + 64);
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
             const uint64_t n_ftiles = (nd + LF_TILE - 1) / LF_TILE;
-            hipLaunchKernelGGL(k_group_candidates, dim3(cr_grid(n_ftiles, 1, 256u * 2u)), dim3(LF_THREADS), 0, ctx->stream, kl, ukey,
-                               nd, cand_b.as<uint8_t>());
-            CR_HIP(ctx, hipGetLastError());
-            CR_TRY(compact(ctx, CandFlag{cand_b.as<uint8_t>()}, EmitHash{kl, ukey, vbits, h_b.as<uint32_t>(), v_b.as<uint32_t>()}, nd,
-                           d_block, d_total));
+            if (cand_flags) {
+                hipLaunchKernelGGL(k_group_candidates<false>, dim3(cr_grid(n_ftiles, 1, 256u * 2u)), dim3(LF_THREADS), 0, ctx->stream, kl,
+                                   ukey, nd, cand_b.as<uint8_t>(), CandEmit{});
+                CR_HIP(ctx, hipGetLastError());
+                CR_TRY(compact(ctx, CandFlag{cand_b.as<uint8_t>()}, EmitHash{kl, ukey, vbits, h_b.as<uint32_t>(), v_b.as<uint32_t>()}, nd,
+                               d_block, d_total));
+            } else {
+                CR_HIP(ctx, hipMemsetAsync(d_ncand, 0, sizeof(unsigned long long), ctx->stream));
+                hipLaunchKernelGGL(k_group_candidates<true>, dim3(cr_grid(n_ftiles, 1, 256u * 2u)), dim3(LF_THREADS), 0, ctx->stream, kl,
+                                   ukey, nd, (uint8_t *)nullptr, CandEmit{h_b.as<uint32_t>(), v_b.as<uint32_t>(), d_ncand, vbits});
+                CR_HIP(ctx, hipGetLastError());
+            }
         }
+        if (!cand_flags) {
+            unsigned long long nc64 = 0;
+            CR_TRY(crgpu_memcpy_d2h(ctx, &nc64, d_ncand, sizeof(nc64)));
+            n_cand32 = (uint32_t)nc64;
+        } else
         CR_TRY(read_u32(ctx, d_total, &n_cand32));
         const uint64_t n_cand = n_cand32;
         if (n_cand >= 2) {

@@ -318,6 +318,7 @@ struct FxtParams {
     uint32_t pitch;               // LDS dwords per row (odd)
     uint32_t slot_mask;
     uint32_t halves;              // 1: the sorted half-key tables of the features are staged in LDS (posterior by pigeonhole)
+    uint32_t needle, needle_mask, needle_off;  // floating patterns: (bytes at start + needle_off) & mask == needle, or mask == 0
 };
 struct FxtPending {
     unsigned long long key;
@@ -513,8 +514,21 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
                     possible = s_lo == 0;
                     s_hi = 0;
                 }
+                uint32_t d_prev = 0xFFFFFFFFu, w_lo = 0, w_hi = 0;
                 if (possible)
                     for (uint32_t st = s_lo; st <= s_hi && found == FX_NO_CAPTURE; st++) {
+                        if (P.needle_mask) {
+                            // the first literal characters of the pattern as one masked 32-bit compare on a window that
+                            // slides over the row's dwords: most starts of a floating pattern end here
+                            const uint32_t p = st + P.needle_off - P.win_lo, d = p >> 2, sh = (p & 3u) * 8u;
+                            if (d != d_prev) {
+                                w_lo = row[d];
+                                w_hi = row[d + 1];  // may lie behind the window: the full comparison below decides
+                                d_prev = d;
+                            }
+                            const uint32_t w = sh ? (w_lo >> sh) | (w_hi << (32u - sh)) : w_lo;
+                            if ((w ^ P.needle) & P.needle_mask) continue;
+                        }
                         bool ok = true;
                         if (!P.pre_dots)
                             for (uint32_t k = 0; k < P.pre_len && ok; k++)
@@ -833,6 +847,16 @@ extern "C" int crgpu_set_feature_extractor(crgpu_ctx *ctx, int extractor, const 
         X.t_n_feat = (uint32_t)P0.feats.size();
         X.t_pre_dots = P0.prefix.find_first_not_of('.') == std::string::npos;
         X.t_suf_dots = P0.suffix.find_first_not_of('.') == std::string::npos;
+        const std::string &src = (!P0.suffix.empty() && P0.suffix[0] != '.') ? P0.suffix : P0.prefix;
+        if (!src.empty() && src[0] != '.') {
+            uint32_t len = 0;
+            while (len < 4 && len < src.size() && src[len] != '.') {
+                X.t_needle |= (uint32_t)(uint8_t)src[len] << (8 * len);
+                len++;
+            }
+            X.t_needle_len = len;
+            X.t_needle_off = (&src == &P0.suffix) ? (uint32_t)P0.prefix.size() + P0.L : 0u;
+        }
     }
     X.set = true;
     ctx->fx[extractor] = X;
@@ -912,6 +936,11 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
             uint32_t slots = 64;
             while (slots < 2u * X.t_n_feat) slots <<= 1;  // load factor <= 0.5
             P.slot_mask = slots - 1u;
+            if (X.t_needle_len && !X.t_anchor5 && !X.t_anchor3) {  // anchored patterns have one start: nothing to skip
+                P.needle = X.t_needle;
+                P.needle_mask = X.t_needle_len >= 4 ? 0xFFFFFFFFu : ((1u << (8u * X.t_needle_len)) - 1u);
+                P.needle_off = X.t_needle_off;
+            }
             P.halves = X.has_dist && X.t_n_feat <= 1024u && X.t_L >= 2 && !getenv("CRGPU_FXT_PROBES");
             const size_t half_bytes = P.halves ? (size_t)X.t_n_feat * 24 : 0;
             CrTimer t(ctx, CRGPU_T_FEATURE, n);
@@ -966,26 +995,47 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
 }
 
 // ---- the prior: MAKE_SHARD's exact-match feature counts and compute_feature_dist ------------------------------------------
+// Few distinct features (hundreds of antibodies) carry all the reads, wherever their indices lie in a feature reference of
+// tens of thousands of entries: a workgroup counts into an LDS hash table of (feature, count) pairs and flushes it once; a
+// feature that finds no slot (more than FC_SLOTS * 3 / 4 distinct ones in one workgroup) is counted in global memory directly.
+// (62.5 M global atomics on 200 addresses took 130 ms.)
+#define FC_SLOTS 4096u
+#define FC_EMPTY 0xFFFFFFFFu
 __global__ __launch_bounds__(256) void k_feature_counts(const uint32_t *__restrict__ feature, uint64_t n, uint32_t n_features,
                                                         unsigned long long *__restrict__ counts) {
-    // a few hundred features: per-workgroup LDS counters for tables that fit, global atomics beyond
-    extern __shared__ uint32_t s_cnt[];
-    const bool lds = n_features <= 8192u;
-    if (lds) {
-        for (uint32_t f = threadIdx.x; f < n_features; f += 256) s_cnt[f] = 0;
-        __syncthreads();
+    __shared__ uint32_t s_f[FC_SLOTS], s_c[FC_SLOTS];
+    __shared__ uint32_t s_used;
+    for (uint32_t t = threadIdx.x; t < FC_SLOTS; t += 256) {
+        s_f[t] = FC_EMPTY;
+        s_c[t] = 0;
     }
+    if (threadIdx.x == 0) s_used = 0;
+    __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t f = feature[i];
         if (f >= n_features) continue;
-        if (lds) atomicAdd(&s_cnt[f], 1u); else atomicAdd(&counts[f], 1ull);
+        uint32_t t = (f * 0x9E3779B1u) >> 20;  // 12 bits
+        bool placed = false;
+        for (uint32_t probe = 0; probe < 16 && !placed; probe++, t = (t + 1u) & (FC_SLOTS - 1u)) {
+            uint32_t cur = s_f[t];
+            if (cur == FC_EMPTY && s_used < FC_SLOTS * 3u / 4u) {
+                cur = atomicCAS(&s_f[t], FC_EMPTY, f);
+                if (cur == FC_EMPTY) {
+                    atomicAdd(&s_used, 1u);
+                    cur = f;
+                }
+            }
+            if (cur == f) {
+                atomicAdd(&s_c[t], 1u);
+                placed = true;
+            }
+        }
+        if (!placed) atomicAdd(&counts[f], 1ull);
     }
-    if (lds) {
-        __syncthreads();
-        for (uint32_t f = threadIdx.x; f < n_features; f += 256)
-            if (s_cnt[f]) atomicAdd(&counts[f], (unsigned long long)s_cnt[f]);
-    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < FC_SLOTS; t += 256)
+        if (s_f[t] != FC_EMPTY && s_c[t]) atomicAdd(&counts[s_f[t]], (unsigned long long)s_c[t]);
 }
 
 extern "C" int crgpu_feature_counts_dev(crgpu_ctx *ctx, const uint32_t *d_feature, uint64_t n, uint32_t n_features,
@@ -1004,8 +1054,7 @@ extern "C" int crgpu_feature_counts_dev(crgpu_ctx *ctx, const uint32_t *d_featur
     CR_HIP(ctx, hipMemsetAsync(d_c, 0, (size_t)n_features * 8, ctx->stream));
     {
         CrTimer t(ctx, CRGPU_T_FEATURE, n);
-        const size_t lds = n_features <= 8192u ? (size_t)n_features * 4 : 4;
-        hipLaunchKernelGGL(k_feature_counts, dim3(cr_grid(n, 256 * 8, 256u * 4u)), dim3(256), lds, ctx->stream, d_feature, n, n_features,
+        hipLaunchKernelGGL(k_feature_counts, dim3(cr_grid(n, 256 * 8, 256u * 4u)), dim3(256), 0, ctx->stream, d_feature, n, n_features,
                            (unsigned long long *)d_c);
         CR_HIP(ctx, hipGetLastError());
     }

@@ -663,7 +663,7 @@ static int onesweep_sort_u64(crgpu_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, 
     }
     uint64_t *in = d_keys, *out = d_tmp;
     uint32_t *vin = d_vals, *vout = d_vals_tmp;
-    static const bool st64_forced = getenv("CRGPU_SORT_STATUS64") != nullptr;  // A/B and test switch
+    const bool st64_forced = getenv("CRGPU_SORT_STATUS64") != nullptr;  // A/B and test switch, read per call like the others
     const bool st32 = n < (1ull << 30) && !st64_forced;
     for (uint32_t p = 0; p < plan.n_passes && e == hipSuccess; p++) {
         const bool wide = widths[p] == 9;

@@ -377,10 +377,13 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, mo
     c.close()
 
 
-def test_random_key_layouts_bit_exact():
+@pytest.mark.parametrize("status64", [False, True])
+def test_random_key_layouts_bit_exact(status64, monkeypatch):
     """Random whitelist sizes, feature counts, UMI lengths and library counts: key widths from 20 to 64 bits, i.e. every
     digit plan of the sort (all 8-bit, mixed 8/9-bit, a narrow last digit), the classic and the onesweep path, keys with
     and without library bits -- each compared with the oracle read by read."""
+    if status64:   # ADVICE r2: the 64-bit status words of sorts of >= 2^30 keys, forced for inputs of test size
+        monkeypatch.setenv("CRGPU_SORT_STATUS64", "1")
     import gpu_helpers as G
     from cellranger_amd import synth as S
     from cellranger_amd._lib import FLAG_NONTXOMIC
@@ -411,8 +414,9 @@ def test_random_key_layouts_bit_exact():
     assert len(seen_bits) >= 8 and max(seen_bits) >= 58 and min(seen_bits) <= 30
 
 
-@pytest.mark.parametrize("bad_pass,finish", [(0, "2"), (2, "2"), (4, "2"), (5, "0")])
-def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, finish, monkeypatch):
+@pytest.mark.parametrize("bad_pass,finish,status64", [(0, "2", False), (2, "2", False), (4, "2", False), (5, "0", False),
+                                                      (1, "2", True), (3, "0", True)])
+def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, finish, status64, monkeypatch):
     """The look-back chain of one onesweep pass is stalled on purpose (CRGPU_SORT_FORCE_ABORT: chunk 0 never publishes).
     The watchdog raises the abort word, that pass and the ones queued behind it write nothing, and the host finishes the
     sort from the failed pass on with the classic histogram / scan / scatter passes inside the same call: the call
@@ -422,6 +426,8 @@ def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, finish, mo
     from cellranger_amd import synth as S
 
     monkeypatch.setenv("CRGPU_SORT_FINISH", finish)
+    if status64:   # the 64-bit look-back status words every sort of >= 2^30 keys uses (no test input is that large)
+        monkeypatch.setenv("CRGPU_SORT_STATUS64", "1")
     n = 400_000
     w = S.Workload(n_total=n, seed=58, n_wl=60_000, n_cells=150, n_ambient=5000, n_genes=500)
     c = G.fresh_ctx()
