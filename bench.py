@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--fb-row-stride", type=int, default=92, help="cfg4: bytes per R2 row (90-base read + padding to a dword)")
     ap.add_argument("--fb-features", type=int, default=200)
+    ap.add_argument("--dense-keys", type=int, default=-1,
+                    help="CRGPU_OPT_DENSE_BARCODE_KEYS: 1 / 0; default: on for whitelists of more than 2^20 barcodes (the 3M list: "
+                         "23-bit ranks -> 18-bit BarcodeIndex columns, one radix pass fewer)")
     ap.add_argument("--no-default-options", action="store_true",
                     help="skip the short second timed loop with CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS off")
     ap.add_argument("--reads-per-gpu", type=int, default=0)
@@ -447,11 +450,16 @@ def main():
     ctx = E.Context(local_rank, n_ranks=world, rank=rank, unique_id=uid)
     # the bench writes its buffers only through the context: K2 may use K1's miss records, the sort the key histograms
     ctx.trust_unchanged_buffers(True)
+    dense_keys = (args.whitelist > (1 << 20)) if args.dense_keys < 0 else bool(args.dense_keys)
+    if dense_keys:
+        ctx.set_option(1, 1)   # before the key layout is set
     be = HipBackend(ctx, local_rank)
     dup_out = None
     cfg4 = None
+    key_layout_args = None
     if workload == "cfg4":
         cfg4 = Cfg4(ctx, args, n, world, rank, E, S, np)
+        key_layout_args = (cfg4.n_feat_all, 12, 2, 0)
         w = cfg4.w_fb
         n_reads_rank = cfg4.n_fb + cfg4.n_gex
         pipe = CountPipeline(be, libs=(0, 1))
@@ -473,7 +481,8 @@ def main():
             shard["feature"] = ctx.empty(n, np.uint32)
             if not args.dupinfo:
                 shard["keys"] = ctx.empty(n, np.uint64)
-            ctx.set_key_layout(w.n_genes, w.umi_len, 1, 0)
+            key_layout_args = (w.n_genes, w.umi_len, 1, 0)
+            ctx.set_key_layout(*key_layout_args)
         # this rank's slice of the job's read stream (cfg5: its own well), generated straight into HBM
         chunk = 1 << 27
         first0 = 0 if workload == "cfg5" else rank * n
@@ -545,11 +554,17 @@ def main():
     default_ms = None
     if not args.no_default_options:
         ctx.trust_unchanged_buffers(False)
+        if dense_keys and key_layout_args:
+            ctx.set_option(1, 0)
+            ctx.set_key_layout(*key_layout_args)
         step()
         dt_def, _, result, _ = timed(max(1, min(2, args.steps)))
         result = None
         default_ms = dt_def / max(1, min(2, args.steps)) * 1e3
         ctx.trust_unchanged_buffers(True)
+        if dense_keys and key_layout_args:
+            ctx.set_option(1, 1)
+            ctx.set_key_layout(*key_layout_args)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -617,7 +632,7 @@ def main():
             "config": {"workload": "%s: %s, %d-entry whitelist" % (workload, desc, args.whitelist),
                        "reads_per_gpu": n_reads_rank, "parallelism": par,
                        # a promise the host makes (off by default): K2 reuses K1's miss records, the sort the key histograms
-                       "options": {"CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS": 1}},
+                       "options": {"CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS": 1, "CRGPU_OPT_DENSE_BARCODE_KEYS": int(dense_keys)}},
             "default_options_ms_per_step": default_ms,
             "roofline": roof,
             "family_roofline_frac": fam_fracs,

@@ -1415,47 +1415,60 @@ __global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, co
                 }
             }
         } else {
-            // rounds of LF_THREADS * LF_BATCH keys: count the round's candidates (wave ballots + one LDS atomic per wave), reserve
-            // the round's stretch of the list with one global atomic, append.  Every thread takes part in every round's barriers.
-            const uint64_t round_keys = (uint64_t)LF_THREADS * LF_BATCH;
+            // count the range's candidates (a second read of its keys, out of L2), reserve the range's stretch of the list
+            // with ONE global atomic, then read the keys once more and append: slots inside the stretch come from an LDS
+            // counter that every wave bumps once per item slot (no barrier inside the passes)
             const uint32_t lane = tid & 63u;
-            for (uint64_t r0 = a; r0 < b; r0 += round_keys) {
+            uint32_t mine = 0;
+            for (uint64_t k0 = a + tid; k0 < b; k0 += (uint64_t)LF_THREADS * LF_BATCH) {
                 uint64_t key[LF_BATCH];
-                bool is_c[LF_BATCH];
-                uint32_t slot[LF_BATCH];
 #pragma unroll
                 for (int j = 0; j < LF_BATCH; j++) {
-                    const uint64_t k = r0 + (uint64_t)j * LF_THREADS + tid;
+                    const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
                     key[j] = k < b ? ukey[k] : 0ull;
                 }
 #pragma unroll
                 for (int j = 0; j < LF_BATCH; j++) {
-                    const uint64_t k = r0 + (uint64_t)j * LF_THREADS + tid;
+                    const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
                     const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
-                    is_c[j] = k < b && ((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u);
-                    const unsigned long long m = __ballot(is_c[j]);
-                    uint32_t wbase = 0;
-                    if (lane == 0 && m) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-                    wbase = __shfl(wbase, 0);
-                    slot[j] = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    mine += (k < b && ((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u)) ? 1u : 0u;
                 }
-                __syncthreads();
-                if (tid == 0) {
-                    s_base = s_cnt ? atomicAdd(em.n_out, (unsigned long long)s_cnt) : 0ull;
-                    s_cnt = 0u;
-                }
-                __syncthreads();
-                const unsigned long long base = s_base;
+            }
 #pragma unroll
-                for (int j = 0; j < LF_BATCH; j++)
-                    if (is_c[j]) {
-                        const uint64_t k = r0 + (uint64_t)j * LF_THREADS + tid;
+            for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+            if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+            __syncthreads();
+            if (tid == 0) {
+                s_base = s_cnt ? atomicAdd(em.n_out, (unsigned long long)s_cnt) : 0ull;
+                s_cnt = 0u;
+            }
+            __syncthreads();
+            const unsigned long long base = s_base;
+            for (uint64_t k0 = a + tid; k0 < b; k0 += (uint64_t)LF_THREADS * LF_BATCH) {
+                uint64_t key[LF_BATCH];
+#pragma unroll
+                for (int j = 0; j < LF_BATCH; j++) {
+                    const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
+                    key[j] = k < b ? ukey[k] : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < LF_BATCH; j++) {
+                    const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
+                    const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
+                    const bool is_c = k < b && ((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u);
+                    const unsigned long long m = __ballot(is_c);
+                    if (!m) continue;  // wave-uniform
+                    uint32_t wbase = 0;
+                    if (lane == (uint32_t)(__ffsll((long long)m) - 1)) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+                    wbase = __shfl(wbase, __ffsll((long long)m) - 1);
+                    if (is_c) {
+                        const unsigned long long o = base + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         // the high half of the mix: independent of the low bits the filter consumed (as EmitHash)
                         const uint64_t g = mix64(group_id(kl, key[j]) ^ 0x9E3779B97F4A7C15ull);
-                        em.hash[base + slot[j]] = LS_HASH_BITS >= 32u ? (uint32_t)g : ((uint32_t)g & ((1u << (LS_HASH_BITS & 31u)) - 1u));
-                        em.val[base + slot[j]] = (em.vbits >= 32u ? 0u : ((uint32_t)(g >> 32) << em.vbits)) | (uint32_t)k;
+                        em.hash[o] = LS_HASH_BITS >= 32u ? (uint32_t)g : ((uint32_t)g & ((1u << (LS_HASH_BITS & 31u)) - 1u));
+                        em.val[o] = (em.vbits >= 32u ? 0u : ((uint32_t)(g >> 32) << em.vbits)) | (uint32_t)k;
                     }
-                __syncthreads();  // s_base is rewritten by the next round
+                }
             }
         }
         __syncthreads();
@@ -1925,7 +1938,9 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     //    the second stream, in the shadow of the sort (which is bound by the latency of its chunks, not by bandwidth) instead
     //    of 0.8 ms on the critical path behind the run lengths.  CRGPU_NO_PREZERO=1: as before.
     DevBuf corr_b, incall_b, st_b, minidx_b;
-    const bool prezero = ctx->stream2 && n_keys >= (1u << 20) && !getenv("CRGPU_NO_PREZERO");
+    // (measured at 1 B records: the 8 GB of zeroing cost the sort passes more than the 0.8 ms they save -- sized by n_keys they
+    // are twice what the distinct keys need: OFF unless CRGPU_PREZERO=1, kept for the A/B record)
+    const bool prezero = ctx->stream2 && n_keys >= (1u << 20) && getenv("CRGPU_PREZERO") != nullptr;
     const uint64_t st_cap = prezero ? n_keys : 0;
     if (prezero) {
         CR_TRY(dmalloc(ctx, minidx_b, st_cap * sizeof(uint32_t)));
