@@ -961,9 +961,13 @@ __global__ __launch_bounds__(CP_BLOCK) void k_rl_count(const uint64_t *__restric
     }
 }
 
+// z_st / z_inc / z_min (nullable, together): the per-key state of the UMI correction starts out here -- 0, 0 and all ones for
+// every distinct key written -- instead of in three memsets on the critical path behind this kernel
 __global__ __launch_bounds__(CP_BLOCK) void k_rl_write(const uint64_t *__restrict__ keys, const uint32_t shift, const uint64_t n,
                                                        const uint64_t tile, const uint32_t *__restrict__ block_offs,
-                                                       uint64_t *__restrict__ ukey, uint32_t *__restrict__ upos) {
+                                                       uint64_t *__restrict__ ukey, uint32_t *__restrict__ upos,
+                                                       uint16_t *__restrict__ z_st, uint32_t *__restrict__ z_inc,
+                                                       uint32_t *__restrict__ z_min) {
     __shared__ uint32_t ws[CP_ITEMS * CP_WAVES];  // heads of (wave, item slot), then their exclusive prefix
     __shared__ uint32_t round_total;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1010,6 +1014,11 @@ __global__ __launch_bounds__(CP_BLOCK) void k_rl_write(const uint64_t *__restric
                 const uint32_t o = run + ws[wave * CP_ITEMS + j] + below[j];
                 ukey[o] = key[j];
                 upos[o] = (uint32_t)(w0 + (uint64_t)j * 64 + lane);
+                if (z_st) {
+                    z_st[o] = 0;
+                    z_inc[o] = 0u;
+                    z_min[o] = 0xFFFFFFFFu;
+                }
             }
         run += round_total;
         __syncthreads();
@@ -1017,12 +1026,14 @@ __global__ __launch_bounds__(CP_BLOCK) void k_rl_write(const uint64_t *__restric
 }
 
 static int run_lengths(crgpu_ctx *ctx, const uint64_t *keys, uint32_t shift, uint64_t n, uint64_t *ukey, uint32_t *upos,
-                       uint32_t *d_block, uint32_t *d_total_out) {
+                       uint32_t *d_block, uint32_t *d_total_out, uint16_t *z_st = nullptr, uint32_t *z_inc = nullptr,
+                       uint32_t *z_min = nullptr) {
     uint64_t tile;
     const uint32_t nb = cp_blocks(n, &tile);
     hipLaunchKernelGGL(k_rl_count, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, keys, shift, n, tile, d_block);
     CR_TRY(cr_scan_small(ctx, d_block, nb, d_total_out));
-    hipLaunchKernelGGL(k_rl_write, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, keys, shift, n, tile, d_block, ukey, upos);
+    hipLaunchKernelGGL(k_rl_write, dim3(nb), dim3(CP_BLOCK), 0, ctx->stream, keys, shift, n, tile, d_block, ukey, upos, z_st, z_inc,
+                       z_min);
     CR_HIP(ctx, hipGetLastError());
     return CRGPU_OK;
 }
@@ -1316,7 +1327,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t g) {
 }
 #define LF_THREADS 1024u  // a workgroup may own one giant barcode: many threads + batched loads keep that pole short
 #define LF_BATCH 4
-// EMIT (the default since round 3): instead of a flag per key -- which a count + write compaction then turned into the list of
+// EMIT (CRGPU_CAND_EMIT=1; measured slower, see the driver): instead of a flag per key -- which a count + write compaction then turned into the list of
 // (hash, index) pairs with two more reads of the flags and one of the keys -- the second pass writes the pairs of its
 // candidates itself: a workgroup counts them, reserves its stretch of the list with ONE atomic per tile and appends.  The
 // list is sorted by hash afterwards, so the order of the tiles in it does not matter.
@@ -1941,7 +1952,16 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     // (measured at 1 B records: the 8 GB of zeroing cost the sort passes more than the 0.8 ms they save -- sized by n_keys they
     // are twice what the distinct keys need: OFF unless CRGPU_PREZERO=1, kept for the A/B record)
     const bool prezero = ctx->stream2 && n_keys >= (1u << 20) && getenv("CRGPU_PREZERO") != nullptr;
-    const uint64_t st_cap = prezero ? n_keys : 0;
+    // default: the run-length write pass zeroes the state of every distinct key it emits (arrays sized by n_keys, the bound on the
+    // number of distinct keys known before that pass); CRGPU_STATE_MEMSET=1: three memsets behind it (round 2)
+    const bool fused_zero = !prezero && !getenv("CRGPU_STATE_MEMSET") && !getenv("CRGPU_RL_GENERIC") && !cr_sort_finish_experiment();
+    const uint64_t st_cap = (prezero || fused_zero) ? n_keys : 0;
+    if (fused_zero) {
+        CR_TRY(dmalloc(ctx, minidx_b, st_cap * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, corr_b, st_cap * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, incall_b, st_cap * sizeof(uint32_t)));
+        CR_TRY(dmalloc(ctx, st_b, ((st_cap + 1) & ~1ull) * sizeof(uint16_t) + 4));
+    }
     if (prezero) {
         CR_TRY(dmalloc(ctx, minidx_b, st_cap * sizeof(uint32_t)));
         CR_TRY(dmalloc(ctx, corr_b, st_cap * sizeof(uint32_t)));
@@ -2012,7 +2032,8 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             if (getenv("CRGPU_RL_GENERIC"))  // A/B: the generic compaction with its three loads per key
                 CR_TRY(compact(ctx, HeadFlag{keys, 1u}, EmitRun{keys, ukey, upos}, n_keys, d_block, d_total));
             else
-                CR_TRY(run_lengths(ctx, keys, 1u, n_keys, ukey, upos, d_block, d_total));
+                CR_TRY(run_lengths(ctx, keys, 1u, n_keys, ukey, upos, d_block, d_total, fused_zero ? st_b.as<uint16_t>() : nullptr,
+                                   fused_zero ? incall_b.as<uint32_t>() : nullptr, fused_zero ? minidx_b.as<uint32_t>() : nullptr));
         }
         CR_TRY(read_u32(ctx, d_total, &nd32));
         nd = nd32;
@@ -2020,12 +2041,13 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
 
     // 3. UMI correction + the read moves (state layout: umi_correct.h)
     const uint64_t st_bytes = ((nd + 1) & ~1ull) * sizeof(uint16_t) + 4;
-    if (!prezero) {
+    const bool zeroed = prezero || (fused_zero && !emitted);
+    if (!prezero && !fused_zero) {
         CR_TRY(dmalloc(ctx, minidx_b, nd * sizeof(uint32_t)));
         CR_TRY(dmalloc(ctx, corr_b, nd * sizeof(uint32_t)));   // written (and valid) only where st says "corrected"
         CR_TRY(dmalloc(ctx, incall_b, nd * sizeof(uint32_t)));
         CR_TRY(dmalloc(ctx, st_b, st_bytes));
-    } else {
+    } else if (prezero) {
         CR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));  // the zeroing of step 0
         prezero_guard.armed = false;
     }
@@ -2052,7 +2074,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             ~TimingBack() { c->timing = v; }
         } timing_back{ctx, timing_was};
         CrTimer t(ctx, CRGPU_T_DEDUP);
-        if (!prezero) {
+        if (!zeroed) {
             CR_HIP(ctx, hipMemsetAsync(inc_all, 0, nd * sizeof(uint32_t), ctx->stream));
             CR_HIP(ctx, hipMemsetAsync(st, 0, st_bytes, ctx->stream));
             CR_HIP(ctx, hipMemsetAsync(minidx, 0xFF, nd * sizeof(uint32_t), ctx->stream));
@@ -2099,13 +2121,16 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     //    (barcode, library, UMI) through a 32-bit hash sort -> exact comparison of the phase-1 counts
     {
         DevBuf cand_b, h_b, v_b;
-        if (getenv("CRGPU_CAND_FLAGS")) CR_TRY(dmalloc(ctx, cand_b, nd));
+        if (!getenv("CRGPU_CAND_EMIT")) CR_TRY(dmalloc(ctx, cand_b, nd));
         CR_TRY(dmalloc(ctx, h_b, nd * sizeof(uint32_t)));   // room for every key; the candidates are ~1/5 of them
         CR_TRY(dmalloc(ctx, v_b, nd * sizeof(uint32_t)));
         const uint32_t vbits = cr_ceil_log2(nd ? nd : 1);  // bits the distinct-key index needs inside the payload
         uint32_t n_cand32 = 0;
         if (overlap) CR_TRY(fork.side(fork.t0));  // from here to join(): ctx->stream is the second stream
-        const bool cand_flags = getenv("CRGPU_CAND_FLAGS") != nullptr;  // A/B: round 2's flag array + count / write compaction
+        // default: a flag per key + the count / write compaction.  CRGPU_CAND_EMIT=1: the filter kernel appends the (hash, index)
+        // pairs itself -- measured SLOWER at 1 B records (k_group_candidates 2.6 -> 7.4 ms for the 2.6 ms of compaction it saves:
+        // a third pass over every barcode range, whose longest ones are one workgroup's job), kept for the A/B record
+        const bool cand_flags = getenv("CRGPU_CAND_EMIT") == nullptr;
         unsigned long long *d_ncand = (unsigned long long *)(ctx->d_scalars + 64);
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
