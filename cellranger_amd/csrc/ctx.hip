@@ -139,7 +139,8 @@ extern "C" int crgpu_create(crgpu_ctx **out, int device_id, int n_ranks, int ran
     }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();  // the count stage then stays on the one stream
         if (ctx->stream2) hipStreamDestroy(ctx->stream2);
         ctx->stream2 = nullptr;
@@ -241,7 +242,8 @@ void cr_dense_free(crgpu_ctx *ctx) {
     cr_dense_drop(ctx);
     (void)hipFree(ctx->dense.d_fwd);
     (void)hipFree(ctx->dense.d_back);
-    ctx->dense.d_fwd = ctx->dense.d_back = nullptr;
+    ctx->dense.d_fwd = nullptr;
+    ctx->dense.d_back = nullptr;
 }
 
 extern "C" int crgpu_invalidate(crgpu_ctx *ctx) {
@@ -297,6 +299,7 @@ extern "C" void crgpu_destroy(crgpu_ctx *ctx) {
     for (auto ev : ctx->event_pool) hipEventDestroy(ev);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_aux) hipEventDestroy(ctx->ev_aux);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

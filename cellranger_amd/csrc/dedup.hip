@@ -123,6 +123,14 @@ static KL make_kl(const KeyLayout &L) {
               L.umi_len, L.n_features, L.n_libs, L.mux_mask, L.bits_ulen, L.sh_libid(), L.umi_min_len};
 }
 __device__ __forceinline__ uint64_t lowmask(uint32_t bits) { return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull); }
+// CRGPU_OPT_DENSE_BARCODE_KEYS: column of a whitelist rank in the BarcodeIndex, or CRGPU_MISS (DenseIndex::d_fwd)
+__device__ __forceinline__ uint32_t dense_column(const uint4 *__restrict__ fwd, uint32_t rank) {
+    const uint4 e = fwd[rank >> 6];
+    const unsigned long long bits = ((unsigned long long)e.y << 32) | e.x;
+    const uint32_t bit = rank & 63u;
+    if (!((bits >> bit) & 1ull)) return CRGPU_MISS;
+    return e.z + (uint32_t)__popcll(bits & ((1ull << bit) - 1ull));
+}
 
 struct DevBuf {  // pooled temporary, returned to the context's pool at scope exit
     crgpu_ctx *ctx = nullptr;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
                                                     unsigned long long *__restrict__ n_out, const SweepPlan plan,
                                                     uint32_t *__restrict__ ghist, unsigned long long *__restrict__ status,
                                                     uint32_t *__restrict__ ticket, const uint8_t *__restrict__ ulen,
-                                                    const uint32_t *__restrict__ dense_fwd, uint32_t *__restrict__ n_unknown,
+                                                    const uint4 *__restrict__ dense_fwd, uint32_t *__restrict__ n_unknown,
                                                     uint32_t *__restrict__ lb_abort) {
     // lb_abort: the watchdog word of the ORDERED look-back (block_utils.h)
     // dense_fwd (nullable): barcode rank -> column of the BarcodeIndex (CRGPU_OPT_DENSE_BARCODE_KEYS)
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256) void k_build_keys(const KL kl, const uint32_t 
             const uint32_t f = vf[jj], fl = vfl[jj];
             const uint32_t lib = fl & CRGPU_FLAG_LIB_MASK;
             if (dense_fwd && b != CRGPU_MISS) {
-                b = dense_fwd[b];
+                b = dense_column(dense_fwd, b);
                 if (b == CRGPU_MISS) atomicAdd(n_unknown, 1u);  // a barcode without reads in the tables: the call fails
             }
             bool keep = b != CRGPU_MISS && f != CRGPU_NO_FEATURE && f < kl.n_features && lib < kl.n_libs;
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256) void k_build_keys_v4(const KL kl, const uint32
                                                        const uint8_t *__restrict__ umi_q, const uint32_t *__restrict__ feature,
                                                        const uint8_t *__restrict__ flags, uint64_t n, uint64_t *__restrict__ keys_out,
                                                        unsigned long long *__restrict__ n_out, const SweepPlan plan,
-                                                       uint32_t *__restrict__ ghist, const uint32_t *__restrict__ dense_fwd,
+                                                       uint32_t *__restrict__ ghist, const uint4 *__restrict__ dense_fwd,
                                                        uint32_t *__restrict__ n_unknown) {
     static_assert(LQW >= 1 && LQW <= 4, "dword quality rows");
     __shared__ __attribute__((aligned(8))) uint32_t lds[10];
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(256) void k_build_keys_v4(const KL kl, const uint32
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const uint32_t rk = b4[r];
-                    const uint32_t c = dense_fwd[rk != CRGPU_MISS ? rk : 0u];
+                    const uint32_t c = dense_column(dense_fwd, rk != CRGPU_MISS ? rk : 0u);
                     if (rk != CRGPU_MISS && c == CRGPU_MISS && iv < n_vec) atomicAdd(n_unknown, 1u);
                     b4[r] = rk != CRGPU_MISS ? c : CRGPU_MISS;
                 }
@@ -473,7 +481,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
                "crgpu_build_keys: the UMI quality buffer must be 4-byte aligned");
     unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
     CR_TRY(cr_dense_ensure(ctx));  // CRGPU_OPT_DENSE_BARCODE_KEYS: the BarcodeIndex of the tables as they stand (else nothing)
-    const uint32_t *d_fwd = ctx->dense.valid ? ctx->dense.d_fwd : nullptr;
+    const uint4 *d_fwd = ctx->dense.valid ? ctx->dense.d_fwd : nullptr;
     uint32_t *d_unknown = ctx->d_scalars + 60, *d_lb_abort = ctx->d_scalars + 61;
     {
         CrTimer t(ctx, CRGPU_T_KEYS, recs->n);
@@ -1952,9 +1960,11 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     // (measured at 1 B records: the 8 GB of zeroing cost the sort passes more than the 0.8 ms they save -- sized by n_keys they
     // are twice what the distinct keys need: OFF unless CRGPU_PREZERO=1, kept for the A/B record)
     const bool prezero = ctx->stream2 && n_keys >= (1u << 20) && getenv("CRGPU_PREZERO") != nullptr;
-    // default: the run-length write pass zeroes the state of every distinct key it emits (arrays sized by n_keys, the bound on the
-    // number of distinct keys known before that pass); CRGPU_STATE_MEMSET=1: three memsets behind it (round 2)
-    const bool fused_zero = !prezero && !getenv("CRGPU_STATE_MEMSET") && !getenv("CRGPU_RL_GENERIC") && !cr_sort_finish_experiment();
+    // experiment: the run-length write pass zeroes the state of every distinct key it emits (arrays sized by n_keys, the bound on
+    // the number of distinct keys known before that pass) instead of three memsets behind it
+    // (measured at 1 B records: k_rl_write 2.2 -> 3.3 ms with the three extra stores per distinct key, against 0.8 ms of memsets:
+    // OFF unless CRGPU_STATE_FUSED_ZERO=1, kept for the A/B record)
+    const bool fused_zero = !prezero && getenv("CRGPU_STATE_FUSED_ZERO") && !getenv("CRGPU_RL_GENERIC") && !cr_sort_finish_experiment();
     const uint64_t st_cap = (prezero || fused_zero) ? n_keys : 0;
     if (fused_zero) {
         CR_TRY(dmalloc(ctx, minidx_b, st_cap * sizeof(uint32_t)));
@@ -2057,6 +2067,10 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     const bool overlap = CrFork::enabled(ctx, nd);
     CrFork fork(ctx);
     DevBuf heads_b, giant_b, best_b;  // step 3's temporaries, alive until the branches have joined
+    bool edges_small_on_side = false;
+    uint64_t es_tiles = 0;
+    uint32_t *es_first = nullptr, *es_last = nullptr, *es_ngiant = nullptr;
+    GiantItem *es_items = nullptr;
     if (overlap) {
         CR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         if (ctx->timing) {
@@ -2100,9 +2114,20 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             GiantItem *items = reinterpret_cast<GiantItem *>(giant_b.as<unsigned char>() + 16);
             unsigned long long *best = best_b.as<unsigned long long>();
             CR_HIP(ctx, hipMemsetAsync(n_giant, 0, sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(k_correct_umis_edges<true>, dim3(cr_grid(n_tiles - 1, 1, 256u * 6u)), dim3(UES_THREADS),
-                               lds_small, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all,
-                               minidx, items, n_giant);
+            // the small edge segments only need the tile heads: with two streams they go to the second one, behind the candidate
+            // search (which ends before this branch does), and leave this branch the large segments and the giant chain
+            edges_small_on_side = overlap && ctx->ev_aux && !getenv("CRGPU_EDGES_MAIN");
+            if (edges_small_on_side) {
+                CR_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));  // the tile heads are written
+                es_tiles = n_tiles;
+                es_first = tile_first;
+                es_last = tile_last;
+                es_items = items;
+                es_ngiant = n_giant;
+            } else
+                hipLaunchKernelGGL(k_correct_umis_edges<true>, dim3(cr_grid(n_tiles - 1, 1, 256u * 6u)), dim3(UES_THREADS),
+                                   lds_small, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all,
+                                   minidx, items, n_giant);
             hipLaunchKernelGGL(k_correct_umis_edges<false>, dim3(cr_grid(n_tiles - 1, 1, 256u * 2u)), dim3(UE_THREADS),
                                lds_large, ctx->stream, kl, ukey, upos, nd, n_keys, tile_first, tile_last, corr, st, inc_all,
                                minidx, items, n_giant);
@@ -2121,6 +2146,17 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
     //    (barcode, library, UMI) through a 32-bit hash sort -> exact comparison of the phase-1 counts
     {
         DevBuf cand_b, h_b, v_b;
+        bool side_edges_done = false;
+        auto side_edges = [&]() -> int {  // the small edge segments of step 3, on the stream the candidate search ran on
+            if (!edges_small_on_side || side_edges_done || !fork.on_side) return CRGPU_OK;
+            side_edges_done = true;
+            CR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));
+            const size_t lds_small = (2 * UES_CAP + UES_BUCKETS * 8) * sizeof(uint32_t);
+            hipLaunchKernelGGL(k_correct_umis_edges<true>, dim3(cr_grid(es_tiles - 1, 1, 256u * 6u)), dim3(UES_THREADS), lds_small,
+                               ctx->stream, kl, ukey, upos, nd, n_keys, es_first, es_last, corr, st, inc_all, minidx, es_items, es_ngiant);
+            CR_HIP(ctx, hipGetLastError());
+            return CRGPU_OK;
+        };
         if (!getenv("CRGPU_CAND_EMIT")) CR_TRY(dmalloc(ctx, cand_b, nd));
         CR_TRY(dmalloc(ctx, h_b, nd * sizeof(uint32_t)));   // room for every key; the candidates are ~1/5 of them
         CR_TRY(dmalloc(ctx, v_b, nd * sizeof(uint32_t)));
@@ -2162,6 +2198,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             bool s_in_tmp = false;
             CR_TRY(cr_radix_sort_u32(ctx, h_b.as<uint32_t>(), ht_b.as<uint32_t>(), v_b.as<uint32_t>(), vt_b.as<uint32_t>(), n_cand,
                                      0, LS_HASH_BITS, &s_in_tmp));
+            CR_TRY(side_edges());
             CR_TRY(fork.join());  // k_low_support compares the phase-1 counts: it needs both branches
             {
                 CrTimer t(ctx, CRGPU_T_DEDUP);
@@ -2171,6 +2208,7 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
                 CR_HIP(ctx, hipGetLastError());
             }
         }
+        CR_TRY(side_edges());
         CR_TRY(fork.join());  // (no candidates: nothing was joined above)
     }
 
@@ -2583,10 +2621,6 @@ struct EmitCol {
 };
 
 // ---- CRGPU_OPT_DENSE_BARCODE_KEYS: the BarcodeIndex of the tables as they stand (cr_types/src/barcode_index.rs:20-53) ------
-__global__ __launch_bounds__(256) void k_dense_fwd(const uint32_t *__restrict__ back, uint32_t V, uint32_t *__restrict__ fwd) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < V; c += stride) fwd[back[c]] = c;
-}
 int cr_dense_ensure(crgpu_ctx *ctx) {
     DenseIndex &D = ctx->dense;
     if (!D.on || D.valid) return CRGPU_OK;
@@ -2599,7 +2633,7 @@ int cr_dense_ensure(crgpu_ctx *ctx) {
             seen.ct.t[seen.ct.n++] = ctx->wl[l].d_valid;
             seen.ct.t[seen.ct.n++] = ctx->wl[l].d_corrected;
         }
-    if (!D.d_fwd) CR_HIP(ctx, hipMalloc((void **)&D.d_fwd, (size_t)W * sizeof(uint32_t)));
+    if (!D.d_fwd) CR_HIP(ctx, hipMalloc((void **)&D.d_fwd, (((size_t)W + 63) / 64) * sizeof(uint4)));
     if (!D.d_back) CR_HIP(ctx, hipMalloc((void **)&D.d_back, (size_t)W * sizeof(uint32_t)));
     uint32_t *d_total = ctx->d_scalars + 16;
     uint32_t V = 0;
@@ -2613,14 +2647,22 @@ int cr_dense_ensure(crgpu_ctx *ctx) {
     CR_REQUIRE(ctx, L.total_bits() <= 64, CRGPU_ERANGE,
                "molecule key needs %u bits even with %u barcodes in the index (barcode %u + feature %u + library %u + umi %u + 1) > 64",
                L.total_bits(), V, L.bits_bc, L.bits_feat, L.bits_lib, L.bits_umi + L.bits_ulen);
-    {
-        CrTimer t(ctx, CRGPU_T_KEYS);
-        CR_HIP(ctx, hipMemsetAsync(D.d_fwd, 0xFF, (size_t)W * sizeof(uint32_t), ctx->stream));
-        if (V) hipLaunchKernelGGL(k_dense_fwd, dim3(cr_grid(V, 256)), dim3(256), 0, ctx->stream, D.d_back, V, D.d_fwd);
-        CR_HIP(ctx, hipGetLastError());
-    }
     D.h_back.resize(V);
     if (V) CR_TRY(crgpu_memcpy_d2h(ctx, D.h_back.data(), D.d_back, (uint64_t)V * sizeof(uint32_t)));
+    {   // rank/select table on the host (V set bits, W / 64 words): 16 bytes per 64 ranks
+        const size_t n_words = ((size_t)W + 63) / 64;
+        std::vector<uint4> t(n_words, make_uint4(0u, 0u, 0u, 0u));
+        for (uint32_t c = 0; c < V; c++) {
+            const uint32_t r = D.h_back[c];
+            if (r & 32u) t[r >> 6].y |= 1u << (r & 31u); else t[r >> 6].x |= 1u << (r & 31u);
+        }
+        uint32_t run = 0;
+        for (size_t w = 0; w < n_words; w++) {
+            t[w].z = run;
+            run += (uint32_t)__builtin_popcount(t[w].x) + (uint32_t)__builtin_popcount(t[w].y);
+        }
+        CR_TRY(crgpu_memcpy_h2d(ctx, D.d_fwd, t.data(), n_words * sizeof(uint4)));
+    }
     D.V = V;
     D.valid = true;
     ctx->layout = L;
