@@ -123,6 +123,11 @@ static KL make_kl(const KeyLayout &L) {
               L.umi_len, L.n_features, L.n_libs, L.mux_mask, L.bits_ulen, L.sh_libid(), L.umi_min_len};
 }
 __device__ __forceinline__ uint64_t lowmask(uint32_t bits) { return bits >= 64 ? ~0ull : ((1ull << bits) - 1ull); }
+typedef uint32_t cr_v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream4(const uint4 *p) {  // 16-byte load that does not stay in the caches
+    const cr_v4u32 v = __builtin_nontemporal_load(reinterpret_cast<const cr_v4u32 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 // CRGPU_OPT_DENSE_BARCODE_KEYS: column of a whitelist rank in the BarcodeIndex, or CRGPU_MISS (DenseIndex::d_fwd)
 __device__ __forceinline__ uint32_t dense_column(const uint4 *__restrict__ fwd, uint32_t rank) {
     const uint4 e = fwd[rank >> 6];
@@ -385,12 +390,22 @@ __global__ __launch_bounds__(256) void k_build_keys_v4(const KL kl, const uint32
             const int v = v0 + vv;
             const uint64_t iv = c * (chunk / 4) + (uint64_t)v * 256 + threadIdx.x;  // index of the vector
             const uint64_t ic = iv < n_vec ? iv : n_vec - 1;                         // loads from a clamped address
-            vb[vv] = bc4[ic];
-            vf[vv] = ft4[ic];
-            vu[vv] = um4[ic];
-            vfl[vv] = fl4 ? fl4[ic] : 0u;
+            if (dense_fwd) {
+                // the rank -> column table has to stay in L2 beside 33 bytes of touch-once input per read: those go past it
+                vb[vv] = ld_stream4(bc4 + ic);
+                vf[vv] = ld_stream4(ft4 + ic);
+                vu[vv] = ld_stream4(um4 + ic);
+                vfl[vv] = fl4 ? __builtin_nontemporal_load(fl4 + ic) : 0u;
 #pragma unroll
-            for (int k = 0; k < LQW; k++) vq[vv][k] = q4[ic * LQW + k];
+                for (int k = 0; k < LQW; k++) vq[vv][k] = ld_stream4(q4 + ic * LQW + k);
+            } else {
+                vb[vv] = bc4[ic];
+                vf[vv] = ft4[ic];
+                vu[vv] = um4[ic];
+                vfl[vv] = fl4 ? fl4[ic] : 0u;
+#pragma unroll
+                for (int k = 0; k < LQW; k++) vq[vv][k] = q4[ic * LQW + k];
+            }
         }
 #pragma unroll
         for (int vv = 0; vv < KEY_VB; vv++) {
@@ -2116,7 +2131,9 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             CR_HIP(ctx, hipMemsetAsync(n_giant, 0, sizeof(uint32_t), ctx->stream));
             // the small edge segments only need the tile heads: with two streams they go to the second one, behind the candidate
             // search (which ends before this branch does), and leave this branch the large segments and the giant chain
-            edges_small_on_side = overlap && ctx->ev_aux && !getenv("CRGPU_EDGES_MAIN");
+            // (measured at 1 B records: 61.66 against 61.45 ms per step with everything on the main stream -- no gain, the candidate
+            // branch is not idle for long enough: OFF unless CRGPU_EDGES_SIDE=1)
+            edges_small_on_side = overlap && ctx->ev_aux && getenv("CRGPU_EDGES_SIDE") != nullptr;
             if (edges_small_on_side) {
                 CR_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));  // the tile heads are written
                 es_tiles = n_tiles;

@@ -355,9 +355,12 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
     const uint32_t words_before_pend = slots + 4u * nfh + (THREADS / 64u) * 64u * P.pitch;
     FxtPending *s_pend = reinterpret_cast<FxtPending *>(s_val + words_before_pend + (words_before_pend & 1u));  // 8-byte aligned
     __shared__ uint32_t s_npend;
+    __shared__ uint8_t s_pat[256];  // prefix then suffix of the pattern ('.' = any); longer ones take the generic kernel
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t L = P.L;
     const unsigned long long *fk = reinterpret_cast<const unsigned long long *>(v.key);  // the one pattern's slice starts at 0
+    for (uint32_t t = tid; t < P.pre_len + P.suf_len; t += THREADS)
+        s_pat[t] = (uint8_t)(t < P.pre_len ? v.chars[v.pat[0].pre_off + t] : v.chars[v.pat[0].suf_off + (t - P.pre_len)]);
     for (uint32_t t = tid; t < slots; t += THREADS) s_key[t] = FXT_EMPTY;
     if (tid == 0) s_npend = 0;
     __syncthreads();
@@ -375,7 +378,6 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
         }
     }
     __syncthreads();
-    const char *pre = v.chars + v.pat[0].pre_off, *suf = v.chars + v.pat[0].suf_off;
     const uint32_t need = P.pre_len + L + P.suf_len;
     const uint32_t tag = P.read << 30;
     const uint32_t hb = L >> 1;  // bases of the last half (the split of the host's half-key tables)
@@ -514,30 +516,44 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
                     possible = s_lo == 0;
                     s_hi = 0;
                 }
-                uint32_t d_prev = 0xFFFFFFFFu, w_lo = 0, w_hi = 0;
-                if (possible)
-                    for (uint32_t st = s_lo; st <= s_hi && found == FX_NO_CAPTURE; st++) {
-                        if (P.needle_mask) {
-                            // the first literal characters of the pattern as one masked 32-bit compare on a window that
-                            // slides over the row's dwords: most starts of a floating pattern end here
-                            const uint32_t p = st + P.needle_off - P.win_lo, d = p >> 2, sh = (p & 3u) * 8u;
-                            if (d != d_prev) {
-                                w_lo = row[d];
-                                w_hi = row[d + 1];  // may lie behind the window: the full comparison below decides
-                                d_prev = d;
-                            }
-                            const uint32_t w = sh ? (w_lo >> sh) | (w_hi << (32u - sh)) : w_lo;
-                            if ((w ^ P.needle) & P.needle_mask) continue;
+                // prefix and suffix at start st (literals only; '.' matches anything): the pattern's characters sit in LDS
+                auto verify = [&](uint32_t st) -> bool {
+                    bool ok = true;
+                    if (!P.pre_dots)
+                        for (uint32_t k = 0; k < P.pre_len && ok; k++)
+                            ok = s_pat[k] == (uint8_t)'.' || (uint32_t)s_pat[k] == fxt_byte(row, st + k - P.win_lo);
+                    if (!P.suf_dots)
+                        for (uint32_t k = 0; k < P.suf_len && ok; k++)
+                            ok = s_pat[P.pre_len + k] == (uint8_t)'.' ||
+                                 (uint32_t)s_pat[P.pre_len + k] == fxt_byte(row, st + P.pre_len + L + k - P.win_lo);
+                    return ok;
+                };
+                if (possible && P.needle_mask) {
+                    // Floating pattern: its first literal characters (up to four) as a masked 32-bit compare, FOUR starts per row
+                    // dword -- the window slides over the row's dwords, the four byte alignments of (this dword, next dword) are
+                    // tested at once, and only the starts that pass (left to right) get the full comparison.
+                    const uint32_t p_lo = s_lo + P.needle_off - P.win_lo, p_hi = s_hi + P.needle_off - P.win_lo;
+                    uint32_t w_lo = row[p_lo >> 2];
+                    for (uint32_t d = p_lo >> 2; d <= (p_hi >> 2) && found == FX_NO_CAPTURE; d++) {
+                        const uint32_t w_hi = row[d + 1];  // may lie behind the window: the full comparison decides
+                        uint32_t m = (((w_lo ^ P.needle) & P.needle_mask) == 0u ? 1u : 0u) |
+                                     (((((w_lo >> 8) | (w_hi << 24)) ^ P.needle) & P.needle_mask) == 0u ? 2u : 0u) |
+                                     (((((w_lo >> 16) | (w_hi << 16)) ^ P.needle) & P.needle_mask) == 0u ? 4u : 0u) |
+                                     (((((w_lo >> 24) | (w_hi << 8)) ^ P.needle) & P.needle_mask) == 0u ? 8u : 0u);
+                        w_lo = w_hi;
+                        while (m && found == FX_NO_CAPTURE) {
+                            const uint32_t a = (uint32_t)__ffs((int)m) - 1u;
+                            m &= m - 1u;
+                            const uint32_t pp = 4u * d + a;
+                            if (pp < p_lo || pp > p_hi) continue;
+                            const uint32_t st = pp + P.win_lo - P.needle_off;
+                            if (verify(st)) found = st + P.pre_len;
                         }
-                        bool ok = true;
-                        if (!P.pre_dots)
-                            for (uint32_t k = 0; k < P.pre_len && ok; k++)
-                                ok = pre[k] == '.' || (uint32_t)(uint8_t)pre[k] == fxt_byte(row, st + k - P.win_lo);
-                        if (!P.suf_dots)
-                            for (uint32_t k = 0; k < P.suf_len && ok; k++)
-                                ok = suf[k] == '.' || (uint32_t)(uint8_t)suf[k] == fxt_byte(row, st + P.pre_len + L + k - P.win_lo);
-                        if (ok) found = st + P.pre_len;
                     }
+                } else if (possible) {
+                    for (uint32_t st = s_lo; st <= s_hi && found == FX_NO_CAPTURE; st++)
+                        if (verify(st)) found = st + P.pre_len;
+                }
             }
             if (found == FX_NO_CAPTURE) {
                 feature_out[i] = CRGPU_NO_FEATURE;
@@ -917,7 +933,7 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
         if (X.t_anchor5) win_hi = std::min(R.stride, (need + 3u) & ~3u);
         else if (X.t_anchor3 && !R.len && need <= R.stride) win_lo = (R.stride - need) & ~3u;
         const uint32_t win_dw = (win_hi - win_lo) / 4u;
-        if (aligned && win_dw >= 1 && win_dw <= 64u && R.stride >= 4) {
+        if (aligned && win_dw >= 1 && win_dw <= 64u && R.stride >= 4 && X.t_pre_len + X.t_suf_len <= 256u) {
             FxtParams P{};
             P.read = X.t_read;
             P.anchor5 = X.t_anchor5;
