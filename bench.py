@@ -66,8 +66,8 @@ def parse_args():
     ap.add_argument("--fb-row-stride", type=int, default=92, help="cfg4: bytes per R2 row (90-base read + padding to a dword)")
     ap.add_argument("--fb-features", type=int, default=200)
     ap.add_argument("--dense-keys", type=int, default=-1,
-                    help="CRGPU_OPT_DENSE_BARCODE_KEYS: 1 / 0; default: on for whitelists of more than 2^20 barcodes (the 3M list: "
-                         "23-bit ranks -> 18-bit BarcodeIndex columns, one radix pass fewer)")
+                    help="CRGPU_OPT_DENSE_BARCODE_KEYS: 1 / 0; default 0 (measured on the 3M list: the rank -> column gather costs the "
+                         "key builder 6 ms per 1 B reads, more than the radix pass it saves; the option is for layouts beyond 64 bits)")
     ap.add_argument("--no-default-options", action="store_true",
                     help="skip the short second timed loop with CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS off")
     ap.add_argument("--reads-per-gpu", type=int, default=0)
@@ -450,7 +450,7 @@ def main():
     ctx = E.Context(local_rank, n_ranks=world, rank=rank, unique_id=uid)
     # the bench writes its buffers only through the context: K2 may use K1's miss records, the sort the key histograms
     ctx.trust_unchanged_buffers(True)
-    dense_keys = (args.whitelist > (1 << 20)) if args.dense_keys < 0 else bool(args.dense_keys)
+    dense_keys = False if args.dense_keys < 0 else bool(args.dense_keys)
     if dense_keys:
         ctx.set_option(1, 1)   # before the key layout is set
     be = HipBackend(ctx, local_rank)

@@ -767,12 +767,14 @@ uint32_t cr_sort_low_bits(uint32_t total_bits, uint32_t umi_bits) {
         const uint32_t low = total_bits - 9 * p;          // <= 16 by construction
         return p < full ? low : 0;
     }
-    for (uint32_t low = 1; low <= 8 && low < total_bits; low++) {
+    // up to 10 low bits (round 3; 8 before): 64-bit keys (the 3M-february-2018 list) then sort in six 9-bit passes instead of
+    // seven; at least 14 UMI bits (7 bases) stay above the cut, so runs of equal top bits that hold different UMIs stay rare
+    for (uint32_t low = 1; low <= 10 && low < total_bits; low++) {
         const uint32_t top = total_bits - low;
         const uint32_t q8 = (top + 7) / 8, q9 = (top + 8) / 9;
         if ((q9 < q8 ? q9 : q8) >= full) continue;               // saves nothing yet
         // bit 0 is the UmiType bit, the UMI sits right above it: low - 1 of its bits fall below the cut
-        return umi_bits >= 16u + (low - 1u) ? low : 0u;
+        return umi_bits >= 14u + (low - 1u) ? low : 0u;
     }
     return 0;
 }

@@ -37,7 +37,7 @@ def main():
         pos = rng.integers(0, L, n)
         pick[mut, pos[mut]] = acgt[rng.integers(0, 4, int(mut.sum()))]
         planted = rng.random(n) < 0.8
-        at = 10 if defs[0][0].startswith("5P") else 30
+        at = 10 if defs[0][0].startswith("5P") else min(30, max(0, stride - L - 20))
         s[planted, at:at + L] = pick[planted]
         if "GTTTAAG" in defs[0][0]:
             suf = np.frombuffer(b"GTTTAAGAGCTAAGCTGGAA", np.uint8)
