@@ -70,9 +70,23 @@ struct FeatureExtractorSet {
     // the extractor's only pattern when that one is tethered (the usual feature reference): k_extract_tethered_lds applies
     bool one_tethered = false;
     uint32_t t_read = 0, t_anchor5 = 0, t_anchor3 = 0, t_pre_len = 0, t_suf_len = 0, t_L = 0, t_n_feat = 0;
+    std::string sig;  // read, pattern, (sequence, index) pairs: two extractors with equal signatures cut the same captures
     bool t_pre_dots = false, t_suf_dots = false;  // prefix / suffix are wildcards only
     // up to four leading literal characters of the suffix (else of the prefix): a floating pattern is first looked for by them
     uint32_t t_needle = 0, t_needle_len = 0, t_needle_off = 0;
+};
+
+// Captures that the one-pattern extraction kernel found no exact feature for, kept by a call WITHOUT a feature distribution
+// for the call WITH one that follows on the same rows (MAKE_SHARD's exact-match counts, then ALIGN_AND_COUNT's corrected
+// matches): only used under CRGPU_OPT_BUFFERS_UNCHANGED_BETWEEN_CALLS, dropped by cr_invalidate (feature_extract.hip)
+struct FxPendingSet {
+    bool valid = false;
+    const void *d_seq = nullptr, *d_qual = nullptr, *d_len = nullptr;
+    uint64_t n = 0, n_recs = 0;
+    uint32_t stride = 0;
+    void *d_feature_out = nullptr, *d_n_ids_out = nullptr, *d_capture_out = nullptr;
+    std::string sig;         // the definitions the captures were cut for
+    void *d_recs = nullptr;  // pool block
 };
 
 struct TimedSpan {
@@ -175,6 +189,7 @@ struct crgpu_ctx {
     WlTables wl[CRGPU_MAX_LIB];
     FeaturePattern pat[CRGPU_MAX_LIB];
     FeatureExtractorSet fx[CRGPU_MAX_LIB];
+    FxPendingSet fxp;
     uint32_t *d_canon_keys = nullptr;         // n_canon packed canonical barcodes, ascending (rank -> sequence)
     unsigned long long *d_hot_image = nullptr;  // K1's hot-barcode table (HOT_SLOTS entries) + 256 u32 of scratch
     MissRecords rec;
@@ -183,6 +198,7 @@ struct crgpu_ctx {
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
     uint64_t sort_refinished = 0;          // sorts whose finishing pass met a run too long for it and that were redone on all bits
     uint64_t k1_split_rounds = 0;          // table rounds of K1 whose histogram was split (table slots in LDS + staged cold hits)
+    uint64_t feature_resumed_reads = 0;    // captures a pass with a distribution took from the records of the pass without one
     uint64_t feature_fast_launches = 0;    // crgpu_extract_features_dev calls that took k_extract_tethered_lds
     uint64_t feature_reads_requeued = 0;   // reads k_extract_features handed to the wide-map launch
     uint64_t comm_bytes[3] = {0, 0, 0};    // bytes this rank put into C1 (table all-reduce), C2 (key exchange), C3 (triplet gather)
@@ -250,6 +266,7 @@ int cr_dense_ensure(crgpu_ctx *ctx);
 void cr_dense_drop(crgpu_ctx *ctx);
 void cr_dense_free(crgpu_ctx *ctx);
 void cr_feature_extractors_free(crgpu_ctx *ctx);  // feature_extract.hip
+void cr_drop_feature_pending(crgpu_ctx *ctx);      // feature_extract.hip
 // the sequence of a canonical rank as up to 32 bases: *lo = the first min(16, cb_len) bases packed, *hi = the rest (0 when
 // cb_len <= 16); whitelist.hip
 void cr_rank_to_seq(const crgpu_ctx *ctx, uint32_t rank, uint32_t *lo, uint32_t *hi);

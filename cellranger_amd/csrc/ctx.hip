@@ -216,6 +216,9 @@ extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
         case CRGPU_STAT_COMM_BYTES_C3:
             *value_out = ctx->comm_bytes[which - CRGPU_STAT_COMM_BYTES_C1];
             return CRGPU_OK;
+        case CRGPU_STAT_FEATURE_RESUMED_READS:
+            *value_out = ctx->feature_resumed_reads;
+            return CRGPU_OK;
         case CRGPU_STAT_FEATURE_FAST_LAUNCHES:
             *value_out = ctx->feature_fast_launches;
             return CRGPU_OK;
@@ -229,6 +232,7 @@ extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
 
 void cr_invalidate(crgpu_ctx *ctx) {
     cr_drop_miss_records(ctx);
+    cr_drop_feature_pending(ctx);
     ctx->ghist.valid = false;
 }
 void cr_dense_drop(crgpu_ctx *ctx) {

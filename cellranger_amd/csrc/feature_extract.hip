@@ -341,7 +341,15 @@ __device__ __forceinline__ uint32_t fxt_byte(const uint32_t *row, uint32_t b) { 
 template <uint32_t THREADS>
 __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v, const FxtParams P, const double *__restrict__ pedit,
                                                                   const FxRows R, uint64_t n, uint32_t *__restrict__ feature_out,
-                                                                  uint32_t *__restrict__ n_ids_out, uint32_t *__restrict__ capture_out) {
+                                                                  uint32_t *__restrict__ n_ids_out, uint32_t *__restrict__ capture_out,
+                                                                  FxtPending *__restrict__ recs, unsigned long long *__restrict__ rec_count,
+                                                                  uint64_t rec_cap, uint64_t n_recs_in) {
+    // recs / rec_count (nullable) -- the two-pass flow of a Feature Barcoding library (MAKE_SHARD's exact-match counts first, the
+    // posterior with the distribution afterwards: make_shard_metrics.rs:336-345, aligner.rs:463-518):
+    //   * an extractor WITHOUT a distribution appends the captures that found no exact feature (at most one N) to recs -- the
+    //     only reads whose answer a distribution can change;
+    //   * n_recs_in > 0 (an extractor WITH a distribution, the same definitions, rows and outputs): only those captures are
+    //     corrected; the rows are not read again (half of the pass's HBM traffic is the rows).
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_key[];
     const uint32_t slots = P.slot_mask + 1u;
     // LDS: [hash keys u64 x slots][feature keys u64 x n_feat (halves)][hash values u32 x slots][half tables 4 x n_feat u32 (halves)]
@@ -389,9 +397,9 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
     // two searches in the sorted half-key tables (LDS) list every candidate -- instead of 3 L hash probes -- and the few
     // candidates are then put into the reference's order.  More than FXT_MAXC candidates (dense feature families): the probes.
     constexpr uint32_t FXT_MAXC = 8;
-    auto drain = [&](uint32_t first, uint32_t count) {  // pending captures [first, first + count), count <= THREADS
-        if (tid < count) {
-            const FxtPending e = s_pend[first + tid];
+    __shared__ unsigned long long s_rec_base;
+    auto posterior = [&](const FxtPending &e) {
+        {
             const uint64_t i = ((uint64_t)e.i_hi << 32) | e.i_lo;
             const uint8_t *q = R.qual + i * R.stride + e.start;
             double sum = 0.0, mx = -1.0;
@@ -483,6 +491,29 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
             if (capture_out) capture_out[i] = (hit ? 0x80000000u : 0u) | tag | (e.start << 8) | L;
         }
     };
+    // pending captures [first, first + count), count <= THREADS; called at workgroup-uniform points
+    auto drain = [&](uint32_t first, uint32_t count) {
+        if (v.dist) {
+            if (tid < count) posterior(s_pend[first + tid]);
+            return;
+        }
+        // no distribution: nothing matches, the captures are kept for the pass that has one
+        if (tid == 0) s_rec_base = count ? atomicAdd(rec_count, (unsigned long long)count) : 0ull;
+        __syncthreads();
+        if (tid < count) {
+            const FxtPending e = s_pend[first + tid];
+            const uint64_t i = ((uint64_t)e.i_hi << 32) | e.i_lo;
+            feature_out[i] = CRGPU_NO_FEATURE;
+            if (n_ids_out) n_ids_out[i] = 0u;
+            if (capture_out) capture_out[i] = tag | (e.start << 8) | L;
+            if (s_rec_base + tid < rec_cap) recs[s_rec_base + tid] = e;
+        }
+        __syncthreads();
+    };
+    if (n_recs_in) {  // second pass over the kept captures only
+        for (uint64_t j = (uint64_t)blockIdx.x * THREADS + tid; j < n_recs_in; j += (uint64_t)gridDim.x * THREADS) posterior(recs[j]);
+        return;
+    }
 
     for (uint64_t base = (uint64_t)blockIdx.x * THREADS; base < n; base += (uint64_t)gridDim.x * THREADS) {
         const uint64_t wrow = base + (tid & ~63u);  // the wave's first row
@@ -575,7 +606,7 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
                     feature_out[i] = v.index[exact];  // find_closest's fast path (:452-457)
                     if (n_ids_out) n_ids_out[i] = 1u;
                     if (capture_out) capture_out[i] = 0x80000000u | tag | (found << 8) | L;
-                } else if (v.dist && n_bad <= 1u) {
+                } else if ((v.dist || recs) && n_bad <= 1u) {
                     const uint32_t slot = atomicAdd(&s_npend, 1u);  // < 2 * THREADS: fewer than THREADS left over + THREADS new
                     s_pend[slot] = FxtPending{key, (uint32_t)i, (uint32_t)(i >> 32), found, npos};
                 } else {
@@ -693,6 +724,11 @@ static void fx_release(FeatureExtractorSet &X) {
 
 void cr_feature_extractors_free(crgpu_ctx *ctx) {
     for (int k = 0; k < CRGPU_MAX_LIB; k++) fx_release(ctx->fx[k]);
+    cr_drop_feature_pending(ctx);
+}
+void cr_drop_feature_pending(crgpu_ctx *ctx) {
+    if (ctx->fxp.d_recs) cr_pool_free(ctx, ctx->fxp.d_recs);  // stream-ordered: the pool reuses the block only for later work
+    ctx->fxp = FxPendingSet();
 }
 
 extern "C" int crgpu_set_feature_extractor(crgpu_ctx *ctx, int extractor, const crgpu_feature_def *defs, uint32_t n_defs,
@@ -854,6 +890,12 @@ extern "C" int crgpu_set_feature_extractor(crgpu_ctx *ctx, int extractor, const 
     if (pats.size() == 1 && pats[0].tethered && !pats[0].never) {
         const HostPattern &P0 = pats[0];
         X.one_tethered = true;
+        {
+            std::vector<std::pair<std::string, uint32_t>> fs(P0.feats);
+            std::sort(fs.begin(), fs.end());
+            X.sig = std::to_string(P0.read) + "|" + P0.regex;
+            for (const auto &f : fs) X.sig += "|" + f.first + ":" + std::to_string(f.second);
+        }
         X.t_read = (uint32_t)P0.read;
         X.t_anchor5 = P0.anchor5;
         X.t_anchor3 = P0.anchor3;
@@ -910,6 +952,25 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
     CR_REQUIRE(ctx, !X.uses_read[1] || (d_r2_seq && d_r2_qual && r2_stride), CRGPU_EINVAL,
                "the extractor holds R2 patterns but no R2 rows were given");
     CR_REQUIRE(ctx, r1_stride < (1u << 22) && r2_stride < (1u << 22), CRGPU_ERANGE, "rows longer than 4 Mi bases");
+    // the captures a distribution-less pass over these very rows kept (FxPendingSet): taken over before the by-products are dropped
+    const FeatureExtractorSet &X0 = ctx->fx[extractor];
+    FxPendingSet resume;
+    {
+        const FxPendingSet &Q = ctx->fxp;
+        const bool r2 = X0.t_read != 0;
+        if (ctx->trust_buffers && Q.valid && X0.one_tethered && X0.has_dist && Q.sig == X0.sig && Q.n == n &&
+            Q.d_seq == (r2 ? d_r2_seq : d_r1_seq) && Q.d_qual == (r2 ? d_r2_qual : d_r1_qual) && Q.d_len == (r2 ? d_r2_len : d_r1_len) &&
+            Q.stride == (r2 ? r2_stride : r1_stride) && Q.d_feature_out == d_feature_out && Q.d_n_ids_out == d_n_ids_out &&
+            Q.d_capture_out == d_capture_out && !getenv("CRGPU_FXT_NO_RESUME")) {
+            resume = ctx->fxp;
+            ctx->fxp = FxPendingSet();  // the block now belongs to this call
+        }
+    }
+    struct ResumeGuard {
+        crgpu_ctx *c;
+        void *p;
+        ~ResumeGuard() { cr_pool_free(c, p); }
+    } resume_guard{ctx, resume.d_recs};
     cr_invalidate(ctx);  // caller buffers are written: by-products of earlier calls are not trusted any more
     double pe[34];
     for (int q = 0; q < 34; q++) pe[q] = std::pow(10.0, -(double)q / 10.0);  // host libm as in :45
@@ -959,20 +1020,60 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
             }
             P.halves = X.has_dist && X.t_n_feat <= 1024u && X.t_L >= 2 && !getenv("CRGPU_FXT_PROBES");
             const size_t half_bytes = P.halves ? (size_t)X.t_n_feat * 24 : 0;
-            CrTimer t(ctx, CRGPU_T_FEATURE, n);
+            // first pass of the two-pass flow (no distribution, by-products allowed): keep the captures without exact feature
+            FxtPending *d_recs = (FxtPending *)resume.d_recs;
+            unsigned long long *d_rec_count = (unsigned long long *)(ctx->d_scalars + 66);
+            uint64_t rec_cap = 0, n_recs_in = resume.valid ? resume.n_recs : 0;
+            void *new_recs = nullptr;
+            const bool record = ctx->trust_buffers && !X.has_dist && !resume.valid && n >= 4096 && !getenv("CRGPU_FXT_NO_RESUME");
+            if (record) {
+                rec_cap = n / 2 + 1024;  // a third of the captures of a real library miss at most; more: the second pass reads the rows
+                if (cr_pool_alloc(ctx, &new_recs, rec_cap * sizeof(FxtPending)) == CRGPU_OK) {
+                    d_recs = (FxtPending *)new_recs;
+                    CR_HIP(ctx, hipMemsetAsync(d_rec_count, 0, sizeof(unsigned long long), ctx->stream));
+                } else {
+                    rec_cap = 0;
+                    (void)hipGetLastError();
+                }
+            }
+            const uint64_t work = n_recs_in ? n_recs_in : n;
+            CrTimer t(ctx, CRGPU_T_FEATURE, work);
             if (X.t_n_feat <= 1024u) {
                 const size_t lds = (size_t)slots * 12 + half_bytes + (size_t)4 * 64 * P.pitch * 4 + 8 + 2 * 256 * sizeof(FxtPending);
                 cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<256>, lds);
-                hipLaunchKernelGGL(k_extract_tethered_lds<256>, dim3(cr_grid(n, 256, 256u * 4u)), dim3(256), lds, ctx->stream, v, P,
-                                   d_pe, R, n, d_feature_out, d_n_ids_out, d_capture_out);
+                hipLaunchKernelGGL(k_extract_tethered_lds<256>, dim3(cr_grid(work, 256, 256u * 4u)), dim3(256), lds, ctx->stream, v, P,
+                                   d_pe, R, n, d_feature_out, d_n_ids_out, d_capture_out, rec_cap || n_recs_in ? d_recs : nullptr, d_rec_count,
+                                   rec_cap, n_recs_in);
             } else {
                 const size_t lds = (size_t)slots * 12 + (size_t)16 * 64 * P.pitch * 4 + 8 + 2 * 1024 * sizeof(FxtPending);
                 cr_allow_lds(ctx, (const void *)k_extract_tethered_lds<1024>, lds);
-                hipLaunchKernelGGL(k_extract_tethered_lds<1024>, dim3(cr_grid(n, 1024, 256u)), dim3(1024), lds, ctx->stream, v, P, d_pe,
-                                   R, n, d_feature_out, d_n_ids_out, d_capture_out);
+                hipLaunchKernelGGL(k_extract_tethered_lds<1024>, dim3(cr_grid(work, 1024, 256u)), dim3(1024), lds, ctx->stream, v, P, d_pe,
+                                   R, n, d_feature_out, d_n_ids_out, d_capture_out, rec_cap || n_recs_in ? d_recs : nullptr, d_rec_count,
+                                   rec_cap, n_recs_in);
             }
             CR_HIP(ctx, hipGetLastError());
             ctx->feature_fast_launches++;
+            if (n_recs_in) ctx->feature_resumed_reads += n_recs_in;
+            if (rec_cap) {
+                unsigned long long cnt = 0;
+                if (crgpu_memcpy_d2h(ctx, &cnt, d_rec_count, sizeof(cnt)) == CRGPU_OK && cnt <= rec_cap) {
+                    FxPendingSet &Q = ctx->fxp;
+                    Q.valid = true;
+                    Q.d_seq = R.seq;
+                    Q.d_qual = R.qual;
+                    Q.d_len = R.len;
+                    Q.n = n;
+                    Q.n_recs = cnt;
+                    Q.stride = R.stride;
+                    Q.d_feature_out = d_feature_out;
+                    Q.d_n_ids_out = d_n_ids_out;
+                    Q.d_capture_out = d_capture_out;
+                    Q.sig = X.sig;
+                    Q.d_recs = new_recs;
+                } else {
+                    cr_pool_free(ctx, new_recs);  // more captures than room: the pass with the distribution reads the rows
+                }
+            }
             return CRGPU_OK;
         }
     }

@@ -769,14 +769,18 @@ uint32_t cr_sort_low_bits(uint32_t total_bits, uint32_t umi_bits) {
     }
     // up to 10 low bits (round 3; 8 before): 64-bit keys (the 3M-february-2018 list) then sort in six 9-bit passes instead of
     // seven; at least 14 UMI bits (7 bases) stay above the cut, so runs of equal top bits that hold different UMIs stay rare
+    uint32_t best_low = 0, best_passes = full;
     for (uint32_t low = 1; low <= 10 && low < total_bits; low++) {
         const uint32_t top = total_bits - low;
         const uint32_t q8 = (top + 7) / 8, q9 = (top + 8) / 9;
-        if ((q9 < q8 ? q9 : q8) >= full) continue;               // saves nothing yet
+        const uint32_t q = q9 < q8 ? q9 : q8;
         // bit 0 is the UmiType bit, the UMI sits right above it: low - 1 of its bits fall below the cut
-        return umi_bits >= 14u + (low - 1u) ? low : 0u;
+        if (q < best_passes && umi_bits >= 14u + (low - 1u)) {  // the fewest passes; among equals the fewest low bits
+            best_passes = q;
+            best_low = low;
+        }
     }
-    return 0;
+    return best_low;
 }
 bool cr_sort_finish_experiment() {
     const char *e = getenv("CRGPU_SORT_FINISH");

@@ -120,6 +120,7 @@ int crgpu_invalidate(crgpu_ctx *ctx);
 #define CRGPU_STAT_K1_SPLIT_ROUNDS 3 /* table rounds of pass A whose histogram was split: table hits counted per slot in LDS, the other hits staged */
 #define CRGPU_STAT_FEATURE_READS_REQUEUED 2 /* reads of crgpu_extract_features_dev redone with the wide correction map */
 #define CRGPU_STAT_FEATURE_FAST_LAUNCHES 4 /* crgpu_extract_features_dev calls served by the one-tethered-pattern LDS kernel */
+#define CRGPU_STAT_FEATURE_RESUMED_READS 8 /* captures corrected from the records of the distribution-less pass (rows not read again) */
 #define CRGPU_STAT_COMM_BYTES_C1 5  /* bytes this rank contributed to the table all-reduces (C1) */
 #define CRGPU_STAT_COMM_BYTES_C2 6  /* bytes of molecule keys this rank put into key exchanges (C2; its own share included) */
 #define CRGPU_STAT_COMM_BYTES_C3 7  /* bytes of triplets this rank sent to the root of gathers (C3) */

@@ -376,17 +376,26 @@ def test_cfg4_one_flow_trans_whitelist_pattern_two_libraries():
         dev.append(d)
     d_rs, d_rq = c.upload(rows_s), c.upload(rows_q)
     d_f1 = c.empty(n1, np.uint32)
+    d_n_ids, d_cap = c.empty(n1, np.uint32), c.empty(n1, np.uint32)
     c.set_feature_extractor(1, defs)                                   # MAKE_SHARD: no distribution yet
-    c.extract_features(1, n1, d_f1, r2=(d_rs, d_rq, None, stride))
+    c.extract_features(1, n1, d_f1, r2=(d_rs, d_rq, None, stride), d_n_ids_out=d_n_ids, d_capture_out=d_cap)
     counts = c.feature_counts(d_f1, n1, n_feat_all)
     dist = E.compute_feature_dist(counts, types)
     c.set_feature_extractor(1, defs, dist)
     for d in dev:
         c.correct(d["cb"], d["cbq"], d["flags"], d["n"], d["idx"])
-    d_n_ids, d_cap = c.empty(n1, np.uint32), c.empty(n1, np.uint32)
+    # the pass with the distribution only corrects the captures the first pass kept (same rows, definitions and outputs, the
+    # context may keep by-products): the rows are not read again ...
     c.extract_features(1, n1, d_f1, r2=(d_rs, d_rq, None, stride), d_n_ids_out=d_n_ids, d_capture_out=d_cap)
     assert c.stat(4) == 2                                              # both passes took the one-pattern LDS kernel
-    got_f1 = d_f1.to_host()
+    resumed = c.stat(8)
+    assert 0 < resumed < n1 // 2, resumed                              # CRGPU_STAT_FEATURE_RESUMED_READS
+    got_f1, got_ids, got_cap = d_f1.to_host(), d_n_ids.to_host(), d_cap.to_host()
+    # ... and gives what a full pass over the rows gives (nothing kept: crgpu_invalidate)
+    c.invalidate()
+    c.extract_features(1, n1, d_f1, r2=(d_rs, d_rq, None, stride), d_n_ids_out=d_n_ids, d_capture_out=d_cap)
+    assert c.stat(8) == resumed and c.stat(4) == 3
+    assert np.array_equal(d_f1.to_host(), got_f1) and np.array_equal(d_n_ids.to_host(), got_ids) and np.array_equal(d_cap.to_host(), got_cap)
     idx_all = np.concatenate([dev[0]["idx"].to_host(), dev[1]["idx"].to_host()])
     n = n0 + n1
     feat_all = np.concatenate([r0["feature"], got_f1])
