@@ -57,6 +57,7 @@
 #endif
 #ifndef SORT_MAX_BLOCKS
 #define SORT_MAX_BLOCKS 1024
+#define OR_MAX_LOW_BITS 8u  // low key bits the finishing step may be left with (bucket arrays of or_run_through_memory)
 #endif
 
 // ---- exclusive scan of a small u32 array (block counts of the compactions), single workgroup -----
@@ -767,10 +768,12 @@ uint32_t cr_sort_low_bits(uint32_t total_bits, uint32_t umi_bits) {
         const uint32_t low = total_bits - 9 * p;          // <= 16 by construction
         return p < full ? low : 0;
     }
-    // up to 10 low bits (round 3; 8 before): 64-bit keys (the 3M-february-2018 list) then sort in six 9-bit passes instead of
-    // seven; at least 14 UMI bits (7 bases) stay above the cut, so runs of equal top bits that hold different UMIs stay rare
+    // at most 8 low bits: or_run_through_memory orders a long run by an in-place permutation over 2^low <= 256 buckets held in
+    // registers / scratch (ten bits -- 64-bit keys in six passes -- overran those arrays and hung the repair kernel on the
+    // 6.8 M-entry list: measured once, reverted); at least 14 UMI bits stay above the cut
+    static_assert(OR_MAX_LOW_BITS == 8, "or_run_through_memory: cnt[] / nxt[] hold 256 buckets");
     uint32_t best_low = 0, best_passes = full;
-    for (uint32_t low = 1; low <= 10 && low < total_bits; low++) {
+    for (uint32_t low = 1; low <= OR_MAX_LOW_BITS && low < total_bits; low++) {
         const uint32_t top = total_bits - low;
         const uint32_t q8 = (top + 7) / 8, q9 = (top + 8) / 9;
         const uint32_t q = q9 < q8 ? q9 : q8;
@@ -961,6 +964,10 @@ __device__ void or_run_through_memory(uint64_t *__restrict__ keys, uint32_t *__r
     // a long run that mixes low bits (many reads of one UMI with both UmiTypes, ...): in-place bucket permutation on the
     // low bits (American flag sort, at most 256 buckets)
     uint32_t cnt[256], nxt[256];
+    if (low > OR_MAX_LOW_BITS) {  // cannot happen (cr_sort_low_bits): never overrun the arrays, let the caller sort on all bits
+        atomicOr(bad, 1u);
+        return;
+    }
     const uint32_t nb = 1u << low, dm = nb - 1u;
     for (uint32_t d = 0; d < nb; d++) cnt[d] = 0;
     for (uint64_t a = i; a < e; a++) cnt[(uint32_t)keys[a] & dm]++;
