@@ -1342,28 +1342,14 @@ struct K2Params {
     uint32_t *idx_inout;
     uint8_t *corrected_out;
 };
-// where a corrected read's rank is counted: rank_sink == NULL -> one device-scope atomicAdd on the library's CORRECTED
-// table per corrected read (scattered atomics run at ~20 G/s: 17 % of K2's time at 1 B reads); otherwise the rank is
-// stored in *rank_sink (a compact, coalesced array) and the table is built afterwards by K1's staged LDS histogram
-
-// one missing read: i = index in the caller's arrays, key = packed barcode, f = flag byte
-template <bool UNIFORM>
-__device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Params &P, uint64_t i, uint32_t key, uint32_t f,
-                                               uint32_t *rank_sink = nullptr) {
+// qualities of read i (bit 7 = N), kept in two 64-bit registers: byte k of (lo, hi) = position k
+struct K2Qual {
+    unsigned long long lo, hi;
+};
+// false: the read cannot be corrected (no qualities and an N somewhere: its position is unknown)
+__device__ __forceinline__ bool k2_load_qual(const K2Params &P, uint64_t i, uint32_t f, K2Qual &q) {
     const uint8_t *__restrict__ qualn = P.qualn;
     const uint32_t len = P.len;
-    const double *__restrict__ ptab = P.ptab;
-    const double max_expected = P.max_expected, thresh = P.thresh;
-    const bool check_expected = P.check_expected;
-    uint32_t *__restrict__ idx_inout = P.idx_inout;
-    uint8_t *__restrict__ corrected_out = P.corrected_out;
-    const uint32_t lib = UNIFORM ? 0u : (f & CRGPU_FLAG_LIB_MASK);
-    if (UNIFORM && (f & CRGPU_FLAG_LIB_MASK) != vs.ulib) return;
-    const WlView &w = vs.v[lib];
-    if (!UNIFORM && w.n == 0) return;
-
-    // qualities (bit 7 = N), kept in two 64-bit registers: byte k of (qlo,qhi) = position k
-    unsigned long long qlo, qhi;
 #ifdef K2_EXP_NO_QUAL
     if (false) {
 #else
@@ -1372,23 +1358,63 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
         if (len == 16) {
             const cr_u32x4 qv = CR_LOAD_STREAM(reinterpret_cast<const cr_u32x4 *>(qualn + i * 16));
             const uint4 q4 = make_uint4(qv.x, qv.y, qv.z, qv.w);
-            qlo = (unsigned long long)q4.x | ((unsigned long long)q4.y << 32);
-            qhi = (unsigned long long)q4.z | ((unsigned long long)q4.w << 32);
+            q.lo = (unsigned long long)q4.x | ((unsigned long long)q4.y << 32);
+            q.hi = (unsigned long long)q4.z | ((unsigned long long)q4.w << 32);
         } else {
-            qlo = 0ull;
-            qhi = 0ull;
+            q.lo = 0ull;
+            q.hi = 0ull;
             for (uint32_t k = 0; k < len; k++) {
                 const unsigned long long b = qualn[i * len + k];
-                if (k < 8) qlo |= b << (8 * k); else qhi |= b << (8 * (k - 8));
+                if (k < 8) q.lo |= b << (8 * k); else q.hi |= b << (8 * (k - 8));
             }
         }
     } else {
-        qlo = qhi = 0x4242424242424242ull;      // BC_MAX_QV = 66, corrector.rs:126 map_or
-        if (f & CRGPU_FLAG_CB_HAS_N) return;   // N position unknown without qualities
+        q.lo = q.hi = 0x4242424242424242ull;         // BC_MAX_QV = 66, corrector.rs:126 map_or
+        if (f & CRGPU_FLAG_CB_HAS_N) return false;  // N position unknown without qualities
     }
-    // movemask of the N bits: bit k = position k
-    const uint32_t nmask = (uint32_t)(((qlo & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56) |
-                           ((uint32_t)(((qhi & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56) << 8);
+    return true;
+}
+// movemask of the N bits: bit k = position k
+__device__ __forceinline__ uint32_t k2_nmask(const K2Qual &q) {
+    return (uint32_t)(((q.lo & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56) |
+           ((uint32_t)(((q.hi & 0x8080808080808080ull) * 0x0002040810204081ull) >> 56) << 8);
+}
+__device__ __forceinline__ uint32_t k2_qv(const K2Qual &q, uint32_t pos) {
+    const uint32_t qv = (uint32_t)((pos < 8u ? q.lo : q.hi) >> (8u * (pos & 7u))) & 0x7Fu;
+    return qv < 66u ? qv : 66u;  // corrector.rs:126
+}
+// the running maximum and sum of the likelihoods, candidates fed in position-major, A<C<G<T order (corrector.rs:146)
+struct K2Best {
+    bool have = false;
+    double like = 0.0, total = 0.0;
+    uint32_t rank = 0;
+    __device__ __forceinline__ void feed(double l, uint32_t r) {
+        if (!have) {
+            have = true;
+            like = l;
+            rank = r;
+        } else if (l > like || (l == like && r >= rank)) {
+            // Ord::max on (NotNan, BarcodeSegment): ties go to the larger sequence == larger rank
+            like = l;
+            rank = r;
+        }
+        total += l;
+    }
+};
+// the acceptance test (corrector.rs:152-160): the rank the read is corrected to, or CRGPU_MISS
+__device__ __forceinline__ uint32_t k2_accept(const K2Params &P, const K2Qual &q, const K2Best &b) {
+    if (!b.have) return CRGPU_MISS;
+    double expected = 0.0;  // :154, uncapped qualities, in order; 0.0 without qualities
+    if (P.check_expected)
+        for (uint32_t k = 0; k < P.len; k++) expected += P.ptab[(uint32_t)((k < 8u ? q.lo : q.hi) >> (8u * (k & 7u))) & 0x7Fu];
+    return (expected < P.max_expected && b.like / b.total >= P.thresh) ? b.rank : CRGPU_MISS;
+}
+
+// one missing read on its own: both pigeonhole bins scanned by this lane.  Returns the rank or CRGPU_MISS.
+__device__ __forceinline__ uint32_t k2_solve_own(const WlView &w, const K2Params &P, uint32_t key, const K2Qual &q) {
+    const uint32_t len = P.len;
+    const double *__restrict__ ptab = P.ptab;
+    const uint32_t nmask = k2_nmask(q);
     const int n_n = __popc(nmask);
 
     // candidate slots: bit (pos*4 + base)
@@ -1424,13 +1450,24 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
     } else if (n_n == 1) {
         // the N is "observed": all four bases are tried at its position (corrector.rs:128-131);
         // a candidate built at any other position still contains the N and cannot match.
+        // The four exact lookups and then the four prior counts are independent loads: issued together (as a loop over the
+        // candidate mask they were a chain of twelve dependent loads, and a tenth of the misses of the cfg3 model are such reads)
         const uint32_t pos = (uint32_t)__ffs((int)nmask) - 1u;
-        cand = 0xFull << (pos * 4u);
+        const uint32_t sh = 2u * (len - 1u - pos);
+        uint32_t r4[4], c4[4];
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) r4[b] = wl_lookup(w, (key & ~(3u << sh)) | (b << sh));
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) c4[b] = r4[b] != CRGPU_MISS ? w.prior[r4[b]] : 0u;
+        const double pq = ptab[k2_qv(q, pos)];
+        K2Best best;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++)
+            if (r4[b] != CRGPU_MISS) best.feed(pq * (double)(1ll + (long long)c4[b]), r4[b]);  // :138-141, A<C<G<T
+        return k2_accept(P, q, best);
     }
 
-    bool have_best = false;
-    double best_like = 0.0, total = 0.0;
-    uint32_t best_rank = 0;
+    K2Best best;
     const bool lone = n_n == 0 && (cand & (cand - 1ull)) == 0ull;  // exactly one candidate, already known to be listed
     while (cand) {
         const uint32_t slot = (uint32_t)__ffsll((long long)cand) - 1u;
@@ -1441,46 +1478,50 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
         // a lone tail mutation was seen in bin A at posA: no second lookup (offE + tail lines) for its rank
         const uint32_t r = (nA == 1u && pos >= tail_from) ? (w.valA ? w.valA[posA] : posA) : wl_lookup(w, ckey);
         if (r == CRGPU_MISS) continue;
-        uint32_t qv = (uint32_t)((pos < 8u ? qlo : qhi) >> (8u * (pos & 7u))) & 0x7Fu;
-        qv = qv < 66u ? qv : 66u;                                  // corrector.rs:126
+        const uint32_t qv = k2_qv(q, pos);
         if (lone && ptab[qv] > 0.0) {
             // the only candidate: likelihood / total == x / x == 1.0 for any positive finite x, whatever the
             // prior count is -- skip its random 4-byte load (the tables are 3x the L2 of an XCD)
-            have_best = true;
-            best_like = total = 1.0;
-            best_rank = r;
+            best.have = true;
+            best.like = best.total = 1.0;
+            best.rank = r;
             break;
         }
         const long long bc_count = 1ll + (long long)w.prior[r];    // Laplace smoothing, :138-139
-        const double like = ptab[qv] * (double)bc_count;           // :140-141
-        if (!have_best) {
-            have_best = true;
-            best_like = like;
-            best_rank = r;
-        } else if (like > best_like || (like == best_like && r >= best_rank)) {
-            // Ord::max on (NotNan, BarcodeSegment): ties go to the larger sequence == larger rank
-            best_like = like;
-            best_rank = r;
-        }
-        total += like;  // pos-major, A<C<G<T order (:146)
+        best.feed(ptab[qv] * (double)bc_count, r);                  // :140-141
     }
-    if (!have_best) return;
-    double expected = 0.0;  // :154, uncapped qualities, in order; 0.0 without qualities
-    if (check_expected)
-        for (uint32_t k = 0; k < len; k++)
-            expected += ptab[(uint32_t)((k < 8u ? qlo : qhi) >> (8u * (k & 7u))) & 0x7Fu];
-    if (expected < max_expected && best_like / total >= thresh) {
+    return k2_accept(P, q, best);
+}
+
+// what a correction leaves behind.  rank_sink == NULL -> one device-scope atomicAdd on the library's CORRECTED table
+// (scattered atomics run at ~20 G/s: 17 % of K2's time at 1 B reads); otherwise the rank is stored in *rank_sink (a
+// compact, coalesced array) and the table is built afterwards by K1's staged LDS histogram
+__device__ __forceinline__ void k2_commit(const WlView &w, const K2Params &P, uint64_t i, uint32_t rank, uint32_t *rank_sink,
+                                          bool count = true, bool flag = true) {
+    if (rank == CRGPU_MISS) return;
 #ifndef K2_EXP_NO_IDX   // cost-attribution builds (scripts/ab.sh): results are wrong without these stores
-        CR_STORE_STREAM(best_rank, &idx_inout[i]);
+    CR_STORE_STREAM(rank, &P.idx_inout[i]);
 #endif
-        if (corrected_out) corrected_out[i] = 1;
+    if (flag && P.corrected_out) P.corrected_out[i] = 1;
 #ifndef K2_EXP_NO_ATOMIC
-        if (rank_sink)
-            CR_STORE_STREAM(best_rank, rank_sink);
-        else
-            atomicAdd(&w.corrected[best_rank], 1u);
+    if (rank_sink)
+        CR_STORE_STREAM(rank, rank_sink);
+    else if (count)
+        atomicAdd(&w.corrected[rank], 1u);
 #endif
-    }
+}
+
+// one missing read: i = index in the caller's arrays, key = packed barcode, f = flag byte
+template <bool UNIFORM>
+__device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Params &P, uint64_t i, uint32_t key, uint32_t f,
+                                               uint32_t *rank_sink = nullptr) {
+    const uint32_t lib = UNIFORM ? 0u : (f & CRGPU_FLAG_LIB_MASK);
+    if (UNIFORM && (f & CRGPU_FLAG_LIB_MASK) != vs.ulib) return;
+    const WlView &w = vs.v[lib];
+    if (!UNIFORM && w.n == 0) return;
+    K2Qual q;
+    if (!k2_load_qual(P, i, f, q)) return;
+    k2_commit(w, P, i, k2_solve_own(w, P, key, q), rank_sink);
 }
 
 // the misses as a list of read indices (k_collect_miss); run_if_zero (nullable): do nothing if *run_if_zero != 0 ...
@@ -1520,6 +1561,236 @@ __global__ __launch_bounds__(256) void k_correct_records(const WlViewSet vs, con
             if (sink) *sink = CRGPU_MISS;
             k2_correct_one<true>(vs, P, CR_LOAD_STREAM(&rec_i[o]), CR_LOAD_STREAM(&rec_key[o]), CR_LOAD_STREAM(&rec_fl[o]), sink);
         }
+    }
+}
+
+// ---- K2 over the misses in BARCODE order ----------------------------------------------------------------------------
+// A miss is a whitelist barcode with one substitution, and the same wrong sequence comes back many times (a cell's 10^4 - 10^5
+// reads put ~8 % of them on its 48 neighbours: runs of a hundred equal keys once the misses are sorted).  The candidate set of
+// a miss -- which listed barcodes lie one substitution away, their ranks and prior counts -- depends on its sequence only, so a
+// wave that holds 64 consecutive sorted misses finds it ONCE per run of equal keys and lets the lanes of the run weigh the
+// candidates with their own qualities.  With the 6.8 M-entry list the two pigeonhole bins hold ~104 entries each and the
+// per-read scan took ~9 L2 misses and 1 KB of table lines per miss.
+// The kernel is bound by dependent loads, so the search is laid out flat: up to KS_HEADS runs of the wave are taken together;
+// the first lane of every run fetches its four bin bounds; the bins are cut into items of 8 entries (one 16-byte load) and ALL
+// items of all the runs are spread over the 64 lanes, so the whole search is one or two rounds of independent loads whatever
+// the bin length; a hit leaves its rank in the run's slot table in LDS (slot = position * 4 + base: at most one
+// listed barcode per slot, and ascending slots are the accumulation order of corrector.rs:146).  Accumulation, tie rule and
+// acceptance test are the ones of k2_solve_own (same K2Best / k2_accept).
+// Reads with an N are not in the list: k_compact_records hands them to k_correct (the flag byte decides, as it does in pass A --
+// CRGPU_FLAG_CB_HAS_N is set by the pack kernels whenever bit 7 of a quality byte is).  Their four candidates sit at the N,
+// they need their quality line and the prior counts, and 10 % of the misses of the cfg3 model are such reads: inside this
+// kernel (tried: marked in bit 31 of the index, candidates from the run's slot table plus an exact-match note) every wave
+// held a few and waited for their loads, 3.2 -> 5.1 ms, which is what k_correct takes for them on its own.  Where the kernel
+// reads the qualities of a read and finds an unannounced N, the read is appended to k_correct's list from here.  Corrected ranks are counted per run of equal ranks: one atomic per run.
+#define KS_WAVES 4
+#define KS_HEADS 8
+__global__ __launch_bounds__(64 * KS_WAVES) void k_correct_sorted(const WlViewSet vs, const uint32_t *__restrict__ skey,
+                                                                  const uint32_t *__restrict__ sidx, uint32_t n_miss,
+                                                                  const K2Params P, uint32_t *__restrict__ late_list,
+                                                                  unsigned long long *__restrict__ n_late) {
+    __shared__ uint32_t s_rank[KS_WAVES][KS_HEADS][64], s_mask[KS_WAVES][KS_HEADS][2];
+    __shared__ uint32_t s_run[KS_WAVES][KS_HEADS][5];          // key, a_lo, a_hi, b_lo, b_hi of the batch's runs
+    __shared__ uint32_t s_first[KS_WAVES][2 * KS_HEADS + 1];   // first item of (run, bin); [2 * KS_HEADS] = number of items
+    const WlView &w = vs.v[0];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t len = P.len;
+    const uint32_t n_chunks = (n_miss + 63u) / 64u;
+    const uint32_t hA = w.bitsA >> 1;
+    const uint32_t tail_mask = (1u << w.bitsB) - 1u;
+    const uint32_t *__restrict__ tA = reinterpret_cast<const uint32_t *>(w.tailA);
+    const uint32_t *__restrict__ hB = reinterpret_cast<const uint32_t *>(w.headB);
+    const uint32_t c_first = blockIdx.x * KS_WAVES + wv, c_step = gridDim.x * KS_WAVES;
+    uint32_t key_next = c_first * 64u + lane < n_miss ? skey[c_first * 64u + lane] : 0xFFFFFFFFu;
+    uint32_t i_next = c_first * 64u + lane < n_miss ? sidx[c_first * 64u + lane] : 0xFFFFFFFFu;
+    for (uint32_t c = c_first; c < n_chunks; c += c_step) {
+        const uint32_t key = key_next, i = i_next;
+        {   // the next chunk's keys are on their way while this one is searched
+            const uint32_t pn = (c + c_step) * 64u + lane;
+            const bool ok = c + c_step < n_chunks && pn < n_miss;
+            key_next = ok ? skey[pn] : 0xFFFFFFFFu;
+            i_next = ok ? sidx[pn] : 0xFFFFFFFFu;
+        }
+        // A read whose run has ONE candidate is corrected to it whatever its qualities are (likelihood / total == x / x == 1.0 for
+        // the positive finite x that any quality gives; corrector.rs:140-152) unless the expected-error veto is on: only the
+        // reads of runs with several candidates fetch their quality line -- the random 64-byte access that bounds this kernel.
+        const bool need_qual_always = P.check_expected;
+        K2Qual q{0ull, 0ull};
+        bool usable = i != 0xFFFFFFFFu;  // (records of another library / with an N carry no index)
+        bool have_q = false;
+        if (usable && need_qual_always) {
+            usable = k2_load_qual(P, i, 0u, q);
+            have_q = true;
+        }
+        const uint32_t left = __shfl_up(key, 1);
+        const bool is_head = lane == 0u || key != left;
+        const unsigned long long heads = __ballot(is_head), want = __ballot(usable);
+        const uint32_t my_run = (uint32_t)__popcll(heads & (~0ull >> (63u - lane))) - 1u;  // my run's number in the wave
+        const uint32_t n_runs = (uint32_t)__popcll(heads);
+        // (a head lane) does any lane of my run want the candidates?
+        const unsigned long long above = lane == 63u ? 0ull : heads >> (lane + 1u);
+        const uint32_t run_len = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+        const unsigned long long run_lanes = (run_len >= 64u ? ~0ull : ((1ull << run_len) - 1ull)) << lane;
+        const bool run_wanted = is_head && (want & run_lanes) != 0ull;
+        uint32_t rank = CRGPU_MISS;
+        for (uint32_t r0 = 0; r0 < n_runs; r0 += KS_HEADS) {  // wave-uniform
+            const bool in_batch = my_run >= r0 && my_run < r0 + KS_HEADS;
+            const bool mine = usable && in_batch;
+            if (__ballot(mine) == 0ull) continue;
+            const uint32_t b = my_run - r0;  // (lanes of the batch)
+            if (lane < KS_HEADS) s_run[wv][lane][1] = s_run[wv][lane][2] = s_run[wv][lane][3] = s_run[wv][lane][4] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (is_head && in_batch && run_wanted) {
+                const U32x2 a2 = *reinterpret_cast<const U32x2 *>(w.offA + (key >> w.bitsB));
+                const U32x2 b2 = *reinterpret_cast<const U32x2 *>(w.offB + (key & tail_mask));
+                s_run[wv][b][0] = key;
+                s_run[wv][b][1] = a2.a;
+                s_run[wv][b][2] = a2.b;
+                s_run[wv][b][3] = b2.a;
+                s_run[wv][b][4] = b2.b;
+                s_mask[wv][b][0] = 0u;
+                s_mask[wv][b][1] = 0u;
+            }
+            __builtin_amdgcn_wave_barrier();
+            {   // lanes 0 .. 2 * KS_HEADS - 1: items of 8 entries in (run, bin) = lane; exclusive prefix over these lanes
+                uint32_t cnt = 0;
+                if (lane < 2u * KS_HEADS) {
+                    const uint32_t lo = s_run[wv][lane >> 1][1u + 2u * (lane & 1u)], hi = s_run[wv][lane >> 1][2u + 2u * (lane & 1u)];
+                    cnt = hi > lo ? (hi - (lo & ~1u) + 7u) / 8u : 0u;
+                }
+                uint32_t inc = cnt;
+#pragma unroll
+                for (uint32_t d = 1; d < 2u * KS_HEADS; d <<= 1) {
+                    const uint32_t y = __shfl_up(inc, d);
+                    if (lane >= d) inc += y;
+                }
+                if (lane < 2u * KS_HEADS) s_first[wv][lane] = inc - cnt;
+                if (lane == 2u * KS_HEADS - 1u) s_first[wv][2 * KS_HEADS] = inc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t total = s_first[wv][2 * KS_HEADS];
+            for (uint32_t it0 = 0; it0 < total; it0 += 64u) {  // wave-uniform
+                const uint32_t it = it0 + lane;
+                if (it >= total) continue;
+                uint32_t g = 0;  // the last (run, bin) whose first item is <= it (empty ones share their successor's first item)
+#pragma unroll
+                for (uint32_t k = 1; k < 2u * KS_HEADS; k++) g += s_first[wv][k] <= it ? 1u : 0u;
+                const uint32_t rb = g >> 1;
+                const bool binB = (g & 1u) != 0u;
+                const uint32_t qk = s_run[wv][rb][0];
+                const uint32_t lo = s_run[wv][rb][binB ? 3 : 1], hi = s_run[wv][rb][binB ? 4 : 2];
+                const uint32_t e0 = (lo & ~1u) + 8u * (it - s_first[wv][g]);
+                const U32x4 d = *reinterpret_cast<const U32x4 *>((binB ? hB : tA) + (e0 >> 1));  // (tables padded by 32 bytes)
+                const uint32_t other = binB ? qk >> w.bitsB : qk & tail_mask;  // the half that may differ in one base
+                uint32_t hits = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t v = (d.w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                    if (e0 + k >= lo && e0 + k < hi && one_base_diff(v, other) >= 0) hits |= 1u << k;
+                }
+                while (hits) {
+                    const uint32_t k = (uint32_t)__ffs((int)hits) - 1u;
+                    hits &= hits - 1u;
+                    const uint32_t dw = (k & 4u) ? ((k & 2u) ? d.w[3] : d.w[2]) : ((k & 2u) ? d.w[1] : d.w[0]);  // (no indexed register file)
+                    const uint32_t v = (dw >> (16u * (k & 1u))) & 0xFFFFu;
+                    const uint32_t bo = (uint32_t)one_base_diff(v, other);
+                    const uint32_t base = (v >> bo) & 3u;
+                    uint32_t pos, r;
+                    if (!binB) {  // mutation in the tail: bin A is the sorted whitelist itself, position -> rank
+                        pos = len - 1u - (bo >> 1);
+                        r = w.valA ? w.valA[e0 + k] : e0 + k;
+                    } else {      // mutation in the head: table B carries the ranks of its entries
+                        pos = hA - 1u - (bo >> 1);
+                        r = w.valB[e0 + k];
+                    }
+                    const uint32_t slot = pos * 4u + base;
+                    s_rank[wv][rb][slot] = r;  // (its prior count is only needed when the run has a second candidate: fetched there)
+                    atomicOr(&s_mask[wv][rb][slot >> 5], 1u << (slot & 31u));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                unsigned long long cand = (unsigned long long)s_mask[wv][b][0] | ((unsigned long long)s_mask[wv][b][1] << 32);
+                if (cand && (cand & (cand - 1ull)) == 0ull && !need_qual_always) {
+                    if (1.0 >= P.thresh && 0.0 < P.max_expected) rank = s_rank[wv][b][(uint32_t)__ffsll((long long)cand) - 1u];  // k2_accept for like == total, expected == 0
+                } else if (cand) {
+                    if (!have_q) (void)k2_load_qual(P, i, 0u, q);
+                    if (k2_nmask(q) != 0u) {  // an N the flag byte did not announce: k_correct takes the read
+                        late_list[atomicAdd(n_late, 1ull)] = i;
+                    } else {
+                        K2Best best;
+                        while (cand) {
+                            const uint32_t slot = (uint32_t)__ffsll((long long)cand) - 1u;
+                            cand &= cand - 1ull;
+                            const uint32_t r = s_rank[wv][b][slot];
+                            const long long bc_count = 1ll + (long long)w.prior[r];        // Laplace smoothing, :138-139
+                            best.feed(P.ptab[k2_qv(q, slot >> 2)] * (double)bc_count, r);  // :140-141
+                        }
+                        rank = k2_accept(P, q, best);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // (the `corrected` bytes are written afterwards in read order, k_flag_corrected: a third random access per miss here)
+        k2_commit(w, P, i, rank, nullptr, false, false);
+#ifndef K2_EXP_NO_ATOMIC
+        {   // one atomic per run of equal corrected ranks (a run of equal keys almost always agrees on its rank)
+            const uint32_t lr = __shfl_up(rank, 1);
+            const unsigned long long starts = __ballot(lane == 0u || rank != lr);
+            const unsigned long long ab = lane == 63u ? 0ull : starts >> (lane + 1u);
+            const uint32_t rl = ab ? (uint32_t)__ffsll((long long)ab) : 64u - lane;
+            if (((starts >> lane) & 1ull) && rank != CRGPU_MISS) atomicAdd(&w.corrected[rank], rl);
+        }
+#endif
+    }
+}
+
+// after k_correct_sorted, in record (= read) order: a recorded miss of the call's library whose index is no longer MISS was corrected
+__global__ __launch_bounds__(256) void k_flag_corrected(const uint32_t *__restrict__ rec_i, const uint8_t *__restrict__ rec_fl,
+                                                        const uint32_t *__restrict__ rec_count, uint32_t rec_cap, uint32_t rec_regions,
+                                                        uint32_t ulib, const uint32_t *__restrict__ idx, uint8_t *__restrict__ corrected) {
+    if (rec_count[rec_regions] != 0u) return;
+    for (uint32_t r = blockIdx.x; r < rec_regions; r += gridDim.x) {
+        const uint32_t cnt = rec_count[r];
+        for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
+            const uint64_t o = (uint64_t)r * rec_cap + p;
+            if ((CR_LOAD_STREAM(&rec_fl[o]) & CRGPU_FLAG_LIB_MASK) != ulib) continue;
+            const uint32_t i = CR_LOAD_STREAM(&rec_i[o]);
+            if (idx[i] != CRGPU_MISS) corrected[i] = 1;
+        }
+    }
+}
+
+// K1's miss records (one region per wave of the lookup, `cap` slots each) -> dense (key, read index) arrays for the sort.
+// Records of another library keep their place with index 0xFFFFFFFF (k_correct_sorted skips them), and so do the reads with
+// an N, whose read indices are appended to the miss list that k_correct works through (one reservation per workgroup and
+// region).
+__global__ __launch_bounds__(256) void k_compact_records(const uint32_t *__restrict__ rec_i, const uint32_t *__restrict__ rec_key,
+                                                         const uint8_t *__restrict__ rec_fl, const uint32_t *__restrict__ rec_count,
+                                                         uint32_t rec_cap, uint32_t rec_regions, const uint32_t *__restrict__ rec_off,
+                                                         uint32_t ulib, uint32_t *__restrict__ out_key, uint32_t *__restrict__ out_i,
+                                                         uint32_t *__restrict__ miss_list, unsigned long long *__restrict__ n_miss) {
+    __shared__ __attribute__((aligned(8))) uint32_t lds[10];
+    if (rec_count[rec_regions] != 0u) return;
+    for (uint32_t r = blockIdx.x; r < rec_regions; r += gridDim.x) {
+        const uint32_t cnt = rec_count[r], base = rec_off[r];
+        uint32_t n_mine = 0;
+        for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
+            const uint64_t o = (uint64_t)r * rec_cap + p;
+            const uint32_t fl = CR_LOAD_STREAM(&rec_fl[o]);
+            const bool lib_ok = (fl & CRGPU_FLAG_LIB_MASK) == ulib, has_n = (fl & CRGPU_FLAG_CB_HAS_N) != 0u;
+            out_key[base + p] = CR_LOAD_STREAM(&rec_key[o]);
+            out_i[base + p] = lib_ok && !has_n ? CR_LOAD_STREAM(&rec_i[o]) : 0xFFFFFFFFu;
+            n_mine += lib_ok && has_n ? 1u : 0u;
+        }
+        unsigned long long o_n = block_reserve_256(n_mine, n_miss, lds);
+        if (n_mine)
+            for (uint32_t p = threadIdx.x; p < cnt; p += 256) {
+                const uint64_t o = (uint64_t)r * rec_cap + p;
+                const uint32_t fl = rec_fl[o];
+                if ((fl & CRGPU_FLAG_LIB_MASK) == ulib && (fl & CRGPU_FLAG_CB_HAS_N)) miss_list[o_n++] = rec_i[o];
+            }
     }
 }
 
@@ -1604,12 +1875,74 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
         hipLaunchKernelGGL(k_collect_miss, dim3(cr_grid(n, 256)), dim3(256), 0, ctx->stream, d_idx_inout, n, 0u,
                            (const uint32_t *)nullptr, miss_list, n_miss);
     }
+    // Barcode order (k_correct_sorted) for the recorded misses: pays once the pigeonhole bins are long (the 6.8 M-entry list:
+    // ~104 entries per bin against ~11 with 737 K); CRGPU_K2_SORTED=0/1 forces either way.  The reads with an N join the
+    // miss list of the k_correct launch below.
+    bool sorted = use_rec && uniform && d_qualn && (uint64_t)rec.regions * rec.cap < 0xFFFFFFFFull;
+    if (const char *g = getenv("CRGPU_K2_SORTED")) sorted = sorted && atoi(g) != 0;
+    else sorted = sorted && ctx->n_canon > (1u << 21);
+    int sorted_rc = CRGPU_OK;
+    if (sorted) {
+        uint32_t *d_o = nullptr, *d_k = nullptr, *d_v = nullptr, *d_kt = nullptr, *d_vt = nullptr;
+        int rc = cr_pool_alloc(ctx, (void **)&d_o, (rec.regions + 1) * sizeof(uint32_t));
+        uint32_t total = 0;
+        if (rc == CRGPU_OK) {
+            hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, rec.d_count, rec.regions, d_o);
+            rc = crgpu_memcpy_d2h(ctx, &total, d_o + rec.regions, sizeof(total));  // 0 when the records overflowed
+        }
+        if (rc == CRGPU_OK && total) {
+            const uint64_t bytes = (uint64_t)total * sizeof(uint32_t);
+            if (cr_pool_alloc(ctx, (void **)&d_k, bytes) != CRGPU_OK || cr_pool_alloc(ctx, (void **)&d_v, bytes) != CRGPU_OK ||
+                cr_pool_alloc(ctx, (void **)&d_kt, bytes) != CRGPU_OK || cr_pool_alloc(ctx, (void **)&d_vt, bytes) != CRGPU_OK)
+                rc = cr_fail(ctx, CRGPU_ENOMEM, "crgpu_correct: no memory for the sorted misses");
+        }
+        if (rc == CRGPU_OK && total) {
+            hipLaunchKernelGGL(k_compact_records, dim3(rec.regions), dim3(256), 0, ctx->stream, rec.d_i, rec.d_key, rec.d_fl, rec.d_count,
+                               rec.cap, rec.regions, d_o, vs.ulib, d_k, d_v, miss_list, n_miss);
+            bool in_tmp = false;
+            {   // the passes of this sort belong to the CORRECT span that is already open (on its own the 32-bit sort books
+                // itself under the count stage, whose candidate sort it normally is)
+                const bool timing = ctx->timing;
+                ctx->timing = false;
+                const uint32_t kb = 2u * ctx->cb_len;
+                uint32_t sb = kb;
+                if (const char *g = getenv("CRGPU_K2_SORT_BITS")) sb = (uint32_t)atoi(g);  // A/B: only the top bits
+                if (sb < 8u || sb > kb) sb = kb;
+                rc = cr_radix_sort_u32(ctx, d_k, d_kt, d_v, d_vt, total, kb - sb, kb, &in_tmp);
+                ctx->timing = timing;
+            }
+            if (rc == CRGPU_OK) {
+                const uint32_t chunks = (total + 63u) / 64u;
+                const uint32_t wgs = (chunks + KS_WAVES - 1) / KS_WAVES;
+                uint32_t per_cu = 16u;
+                if (const char *g = getenv("CRGPU_K2_WGS")) per_cu = (uint32_t)atoi(g);  // A/B
+                if (per_cu < 1u || per_cu > 64u) per_cu = 16u;
+                hipLaunchKernelGGL(k_correct_sorted, dim3(wgs < 256u * per_cu ? wgs : 256u * per_cu), dim3(64 * KS_WAVES), 0, ctx->stream, vs,
+                                   in_tmp ? d_kt : d_k, in_tmp ? d_vt : d_v, total, P, miss_list, n_miss);
+                if (d_corrected_out)
+                    hipLaunchKernelGGL(k_flag_corrected, dim3(rec.regions), dim3(256), 0, ctx->stream, rec.d_i, rec.d_fl, rec.d_count,
+                                       rec.cap, rec.regions, vs.ulib, d_idx_inout, d_corrected_out);
+                if (hipGetLastError() != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "crgpu_correct: launch failed");
+            }
+        }
+        cr_pool_free(ctx, d_o);
+        cr_pool_free(ctx, d_k);
+        cr_pool_free(ctx, d_v);
+        cr_pool_free(ctx, d_kt);
+        cr_pool_free(ctx, d_vt);
+        sorted_rc = rc;
+    }
     // K2 is launched for the worst case and loops over the device-side count: no host round trip
     const dim3 grid(cr_grid((use_rec ? rec.first + n / 64 : n) / 8 + 1, 256)), block(256);
     if (uniform)
         hipLaunchKernelGGL(k_correct<true>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, miss_list, n_miss, P);
     else
         hipLaunchKernelGGL(k_correct<false>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, miss_list, n_miss, P);
+    if (sorted) {
+        CR_HIP(ctx, hipGetLastError());
+        cr_drop_miss_records(ctx);  // stream-ordered: the pool reuses the blocks only for later work
+        return sorted_rc;
+    }
     if (use_rec) {
         // the corrected ranks of the records go to a compact array and are counted by K1's staged LDS histogram (when its
         // bucket plan applies: one library, at most 31 rank buckets) instead of one scattered atomic per corrected read

@@ -112,6 +112,7 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
     const uint32_t maskB = (uint32_t)((1ull << bitsB) - 1);
     std::vector<uint32_t> offA((1u << bitsA) + 1, 0), offB((1u << bitsB) + 1, 0), valA(m);
     std::vector<uint16_t> tailA(m), headB(m);
+    std::vector<uint32_t> valB(m);
     bool identity = true;
     for (uint32_t p = 0; p < m; p++) {
         const uint32_t head = (uint32_t)((uint64_t)uniq[p].key >> bitsB), tail = uniq[p].key & maskB;
@@ -128,6 +129,7 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
         std::vector<uint32_t> cur(offB.begin(), offB.end() - 1);
         for (uint32_t p = 0; p < m; p++) {
             const uint32_t head = (uint32_t)((uint64_t)uniq[p].key >> bitsB), tail = uniq[p].key & maskB;
+            valB[cur[tail]] = uniq[p].val;
             headB[cur[tail]++] = (uint16_t)head;
         }
     }
@@ -155,6 +157,7 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
     if (!identity) CR_TRY(upload(ctx, &w.d_valA, valA));
     CR_TRY(upload(ctx, &w.d_offB, offB));
     CR_TRY(upload(ctx, &w.d_headB, headB));
+    CR_TRY(upload(ctx, &w.d_valB, valB));
     std::vector<uint32_t> zeros(n_canon, 0);
     CR_TRY(upload(ctx, &w.d_valid, zeros));
     CR_TRY(upload(ctx, &w.d_corrected, zeros));
@@ -409,6 +412,7 @@ int cr_make_views(crgpu_ctx *ctx, WlView *views) {
             v.offE = w.d_offE;
             v.shiftE = w.shiftE;
             v.headB = w.d_headB;
+            v.valB = w.d_valB;
             v.valid = w.d_valid;
             v.corrected = w.d_corrected;
             v.prior = w.d_prior_override ? w.d_prior_override : w.d_valid;

@@ -8,6 +8,7 @@ struct WlView {
     const uint32_t *valA;   // nullptr => rank == sorted position
     const uint32_t *offB;
     const uint16_t *headB;  // n entries (+2 of padding), 4-byte aligned base
+    const uint32_t *valB;   // rank of every entry of table B
     uint32_t *valid;
     uint32_t *corrected;
     const uint32_t *prior;

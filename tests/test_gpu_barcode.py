@@ -444,3 +444,37 @@ def test_3m_whitelist_1m_reads_bit_exact(hot, monkeypatch):
     assert st["corrected"] > 20_000 and st["invalid"] > 1_000 and st["valid"] > 800_000
     # 208 histogram buckets: with the table on, the rounds behind the sampling batch split their histogram by default
     assert (st["k1_split_rounds"] >= 1) == hot
+
+
+@pytest.mark.parametrize("case", ["cfg2_1m", "dense_ties", "3m_list", "many_distinct", "record_overflow"])
+def test_pass_b_in_barcode_order_bit_exact(case, monkeypatch):
+    """Pass B over the misses SORTED by sequence (k_correct_sorted: one cooperative scan of the two pigeonhole bins per run
+    of equal keys, the run's reads weigh the shared candidates with their own qualities; the default for lists of more
+    than 2 M entries) gives the per-read indices, flags and both histograms of the oracle: on the cfg2 model, on short
+    dense lists with several neighbours, ties and N's (the reads with an N go to the per-read kernel), on the 6.8 M-entry
+    list, with almost every miss a different sequence (many runs per wave) and when the records overflow (the scan of idx
+    takes over)."""
+    from cellranger_amd import synth as S
+
+    monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")   # miss records come from the LDS-table lookup
+    monkeypatch.setenv("CRGPU_K2_SORTED", "1")
+    if case == "cfg2_1m":
+        st = _compare_barcode_stage(S.Workload(n_total=1_000_000, seed=S.SEED0 + 12), 1_000_000)
+        assert st["corrected"] > 20_000
+    elif case == "dense_ties":
+        for cb_len, n_wl, thr in [(5, 300, 0.5), (6, 1500, 0.3), (8, 20000, 0.6), (11, 100000, 0.9)]:
+            w = S.Workload(n_total=200_000, seed=177 + cb_len, n_wl=n_wl, n_cells=min(200, n_wl // 3),
+                           n_ambient=n_wl // 2, cb_len=cb_len, cb_err=0.03, n_rate=0.004)
+            assert _compare_barcode_stage(w, 200_000, threshold=thr)["corrected"] > 0
+            _compare_barcode_stage(w, 50_000, first=200_000, threshold=0.95, max_err=1.0)
+    elif case == "3m_list":
+        monkeypatch.delenv("CRGPU_K2_SORTED")            # the default for a list of this size
+        st = _compare_barcode_stage(S.Workload(n_total=1_000_000, seed=S.SEED0 + 16, n_wl=6_794_880), 1_000_000)
+        assert st["corrected"] > 20_000
+    elif case == "many_distinct":
+        # as many cells as reads / 4: runs of equal misses are short, waves hold more than KS_MAX_RUNS different keys
+        w = S.Workload(n_total=300_000, seed=S.SEED0 + 13, n_cells=60_000, n_ambient=100_000, cb_err=0.02)
+        assert _compare_barcode_stage(w, 300_000)["corrected"] > 20_000
+    else:
+        monkeypatch.setenv("CRGPU_MISS_RECORD_CAP", "3")
+        assert _compare_barcode_stage(S.Workload(n_total=400_000, seed=S.SEED0 + 14), 400_000)["corrected"] > 8_000
