@@ -1341,6 +1341,7 @@ struct K2Params {
     bool check_expected;
     uint32_t *idx_inout;
     uint8_t *corrected_out;
+    bool have_flags;  // the call came with flag bytes: CRGPU_FLAG_CB_HAS_N tells which reads have an N
 };
 // qualities of read i (bit 7 = N), kept in two 64-bit registers: byte k of (lo, hi) = position k
 struct K2Qual {
@@ -1410,18 +1411,44 @@ __device__ __forceinline__ uint32_t k2_accept(const K2Params &P, const K2Qual &q
     return (expected < P.max_expected && b.like / b.total >= P.thresh) ? b.rank : CRGPU_MISS;
 }
 
+// a read with ONE N: the N is "observed" -- all four bases are tried at its position (corrector.rs:128-131); a candidate
+// built at any other position still contains the N and cannot match.  The four exact lookups and then the four prior counts
+// are independent loads, issued together.
+__device__ __forceinline__ uint32_t k2_solve_n(const WlView &w, const K2Params &P, uint32_t key, const K2Qual &q, uint32_t nmask) {
+    const uint32_t pos = (uint32_t)__ffs((int)nmask) - 1u;
+    const uint32_t sh = 2u * (P.len - 1u - pos);
+    uint32_t r4[4], c4[4];
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++) r4[b] = wl_lookup(w, (key & ~(3u << sh)) | (b << sh));
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++) c4[b] = r4[b] != CRGPU_MISS ? w.prior[r4[b]] : 0u;
+    const double pq = P.ptab[k2_qv(q, pos)];
+    K2Best best;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++)
+        if (r4[b] != CRGPU_MISS) best.feed(pq * (double)(1ll + (long long)c4[b]), r4[b]);  // :138-141, A<C<G<T
+    return k2_accept(P, q, best);
+}
+
 // one missing read on its own: both pigeonhole bins scanned by this lane.  Returns the rank or CRGPU_MISS.
-__device__ __forceinline__ uint32_t k2_solve_own(const WlView &w, const K2Params &P, uint32_t key, const K2Qual &q) {
+// have_q: q holds the read's qualities.  Otherwise the caller vouches that the read has no N (its flag byte) and that the
+// expected-error veto is off, and load_q(q) fetches the quality line only if the candidates have to be weighed: a read with
+// ONE candidate is corrected to it whatever its qualities are (likelihood / total == x / x == 1.0 for the positive finite x
+// that any quality gives, corrector.rs:140-152), and that is 99 % of the misses on the 737 K list -- their random 16 bytes
+// of a 128-byte line were a third of this pass (profiles/r02_k2_cost_attribution_ab.txt).
+template <typename LoadQ>
+__device__ __forceinline__ uint32_t k2_solve_own(const WlView &w, const K2Params &P, uint32_t key, K2Qual &q, bool have_q, LoadQ load_q) {
     const uint32_t len = P.len;
     const double *__restrict__ ptab = P.ptab;
-    const uint32_t nmask = k2_nmask(q);
-    const int n_n = __popc(nmask);
-
+    if (have_q) {
+        const uint32_t nmask = k2_nmask(q);
+        if (nmask) return (nmask & (nmask - 1u)) == 0u ? k2_solve_n(w, P, key, q, nmask) : CRGPU_MISS;
+    }
     // candidate slots: bit (pos*4 + base)
     unsigned long long cand = 0ull;
-    uint32_t posA = 0u, nA = 0u, tail_from = 0xFFFFFFFFu;  // tail_from: first position that lies in the tail
-    if (n_n == 0) {
-        tail_from = w.bitsA >> 1;
+    uint32_t posA = 0u, nA = 0u, posB = 0u, nB = 0u;
+    const uint32_t tail_from = w.bitsA >> 1;  // first position that lies in the tail
+    {
         const uint32_t head = key >> w.bitsB;
         const uint32_t tail = key & ((1u << w.bitsB) - 1u);
         const uint32_t hA = w.bitsA >> 1;
@@ -1440,43 +1467,38 @@ __device__ __forceinline__ uint32_t k2_solve_own(const WlView &w, const K2Params
             }
         });
         // mutation in the head: same tail -> bin B
-        scan_u16_range<K2_SCAN_DWORDS>(w.headB, b_lo, b_hi, [&](uint32_t h, uint32_t) {
+        scan_u16_range<K2_SCAN_DWORDS>(w.headB, b_lo, b_hi, [&](uint32_t h, uint32_t at) {
             const int bo = one_base_diff(h, head);
             if (bo >= 0) {
                 const uint32_t pos = hA - 1u - (uint32_t)(bo >> 1);
                 cand |= 1ull << (pos * 4u + ((h >> bo) & 3u));
+                posB = at;  // table B carries the ranks of its entries
+                nB++;
             }
         });
-    } else if (n_n == 1) {
-        // the N is "observed": all four bases are tried at its position (corrector.rs:128-131);
-        // a candidate built at any other position still contains the N and cannot match.
-        // The four exact lookups and then the four prior counts are independent loads: issued together (as a loop over the
-        // candidate mask they were a chain of twelve dependent loads, and a tenth of the misses of the cfg3 model are such reads)
-        const uint32_t pos = (uint32_t)__ffs((int)nmask) - 1u;
-        const uint32_t sh = 2u * (len - 1u - pos);
-        uint32_t r4[4], c4[4];
-#pragma unroll
-        for (uint32_t b = 0; b < 4; b++) r4[b] = wl_lookup(w, (key & ~(3u << sh)) | (b << sh));
-#pragma unroll
-        for (uint32_t b = 0; b < 4; b++) c4[b] = r4[b] != CRGPU_MISS ? w.prior[r4[b]] : 0u;
-        const double pq = ptab[k2_qv(q, pos)];
-        K2Best best;
-#pragma unroll
-        for (uint32_t b = 0; b < 4; b++)
-            if (r4[b] != CRGPU_MISS) best.feed(pq * (double)(1ll + (long long)c4[b]), r4[b]);  // :138-141, A<C<G<T
-        return k2_accept(P, q, best);
     }
-
+    if (!cand) return CRGPU_MISS;
+    const bool lone = (cand & (cand - 1ull)) == 0ull;  // exactly one candidate, already known to be listed
+    if (lone && !have_q) {
+        // k2_accept for like == total and expected == 0.0 (no veto)
+        const uint32_t r = nA ? (w.valA ? w.valA[posA] : posA) : w.valB[posB];
+        return (0.0 < P.max_expected && 1.0 >= P.thresh) ? r : CRGPU_MISS;
+    }
+    if (!have_q) {
+        load_q(q);
+        const uint32_t nmask = k2_nmask(q);  // an N the flag byte did not announce
+        if (nmask) return (nmask & (nmask - 1u)) == 0u ? k2_solve_n(w, P, key, q, nmask) : CRGPU_MISS;
+    }
     K2Best best;
-    const bool lone = n_n == 0 && (cand & (cand - 1ull)) == 0ull;  // exactly one candidate, already known to be listed
     while (cand) {
         const uint32_t slot = (uint32_t)__ffsll((long long)cand) - 1u;
         cand &= cand - 1ull;
         const uint32_t pos = slot >> 2, base = slot & 3u;
         const uint32_t sh = 2u * (len - 1u - pos);
         const uint32_t ckey = (key & ~(3u << sh)) | (base << sh);
-        // a lone tail mutation was seen in bin A at posA: no second lookup (offE + tail lines) for its rank
-        const uint32_t r = (nA == 1u && pos >= tail_from) ? (w.valA ? w.valA[posA] : posA) : wl_lookup(w, ckey);
+        // a lone mutation of its half was seen at posA / posB: no second lookup (offE + tail lines) for its rank
+        const uint32_t r = (nA == 1u && pos >= tail_from) ? (w.valA ? w.valA[posA] : posA)
+                           : (nB == 1u && pos < tail_from) ? w.valB[posB] : wl_lookup(w, ckey);
         if (r == CRGPU_MISS) continue;
         const uint32_t qv = k2_qv(q, pos);
         if (lone && ptab[qv] > 0.0) {
@@ -1519,9 +1541,12 @@ __device__ __forceinline__ void k2_correct_one(const WlViewSet &vs, const K2Para
     if (UNIFORM && (f & CRGPU_FLAG_LIB_MASK) != vs.ulib) return;
     const WlView &w = vs.v[lib];
     if (!UNIFORM && w.n == 0) return;
-    K2Qual q;
-    if (!k2_load_qual(P, i, f, q)) return;
-    k2_commit(w, P, i, k2_solve_own(w, P, key, q), rank_sink);
+    K2Qual q{0ull, 0ull};
+    // the flag byte says whether the read has an N (CRGPU_FLAG_CB_HAS_N is set by the pack kernels whenever bit 7 of a quality
+    // byte is; pass A decides by it, too): without one, and without the veto, the quality line is fetched only on demand
+    const bool lazy = P.qualn != nullptr && P.have_flags && !P.check_expected && !(f & CRGPU_FLAG_CB_HAS_N);
+    if (!lazy && !k2_load_qual(P, i, f, q)) return;
+    k2_commit(w, P, i, k2_solve_own(w, P, key, q, !lazy, [&](K2Qual &qq) { (void)k2_load_qual(P, i, f, qq); }), rank_sink);
 }
 
 // the misses as a list of read indices (k_collect_miss); run_if_zero (nullable): do nothing if *run_if_zero != 0 ...
@@ -1862,7 +1887,7 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
     // expected_errors < f64::MAX is always true for a finite sum: skip the sum for the default
     const bool check_expected = d_qualn && !fake_quals && ctx->max_expected_errors < 1.7976931348623157e308;
     const K2Params P{d_qualn, ctx->cb_len, ctx->d_ptab, ctx->max_expected_errors, ctx->confidence_threshold, check_expected,
-                     d_idx_inout, d_corrected_out};
+                     d_idx_inout, d_corrected_out, d_flags != nullptr && getenv("CRGPU_K2_EAGER_QUAL") == nullptr};  // (A/B switch)
     if (use_rec) {
         // reads before rec.first (K1's sampling batch) are not in the records; everything is scanned when they overflowed
         const uint32_t *overflow = rec.d_count + rec.regions;
@@ -1878,7 +1903,7 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
     // Barcode order (k_correct_sorted) for the recorded misses: pays once the pigeonhole bins are long (the 6.8 M-entry list:
     // ~104 entries per bin against ~11 with 737 K); CRGPU_K2_SORTED=0/1 forces either way.  The reads with an N join the
     // miss list of the k_correct launch below.
-    bool sorted = use_rec && uniform && d_qualn && (uint64_t)rec.regions * rec.cap < 0xFFFFFFFFull;
+    bool sorted = use_rec && uniform && d_qualn && d_flags && (uint64_t)rec.regions * rec.cap < 0xFFFFFFFFull;
     if (const char *g = getenv("CRGPU_K2_SORTED")) sorted = sorted && atoi(g) != 0;
     else sorted = sorted && ctx->n_canon > (1u << 21);
     int sorted_rc = CRGPU_OK;
