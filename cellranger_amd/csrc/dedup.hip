@@ -495,6 +495,8 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
     CR_REQUIRE(ctx, (recs->umi_len & 3u) != 0u || (uintptr_t)recs->d_umi_qualn % 4 == 0, CRGPU_EINVAL,
                "crgpu_build_keys: the UMI quality buffer must be 4-byte aligned");
     unsigned long long *d_n = (unsigned long long *)(ctx->d_scalars + 8);
+    bool append = false;
+    const uint64_t n_before = ctx->ghist.n;
     CR_TRY(cr_dense_ensure(ctx));  // CRGPU_OPT_DENSE_BARCODE_KEYS: the BarcodeIndex of the tables as they stand (else nothing)
     const uint4 *d_fwd = ctx->dense.valid ? ctx->dense.d_fwd : nullptr;
     uint32_t *d_unknown = ctx->d_scalars + 60, *d_lb_abort = ctx->d_scalars + 61;
@@ -506,6 +508,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         // keys only (no read ordinals): count the sort's digit histograms on the way (1024 workgroups keep the
         // flush at a few million atomics)
         KeyHistograms &gh = ctx->ghist;
+        const bool had = gh.valid;
         gh.valid = false;
         SweepPlan plan;
         uint32_t widths[OS_MAX_PASSES];
@@ -514,7 +517,10 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         if (ctx->trust_buffers && !getenv("CRGPU_NO_KEY_HIST") && cr_sweep_plan(cr_sort_low_bits(ctx->layout.total_bits(), ctx->layout.bits_umi), ctx->layout.total_bits(), &plan, widths)) {
             if (!gh.d_hist) CR_TRY(cr_pool_alloc(ctx, (void **)&gh.d_hist, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t)));
             d_hist = gh.d_hist;
-            CR_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t), ctx->stream));
+            // a call that writes its keys right behind the previous call's (the libraries of a well, one after the other, into
+            // one buffer) adds to that call's histograms: the sort of the whole buffer then still finds them
+            append = had && !d_vals_out && gh.d_keys + gh.n == d_keys_out && memcmp(&gh.plan, &plan, sizeof(plan)) == 0;
+            if (!append) CR_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)OS_MAX_PASSES * RADIX_MAX * sizeof(uint32_t), ctx->stream));
         }
 #ifndef KEY_GRID_HIST
 #define KEY_GRID_HIST 1024u
@@ -590,7 +596,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
             default: CR_BUILD_KEYS(0); break;
         }
         if (d_hist) {
-            gh.d_keys = d_keys_out;
+            if (!append) gh.d_keys = d_keys_out;
             gh.plan = plan;
             gh.valid = true;  // gh.n is filled in below, once the number of keys is known
         }
@@ -618,7 +624,7 @@ static int build_keys_impl(crgpu_ctx *ctx, const crgpu_records *recs, uint64_t *
         }
     }
     *n_keys_out = h;
-    ctx->ghist.n = h;
+    ctx->ghist.n = append ? n_before + h : h;
     return CRGPU_OK;
 }
 
@@ -1360,9 +1366,22 @@ struct CandEmit {
     unsigned long long *n_out;  // its length (device counter, zeroed by the host)
     uint32_t vbits;
 };
+// entry e of the table: bit 0 "seen", bit 1 "seen again"
+__device__ __forceinline__ void lf_note(uint32_t *bm, uint32_t e) {
+    const uint32_t sh = (e & 15u) * 2u;
+    const uint32_t old = atomicOr(&bm[e >> 4], 1u << sh);
+    if ((old >> sh) & 1u) atomicOr(&bm[e >> 4], 2u << sh);
+}
+// two: TWO entries per group (bits 0.. and 24.. of the mix; opt-in, see the driver): a group with two members has hit both of
+// its entries twice, a single key is marked only if other keys hit BOTH of its entries
+__device__ __forceinline__ bool lf_again(const uint32_t *bm, uint64_t mx, uint32_t emask, bool two) {
+    const uint32_t e1 = (uint32_t)mx & emask, e2 = (uint32_t)(mx >> 24) & emask;
+    const bool a1 = (bm[e1 >> 4] >> ((e1 & 15u) * 2u + 1u)) & 1u;
+    return two ? a1 && ((bm[e2 >> 4] >> ((e2 & 15u) * 2u + 1u)) & 1u) : a1;
+}
 template <bool EMIT>
 __global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, const uint64_t *__restrict__ ukey, uint64_t nd,
-                                                                 uint8_t *__restrict__ cand, const CandEmit em) {
+                                                                 uint8_t *__restrict__ cand, const CandEmit em, const bool two) {
     __shared__ uint32_t bm[LF_WORDS];
     __shared__ uint32_t s_first;
     __shared__ unsigned long long s_end;
@@ -1425,10 +1444,9 @@ __global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, co
 #pragma unroll
             for (int j = 0; j < LF_BATCH; j++) {
                 if (k0 + (uint64_t)j * LF_THREADS >= b) break;
-                const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
-                const uint32_t sh = (e & 15u) * 2u;
-                const uint32_t old = atomicOr(&bm[e >> 4], 1u << sh);
-                if ((old >> sh) & 1u) atomicOr(&bm[e >> 4], 2u << sh);
+                const uint64_t mx = mix64(group_id(kl, key[j]));
+                lf_note(bm, (uint32_t)mx & emask);
+                if (two) lf_note(bm, (uint32_t)(mx >> 24) & emask);
             }
         }
         __syncthreads();
@@ -1444,8 +1462,7 @@ __global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, co
                 for (int j = 0; j < LF_BATCH; j++) {
                     const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
                     if (k >= b) break;
-                    const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
-                    cand[k] = (uint8_t)((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u);
+                    cand[k] = (uint8_t)lf_again(bm, mix64(group_id(kl, key[j])), emask, two);
                 }
             }
         } else {
@@ -1464,8 +1481,7 @@ __global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, co
 #pragma unroll
                 for (int j = 0; j < LF_BATCH; j++) {
                     const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
-                    const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
-                    mine += (k < b && ((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u)) ? 1u : 0u;
+                    mine += (k < b && lf_again(bm, mix64(group_id(kl, key[j])), emask, two)) ? 1u : 0u;
                 }
             }
 #pragma unroll
@@ -1488,8 +1504,7 @@ __global__ __launch_bounds__(LF_THREADS) void k_group_candidates(const KL kl, co
 #pragma unroll
                 for (int j = 0; j < LF_BATCH; j++) {
                     const uint64_t k = k0 + (uint64_t)j * LF_THREADS;
-                    const uint32_t e = (uint32_t)mix64(group_id(kl, key[j])) & emask;
-                    const bool is_c = k < b && ((bm[e >> 4] >> ((e & 15u) * 2u + 1u)) & 1u);
+                    const bool is_c = k < b && lf_again(bm, mix64(group_id(kl, key[j])), emask, two);
                     const unsigned long long m = __ballot(is_c);
                     if (!m) continue;  // wave-uniform
                     uint32_t wbase = 0;
@@ -2184,20 +2199,24 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         // pairs itself -- measured SLOWER at 1 B records (k_group_candidates 2.6 -> 7.4 ms for the 2.6 ms of compaction it saves:
         // a third pass over every barcode range, whose longest ones are one workgroup's job), kept for the A/B record
         const bool cand_flags = getenv("CRGPU_CAND_EMIT") == nullptr;
+        // CRGPU_CAND_FILTER=2: two table entries per group.  Measured at 1 B records: the filter kernel 2.6 -> 3.8 ms, the hash sort
+        // only 20 % shorter (the large cells saturate the table either way), k_cp_count 1.6 -> 0.5: no change of the stage
+        const char *cf2 = getenv("CRGPU_CAND_FILTER");
+        const bool two_entries = cf2 && atoi(cf2) == 2;
         unsigned long long *d_ncand = (unsigned long long *)(ctx->d_scalars + 64);
         {
             CrTimer t(ctx, CRGPU_T_DEDUP);
             const uint64_t n_ftiles = (nd + LF_TILE - 1) / LF_TILE;
             if (cand_flags) {
                 hipLaunchKernelGGL(k_group_candidates<false>, dim3(cr_grid(n_ftiles, 1, 256u * 2u)), dim3(LF_THREADS), 0, ctx->stream, kl,
-                                   ukey, nd, cand_b.as<uint8_t>(), CandEmit{});
+                                   ukey, nd, cand_b.as<uint8_t>(), CandEmit{}, two_entries);
                 CR_HIP(ctx, hipGetLastError());
                 CR_TRY(compact(ctx, CandFlag{cand_b.as<uint8_t>()}, EmitHash{kl, ukey, vbits, h_b.as<uint32_t>(), v_b.as<uint32_t>()}, nd,
                                d_block, d_total));
             } else {
                 CR_HIP(ctx, hipMemsetAsync(d_ncand, 0, sizeof(unsigned long long), ctx->stream));
                 hipLaunchKernelGGL(k_group_candidates<true>, dim3(cr_grid(n_ftiles, 1, 256u * 2u)), dim3(LF_THREADS), 0, ctx->stream, kl,
-                                   ukey, nd, (uint8_t *)nullptr, CandEmit{h_b.as<uint32_t>(), v_b.as<uint32_t>(), d_ncand, vbits});
+                                   ukey, nd, (uint8_t *)nullptr, CandEmit{h_b.as<uint32_t>(), v_b.as<uint32_t>(), d_ncand, vbits}, two_entries);
                 CR_HIP(ctx, hipGetLastError());
             }
         }
