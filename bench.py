@@ -544,6 +544,9 @@ def main():
     if workload == "cfg5" and rank == 0 and result is not None:
         out_info = {"matrix_columns": int(result["barcode_rank"].numel()), "matrix_nnz": int(result["data"].numel()),
                     "wells": world}
+    if workload in ("cfg3", "cfg4", "cfg5") and rank == 0 and out_info:
+        out_info["distinct_keys"] = ctx.stat(9)                  # CRGPU_STAT_DISTINCT_KEYS
+        out_info["low_support_candidates"] = ctx.stat(10)        # CRGPU_STAT_LOW_SUPPORT_CANDIDATES
     if workload == "cfg2" and rank == 0:
         idx = shard["idx"].to_host(count=min(n, 1 << 22))
         out_info = {"valid_frac_sample": float((idx != 0xFFFFFFFF).mean())}

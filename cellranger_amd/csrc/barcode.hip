@@ -640,7 +640,31 @@ __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ 
 #define LH_QITEMS 4                  // item slots packed into the cold queue at a time
 #endif
 #define LH_QUEUE (64 * LH_QITEMS)    // entries of a wave's queue: every lane of every slot could be cold
-template <bool SPLIT>
+// MODE 0: every hit goes through the staged histogram afterwards (k_stage_idx over idx).
+// MODE 1 (LH_SPLIT): hits the table answers are written out as table slots (2 bytes per read) and counted by k_hist_hot_slots.
+// MODE 2 (LH_COUNT): the table keeps 4-byte keys only (64 KB) and the other 64 KB of its LDS hold one counter per slot: a hit
+//   the table answers bumps its slot's counter right here and takes its rank from the table image in global memory (128 KB,
+//   cache resident); the counters are added to the VALID table when the workgroup ends.  No slot stream, no second kernel,
+//   and the staged histogram sees the cold hits only.  A cold region that overflows counts its surplus hits by device atomics.
+//   Opt-in (CRGPU_K1_MODE=count), measured SLOWER at 1 B reads: pass A 8.05 -> 9.05 ms on the 737 K list, 12.0 -> 12.65 on the
+//   6.8 M one, cfg2 0.93 -> 1.13 -- the rank gather (64 different lines of the image per wave instruction) costs the lookup
+//   more than the staging it saves; profiles/r03_count_stage_and_sort_ab.txt.
+#define LH_FULL 0
+#define LH_SPLIT 1
+#define LH_COUNT 2
+// 4-byte-key table: slot of `key` or 0xFFFF.  An empty slot holds 0xFFFFFFFF, so the all-T barcode is never cached (cold path).
+__device__ __forceinline__ uint32_t hot_probe_keys(const uint32_t *s_key, uint32_t key) {
+    const uint32_t b0 = hot_hash(key), b1 = (b0 + 1u) & (HOT_BUCKETS - 1u);
+    const uint2 x = *reinterpret_cast<const uint2 *>(s_key + 2u * b0);
+    const uint2 y = *reinterpret_cast<const uint2 *>(s_key + 2u * b1);
+    uint32_t sl = 0xFFFFu;
+    sl = y.y == key ? 2u * b1 + 1u : sl;
+    sl = y.x == key ? 2u * b1 : sl;
+    sl = x.y == key ? 2u * b0 + 1u : sl;
+    sl = x.x == key ? 2u * b0 : sl;
+    return key == 0xFFFFFFFFu ? 0xFFFFu : sl;
+}
+template <int MODE>
 __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                                                            const unsigned long long *__restrict__ hot_image,
                                                            const uint32_t *__restrict__ cb, const uint8_t *__restrict__ flags,
@@ -657,17 +681,27 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
     // through the staged histogram -- 15 % of the reads instead of all of them.
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_hot[];  // HOT_SLOTS, then the cold queues
     uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_hot + HOT_SLOTS);          // LH_THREADS / 64 queues of LH_QUEUE
+    constexpr bool SPLIT = MODE == LH_SPLIT, COUNT = MODE == LH_COUNT, COLD = MODE != LH_FULL;
+    uint32_t *s_key = reinterpret_cast<uint32_t *>(s_hot), *s_cnt = s_key + HOT_SLOTS;  // COUNT: keys, then one counter per slot
+    const uint32_t *__restrict__ hot_words = reinterpret_cast<const uint32_t *>(hot_image);  // [2 s] key, [2 s + 1] rank of slot s
     const uint32_t tid = threadIdx.x;
     const WlView &w = vs.v[0];
     const uint32_t *__restrict__ tw = reinterpret_cast<const uint32_t *>(w.tailA);
     const uint32_t tail_mask = (1u << w.bitsB) - 1u;
-    for (uint32_t s = tid; s < HOT_SLOTS; s += LH_THREADS) s_hot[s] = hot_image[s];
+    if (COUNT) {
+        for (uint32_t s = tid; s < HOT_SLOTS; s += LH_THREADS) {
+            s_key[s] = hot_words[2u * s];
+            s_cnt[s] = 0u;
+        }
+    } else {
+        for (uint32_t s = tid; s < HOT_SLOTS; s += LH_THREADS) s_hot[s] = hot_image[s];
+    }
     __syncthreads();
     const uint64_t chunk = (uint64_t)LH_THREADS * LH_ITEMS;
     // miss records (for K2): every wave appends to its own region, no atomics; the cursor lives in a register
     const uint32_t region = blockIdx.x * (LH_THREADS / 64) + (tid >> 6);
     uint32_t rec_cur = rec_i ? rec_count[region] : 0u;
-    uint32_t cold_cur = SPLIT ? cold_count[region] : 0u;
+    uint32_t cold_cur = COLD ? cold_count[region] : 0u;
     // the keys of the next chunk are requested before this chunk's table probes and global lookups
     uint32_t nkey[LH_ITEMS], nfl[LH_ITEMS];
 #pragma unroll
@@ -693,6 +727,22 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
             nkey[j] = i < n ? CR_LOAD_STREAM(&cb[i]) : 0u;
             nfl[j] = (i < n && flags) ? CR_LOAD_STREAM(&flags[i]) : 0u;
         }
+        if (COUNT) {
+#pragma unroll
+            for (int j = 0; j < LH_ITEMS; j++) {
+                const uint32_t sl = hot_probe_keys(s_key, key[j]);
+                hslot[j] = todo[j] ? sl : 0xFFFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < LH_ITEMS; j++)   // the ranks of the slots that answered: independent loads, issued together
+                if (hslot[j] != 0xFFFFu) rank[j] = hot_words[2u * hslot[j] + 1u];
+#pragma unroll
+            for (int j = 0; j < LH_ITEMS; j++)
+                if (hslot[j] != 0xFFFFu) {
+                    todo[j] = false;
+                    atomicAdd(&s_cnt[hslot[j]], 1u);
+                }
+        } else {
 #pragma unroll
         for (int j = 0; j < LH_ITEMS; j++) {
             uint32_t sl = 0xFFFFu;
@@ -703,6 +753,7 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                 todo[j] = false;
                 hslot[j] = sl;
             }
+        }
         }
         if (SPLIT) {
             // the table slots that answered this thread's LH_ITEMS reads, as one 16-byte store: the histogram does not care
@@ -758,10 +809,11 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                     }
                     q[dpos] = found;  // valA == nullptr on this path: sorted position == rank
                 }
-                if (SPLIT) {  // the hits of this batch of 64 cold lookups, densely, behind the wave's earlier ones
+                if (COLD) {  // the hits of this batch of 64 cold lookups, densely, behind the wave's earlier ones
                     const unsigned long long cm = __ballot(found != CRGPU_MISS);
                     const uint32_t pos = cold_cur + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
                     if (found != CRGPU_MISS && pos < cold_cap) cold_rank[(uint64_t)region * cold_cap + pos] = found;
+                    if (COUNT && found != CRGPU_MISS && pos >= cold_cap) atomicAdd(&w.valid[found], 1u);  // region full: counted here
                     cold_cur += (uint32_t)__popcll(cm);
                 }
             }
@@ -796,6 +848,14 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
     if (SPLIT && (tid & 63u) == 0u) {
         cold_count[region] = cold_cur;
         if (cold_cur > cold_cap) atomicOr(&cold_count[cold_regions], 1u);  // overflow: this round is counted by k_hist_ranks_atomic
+    }
+    if (COUNT) {
+        if ((tid & 63u) == 0u) cold_count[region] = cold_cur < cold_cap ? cold_cur : cold_cap;
+        __syncthreads();
+        for (uint32_t s = tid; s < HOT_SLOTS; s += LH_THREADS) {
+            const uint32_t c = s_cnt[s];
+            if (c) atomicAdd(&w.valid[hot_words[2u * s + 1u]], c);
+        }
     }
 }
 
@@ -1116,8 +1176,9 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
         }
     }
     if (use_hot) {
-        cr_allow_lds(ctx, (const void *)k_lookup_hot<false>, lookup_lds);
-        cr_allow_lds(ctx, (const void *)k_lookup_hot<true>, lookup_lds);
+        cr_allow_lds(ctx, (const void *)k_lookup_hot<LH_FULL>, lookup_lds);
+        cr_allow_lds(ctx, (const void *)k_lookup_hot<LH_SPLIT>, lookup_lds);
+        cr_allow_lds(ctx, (const void *)k_lookup_hot<LH_COUNT>, lookup_lds);
     }
     hipError_t e = hipSuccess;
     bool hot_ready = false;
@@ -1130,6 +1191,9 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     uint32_t *d_cold = nullptr, *d_cold_count = nullptr;
     uint64_t hot_round = 0;   // reads per table round (0: the split histogram is off)
     uint32_t cold_cap = 0;
+    // CRGPU_K1_MODE=count: table hits counted inside the lookup kernel (LH_COUNT); =split / =full: the other two
+    const char *k1_mode = getenv("CRGPU_K1_MODE");
+    const bool count_mode = k1_mode && strcmp(k1_mode, "count") == 0;
     struct ColdRelease {
         crgpu_ctx *c;
         uint16_t *&a;
@@ -1150,16 +1214,24 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
             if (hot_ready && hot_round) {
                 ctx->k1_split_rounds++;
                 const uint64_t C = (uint64_t)cold_regions * cold_cap;
-                const uint32_t *d_over = d_cold_count + cold_regions;
+                const uint32_t *d_over = d_cold_count + cold_regions;  // != 0 after the lookup: a cold region overflowed
                 if (e == hipSuccess) e = hipMemsetAsync(d_cold_count, 0, (cold_regions + 1) * sizeof(uint32_t), ctx->stream);
                 if (e == hipSuccess) e = hipMemsetAsync(d_cold, 0xFF, C * sizeof(uint32_t), ctx->stream);
-                hipLaunchKernelGGL(k_lookup_hot<true>, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
+                if (count_mode) {
+                    d_over = nullptr;  // nothing to fall back to: a full region counts its surplus hits itself
+                    hipLaunchKernelGGL(k_lookup_hot<LH_COUNT>, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS),
+                                       lookup_lds, ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
+                                       d_idx_out + off, rec.valid ? rec.d_i : nullptr, rec.d_key, rec.d_fl, rec.d_count, rec.cap,
+                                       rec.regions, (uint32_t)off, (uint16_t *)nullptr, d_cold, d_cold_count, cold_cap, cold_regions);
+                } else {
+                hipLaunchKernelGGL(k_lookup_hot<LH_SPLIT>, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
                                    ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
                                    d_idx_out + off, rec.valid ? rec.d_i : nullptr, rec.d_key, rec.d_fl, rec.d_count, rec.cap,
                                    rec.regions, (uint32_t)off, d_hot_slot, d_cold, d_cold_count, cold_cap, cold_regions);
                 const uint64_t lh_chunk = (uint64_t)LH_THREADS * LH_ITEMS;
                 hipLaunchKernelGGL(k_hist_hot_slots, dim3(128), dim3(HH_THREADS), HOT_SLOTS * sizeof(uint32_t), ctx->stream, d_hot_slot,
                                    (m + lh_chunk - 1) / lh_chunk * LH_THREADS, ctx->d_hot_image, uw.d_valid, d_over);
+                }
                 if (plan.n_buckets <= SI_MISS_BUCKET)
                     hipLaunchKernelGGL(k_stage_idx, dim3(cr_grid((C + SI_TILE - 1) / SI_TILE, 1, 256u * 6u)), dim3(256), 0, ctx->stream,
                                        plan, d_cold, C, d_stage, d_cursor, d_over);
@@ -1167,8 +1239,9 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                     hipLaunchKernelGGL((k_match_binned<true, true>), dim3(cr_grid((C + MB_ITEMS - 1) / MB_ITEMS, 256, 256u * 6u)),
                                        dim3(256), 0, ctx->stream, vs, plan, (const uint32_t *)nullptr, (const uint8_t *)nullptr, C, d_cold,
                                        d_stage, d_cursor, d_over);
-                hipLaunchKernelGGL(k_hist_ranks_atomic, dim3(cr_grid(m, 256)), dim3(256), 0, ctx->stream, d_idx_out + off, m, uw.d_valid,
-                                   d_over);
+                if (!count_mode)
+                    hipLaunchKernelGGL(k_hist_ranks_atomic, dim3(cr_grid(m, 256)), dim3(256), 0, ctx->stream, d_idx_out + off, m, uw.d_valid,
+                                       d_over);
                 if (getenv("CRGPU_K1_DEBUG")) {
                     std::vector<uint32_t> cc(cold_regions + 1);
                     (void)hipMemcpyAsync(cc.data(), d_cold_count, cc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
@@ -1183,7 +1256,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                             (unsigned long long)off, (unsigned long long)m, cold_cap, mx, (unsigned long long)tot, cc[cold_regions]);
                 }
             } else if (hot_ready) {
-                hipLaunchKernelGGL(k_lookup_hot<false>, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
+                hipLaunchKernelGGL(k_lookup_hot<LH_FULL>, dim3(cr_grid((m + MB_TILE - 1) / MB_TILE, 1, 256u)), dim3(LH_THREADS), lookup_lds,
                                    ctx->stream, vs, ctx->d_hot_image, d_cb + off, d_flags ? d_flags + off : nullptr, m,
                                    d_idx_out + off, rec.valid ? rec.d_i : nullptr, rec.d_key, rec.d_fl, rec.d_count, rec.cap,
                                    rec.regions, (uint32_t)off, (uint16_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, 0u);
@@ -1223,7 +1296,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                 // of the slot stream cost the lookup what the shorter staging saves (8.05 against 8.07 ms) and 100 M-read calls
                 // lose 5 %.  CRGPU_K1_SPLIT=1 / 0 forces it on / off.
                 const char *split_env = getenv("CRGPU_K1_SPLIT");
-                const bool want_split = split_env ? split_env[0] != '0' : plan.n_buckets > SI_MISS_BUCKET;
+                const bool want_split = count_mode || (split_env ? split_env[0] != '0' : plan.n_buckets > SI_MISS_BUCKET);
                 if (e == hipSuccess && want_split && !getenv("CRGPU_K1_FULL_STAGING") &&
                     hipMemcpyAsync(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                     hipStreamSynchronize(ctx->stream) == hipSuccess && sums[0] > 0) {
@@ -1244,7 +1317,8 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                         if (const char *env = getenv("CRGPU_COLD_CAP")) cap = strtoull(env, nullptr, 10);  // tests: force the overflow fallback
                         if ((round >= sb || round >= (n - first) / MB_TILE * MB_TILE) && round > 0 && cap * cold_regions <= plan.cap) {
                             const uint64_t lh_chunk = (uint64_t)LH_THREADS * LH_ITEMS;
-                            int rr = cr_pool_alloc(ctx, (void **)&d_hot_slot, (round + lh_chunk) / lh_chunk * lh_chunk * sizeof(uint16_t));
+                            int rr = count_mode ? CRGPU_OK
+                                                : cr_pool_alloc(ctx, (void **)&d_hot_slot, (round + lh_chunk) / lh_chunk * lh_chunk * sizeof(uint16_t));
                             if (rr == CRGPU_OK) rr = cr_pool_alloc(ctx, (void **)&d_cold, cap * cold_regions * sizeof(uint32_t));
                             if (rr == CRGPU_OK) rr = cr_pool_alloc(ctx, (void **)&d_cold_count, (cold_regions + 1) * sizeof(uint32_t));
                             if (rr == CRGPU_OK) {

@@ -197,6 +197,7 @@ struct crgpu_ctx {
     KeyHistograms ghist;
     std::map<const void *, size_t> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device (to how much)
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
+    uint64_t last_distinct_keys = 0, last_low_support_candidates = 0;  // of the last count call
     uint64_t sort_refinished = 0;          // sorts whose finishing pass met a run too long for it and that were redone on all bits
     uint64_t k1_split_rounds = 0;          // table rounds of K1 whose histogram was split (table slots in LDS + staged cold hits)
     uint64_t feature_resumed_reads = 0;    // captures a pass with a distribution took from the records of the pass without one

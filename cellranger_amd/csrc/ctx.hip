@@ -137,7 +137,14 @@ extern "C" int crgpu_create(crgpu_ctx **out, int device_id, int n_ranks, int ran
         delete ctx;
         return cr_fail(nullptr, CRGPU_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+    // the second stream carries the branch of the count stage that is NOT the critical path (candidate filter + hash sort beside
+    // the UMI correction): lowest priority, so that its kernels fill what the main stream leaves (CRGPU_STREAM2_PRIORITY=same: A/B)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const char *sp = getenv("CRGPU_STREAM2_PRIORITY");
+    const bool low2 = !(sp && strcmp(sp, "same") == 0);
+    if ((low2 ? hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_least)
+              : hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming) != hipSuccess) {
@@ -221,6 +228,12 @@ extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
             return CRGPU_OK;
         case CRGPU_STAT_FEATURE_FAST_LAUNCHES:
             *value_out = ctx->feature_fast_launches;
+            return CRGPU_OK;
+        case CRGPU_STAT_DISTINCT_KEYS:
+            *value_out = ctx->last_distinct_keys;
+            return CRGPU_OK;
+        case CRGPU_STAT_LOW_SUPPORT_CANDIDATES:
+            *value_out = ctx->last_low_support_candidates;
             return CRGPU_OK;
         case CRGPU_STAT_FEATURE_READS_REQUEUED:
             *value_out = ctx->feature_reads_requeued;

@@ -2227,6 +2227,8 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         } else
         CR_TRY(read_u32(ctx, d_total, &n_cand32));
         const uint64_t n_cand = n_cand32;
+        ctx->last_distinct_keys = nd;
+        ctx->last_low_support_candidates = n_cand;
         if (n_cand >= 2) {
             DevBuf ht_b, vt_b;
             CR_TRY(dmalloc(ctx, ht_b, n_cand * sizeof(uint32_t)));

@@ -170,6 +170,30 @@ def test_split_histogram_rounds_and_their_overflow_fallback(monkeypatch):
     assert _compare_barcode_stage(w, 600_000)["k1_split_rounds"] == 0
 
 
+@pytest.mark.parametrize("case", ["plain", "cold_regions_overflow", "3m_list", "tiny_list_all_T"])
+def test_table_hits_counted_inside_the_lookup_kernel(case, monkeypatch):
+    """CRGPU_K1_MODE=count: the LDS table holds 4-byte keys and one counter per slot; a hit the table answers bumps its
+    counter in the lookup kernel and takes its rank from the table image, the other hits go to per-wave regions and the
+    staged histogram (a full region counts its surplus by device atomics).  Indices and both histograms equal the oracle's;
+    the all-T barcode (the value of an empty slot) is never cached and still counted."""
+    from cellranger_amd import synth as S
+
+    monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")
+    monkeypatch.setenv("CRGPU_K1_MODE", "count")
+    if case == "plain":
+        assert _compare_barcode_stage(S.Workload(n_total=600_000, seed=S.SEED0 + 19), 600_000)["k1_split_rounds"] >= 1
+    elif case == "cold_regions_overflow":
+        monkeypatch.setenv("CRGPU_COLD_CAP", "5")
+        assert _compare_barcode_stage(S.Workload(n_total=600_000, seed=S.SEED0 + 20), 600_000)["k1_split_rounds"] >= 1
+    elif case == "3m_list":
+        st = _compare_barcode_stage(S.Workload(n_total=1_000_000, seed=S.SEED0 + 21, n_wl=6_794_880), 1_000_000)
+        assert st["k1_split_rounds"] >= 1 and st["corrected"] > 20_000
+    else:
+        # 4-base barcodes, the whole space listed: TTTT = 0xFF...; few cells, so nearly every read is answered by the table
+        w = S.Workload(n_total=200_000, seed=33, n_wl=256, n_cells=40, n_ambient=100, cb_len=4, umi_len=6, cb_err=0.05)
+        _compare_barcode_stage(w, 200_000)
+
+
 def test_miss_record_overflow_falls_back_to_the_scan(monkeypatch):
     """Pass A leaves compact records of its misses for pass B; when a wave's region overflows, pass B scans idx as it
     does for any other call sequence -- same indices, flags and histograms."""
