@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256) void k_hot_hist(const uint32_t *__restrict__ v
 // which share of the hits the table will NOT answer)
 __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ valid, const uint32_t *__restrict__ keys,
                                                    uint32_t n, const uint32_t *__restrict__ hist,
-                                                   unsigned long long *__restrict__ image, unsigned long long *__restrict__ sums) {
+                                                   unsigned long long *__restrict__ image, unsigned long long *__restrict__ sums,
+                                                   const bool sparse_keys) {
+    // sparse_keys: keys[] is a list's own rank -> key array, 0xFFFFFFFF where the list has no key of that rank
     __shared__ uint32_t h[256];
     __shared__ uint32_t s_min;
     h[threadIdx.x] = hist[threadIdx.x];
@@ -607,6 +609,7 @@ __global__ __launch_bounds__(256) void k_hot_build(const uint32_t *__restrict__ 
         all += c;
         if (!c || hot_class(c) < cmin) continue;
         const uint32_t key = keys[r];
+        if (sparse_keys && key == 0xFFFFFFFFu) continue;  // (a count without a key of this list: a table the host wrote)
         const unsigned long long e = ((unsigned long long)r << 32) | key;
         const uint32_t b0 = hot_hash(key), b1 = (b0 + 1u) & (HOT_BUCKETS - 1u);
         const uint32_t slots[4] = {2u * b0, 2u * b0 + 1u, 2u * b1, 2u * b1 + 1u};
@@ -807,7 +810,8 @@ __global__ __launch_bounds__(LH_THREADS) void k_lookup_hot(const WlViewSet vs,
                                 if (t == tail) found = pos;
                             });
                     }
-                    q[dpos] = found;  // valA == nullptr on this path: sorted position == rank
+                    if (w.valA && found != CRGPU_MISS) found = w.valA[found];  // (translated / partial list: position -> rank)
+                    q[dpos] = found;
                 }
                 if (COLD) {  // the hits of this batch of 64 cold lookups, densely, behind the wave's earlier ones
                     const unsigned long long cm = __ballot(found != CRGPU_MISS);
@@ -1133,8 +1137,10 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     // (CRGPU_HOT_MIN_READS lowers the threshold so that the parity tests can drive this path with small inputs)
     uint64_t hot_min = 16ull << 20;
     if (const char *env = getenv("CRGPU_HOT_MIN_READS")) hot_min = strtoull(env, nullptr, 10);
-    const bool use_hot = uniform && uw.d_valA == nullptr && n >= hot_min && n >= 4ull * MB_TILE &&
-                         ctx->d_canon_keys != nullptr;
+    // (a translated or partial list brings its own rank -> key array; a rank without a key of this list never has a count)
+    const uint32_t *d_hot_keys = uw.d_valA ? uw.d_key_of_rank : ctx->d_canon_keys;
+    const bool use_hot = uniform && n >= hot_min && n >= 4ull * MB_TILE && d_hot_keys != nullptr &&
+                         !(uw.d_valA && getenv("CRGPU_HOT_PLAIN_ONLY"));  // (A/B switch: round 2's rule)
     uint64_t first = 0;  // reads of the sampling batch (a multiple of MB_TILE)
     if (use_hot) {
         first = n / 4 < (4ull << 20) ? n / 4 : (4ull << 20);
@@ -1286,8 +1292,8 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                 hipLaunchKernelGGL(k_hot_hist, dim3(128), dim3(256), 0, ctx->stream, uw.d_valid, ctx->n_canon, d_hh);
                 unsigned long long *d_sums = reinterpret_cast<unsigned long long *>(d_hh + 256);
                 if (e == hipSuccess) e = hipMemsetAsync(d_sums, 0, 2 * sizeof(unsigned long long), ctx->stream);
-                hipLaunchKernelGGL(k_hot_build, dim3(128), dim3(256), 0, ctx->stream, uw.d_valid, ctx->d_canon_keys,
-                                   ctx->n_canon, d_hh, ctx->d_hot_image, d_sums);
+                hipLaunchKernelGGL(k_hot_build, dim3(128), dim3(256), 0, ctx->stream, uw.d_valid, d_hot_keys,
+                                   ctx->n_canon, d_hh, ctx->d_hot_image, d_sums, uw.d_valA != nullptr);
                 hot_ready = true;
                 // share of the hits that the table will not answer (one read-back per call) -> size of the cold regions
                 unsigned long long sums[2] = {0, 0};

@@ -43,6 +43,7 @@ struct WlTables {
     uint32_t *d_offE = nullptr;   // exact-lookup index, (1 << (key bits - shiftE)) + 1
     uint32_t shiftE = 0;
     uint16_t *d_headB = nullptr;  // n
+    uint32_t *d_key_of_rank = nullptr;  // n_canon, only when d_valA != nullptr: a key of this list that has the rank (0xFFFFFFFF: none)
     uint32_t *d_valB = nullptr;   // n: canonical rank of every entry of table B (k_correct_sorted: no second lookup for a head mutation)
     uint32_t *d_valid = nullptr;      // n_canon valid counts
     uint32_t *d_corrected = nullptr;  // n_canon corrected counts

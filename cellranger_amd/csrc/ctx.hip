@@ -279,6 +279,7 @@ static void free_wl(WlTables &w) {
     hipFree(w.d_offE);
     hipFree(w.d_headB);
     hipFree(w.d_valB);
+    hipFree(w.d_key_of_rank);
     hipFree(w.d_valid);
     hipFree(w.d_corrected);
     hipFree(w.d_prior_override);

@@ -154,7 +154,14 @@ extern "C" int crgpu_set_whitelist_packed(crgpu_ctx *ctx, int lib, const uint32_
     w.bitsB = bitsB;
     CR_TRY(upload(ctx, &w.d_offA, offA));
     CR_TRY(upload(ctx, &w.d_tailA, tailA));
-    if (!identity) CR_TRY(upload(ctx, &w.d_valA, valA));
+    if (!identity) {
+        CR_TRY(upload(ctx, &w.d_valA, valA));
+        // rank -> a key of THIS list with that rank (a translated list: the partner's key; a subset: some ranks have none): what
+        // pass A's table of frequent barcodes is built from (on a plain full list the canonical keys serve)
+        std::vector<uint32_t> key_of_rank(n_canon, 0xFFFFFFFFu);
+        for (uint32_t p = 0; p < m; p++) key_of_rank[uniq[p].val] = uniq[p].key;
+        CR_TRY(upload(ctx, &w.d_key_of_rank, key_of_rank));
+    }
     CR_TRY(upload(ctx, &w.d_offB, offB));
     CR_TRY(upload(ctx, &w.d_headB, headB));
     CR_TRY(upload(ctx, &w.d_valB, valB));
