@@ -1073,7 +1073,9 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
                "crgpu_match_and_count: this context holds a segmented barcode space; run the barcode stage on the segment contexts");
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_cb && d_idx_out, CRGPU_EINVAL, "crgpu_match_and_count: NULL buffer");
-    cr_drop_miss_records(ctx);
+    // records of an earlier call about these buffers are stale now; the other sets stay (other libraries of the well)
+    for (MissRecords &old : ctx->recs)
+        if (old.valid && (old.d_cb == d_cb || old.d_idx == d_idx_out)) cr_drop_miss_records(ctx, old);
     cr_dense_drop(ctx);  // the VALID table changes
     if (!d_flags) {
         // NULL flags mean "no barcode holds an N".  A pack call that ran without a flags array and met an N left a mark:
@@ -1156,7 +1158,15 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
         }
     }
     // miss records for K2: one region per wave of the lookup kernel (its grid is pinned to 256 workgroups)
-    MissRecords &rec = ctx->rec;
+    uint32_t rec_slot = CR_REC_SETS;
+    for (uint32_t k = 0; k < CR_REC_SETS && rec_slot == CR_REC_SETS; k++)
+        if (!ctx->recs[k].valid) rec_slot = k;
+    if (rec_slot == CR_REC_SETS) {
+        rec_slot = ctx->rec_next;
+        ctx->rec_next = (ctx->rec_next + 1u) % CR_REC_SETS;
+    }
+    MissRecords &rec = ctx->recs[rec_slot];
+    cr_drop_miss_records(ctx, rec);
     if (use_hot && ctx->trust_buffers && n < 0xFFFFFFFFull && !getenv("CRGPU_NO_MISS_RECORDS")) {
         const uint64_t H = n - first;
         const uint64_t launches = (H + sb - 1) / sb + 1;
@@ -1178,7 +1188,7 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
             rec.first = first;
             rec.ulib = ulib;
         } else {
-            cr_drop_miss_records(ctx);  // not fatal: K2 scans idx as before
+            cr_drop_miss_records(ctx, rec);  // not fatal: K2 scans idx as before
         }
     }
     if (use_hot) {
@@ -1343,14 +1353,16 @@ extern "C" int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, c
     cr_pool_free(ctx, d_stage);
     cr_pool_free(ctx, d_cursor);
     if (e != hipSuccess) {
-        cr_drop_miss_records(ctx);
+        cr_drop_miss_records(ctx, rec);
         return cr_fail(ctx, CRGPU_EHIP, "crgpu_match_and_count: %s", hipGetErrorString(e));
     }
     return CRGPU_OK;
 }
 
 void cr_drop_miss_records(crgpu_ctx *ctx) {
-    MissRecords &r = ctx->rec;
+    for (MissRecords &r : ctx->recs) cr_drop_miss_records(ctx, r);
+}
+void cr_drop_miss_records(crgpu_ctx *ctx, MissRecords &r) {
     cr_pool_free(ctx, r.d_i);
     cr_pool_free(ctx, r.d_key);
     cr_pool_free(ctx, r.d_fl);
@@ -1947,8 +1959,12 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
     if (ctx->confidence_threshold != ctx->confidence_threshold) return CRGPU_OK;
     // the records K1 left for exactly these buffers (consumed here: a second call scans idx again) also say which
     // library the call is about; otherwise the flag bytes do
-    MissRecords &rec = ctx->rec;
-    const bool use_rec = rec.valid && rec.d_cb == d_cb && rec.d_flags == d_flags && rec.d_idx == d_idx_inout && rec.n == n;
+    MissRecords *recp = nullptr;
+    for (MissRecords &r : ctx->recs)
+        if (r.valid && r.d_cb == d_cb && r.d_flags == d_flags && r.d_idx == d_idx_inout && r.n == n) recp = &r;
+    const bool use_rec = recp != nullptr;
+    MissRecords none;
+    MissRecords &rec = recp ? *recp : none;
     int ulib = -1;
     if (use_rec)
         ulib = rec.ulib;
@@ -2045,7 +2061,7 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
         hipLaunchKernelGGL(k_correct<false>, grid, block, 0, ctx->stream, vs, d_cb, d_flags, miss_list, n_miss, P);
     if (sorted) {
         CR_HIP(ctx, hipGetLastError());
-        cr_drop_miss_records(ctx);  // stream-ordered: the pool reuses the blocks only for later work
+        cr_drop_miss_records(ctx, rec);  // stream-ordered: the pool reuses the blocks only for later work
         return sorted_rc;
     }
     if (use_rec) {
@@ -2087,7 +2103,7 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
         }
         cr_pool_free(ctx, d_off);
         cr_pool_free(ctx, d_rank);
-        cr_drop_miss_records(ctx);  // stream-ordered: the pool reuses the blocks only for later work
+        cr_drop_miss_records(ctx, rec);  // stream-ordered: the pool reuses the blocks only for later work
         return rc;
     }
     CR_HIP(ctx, hipGetLastError());

@@ -194,7 +194,12 @@ struct crgpu_ctx {
     FxPendingSet fxp;
     uint32_t *d_canon_keys = nullptr;         // n_canon packed canonical barcodes, ascending (rank -> sequence)
     unsigned long long *d_hot_image = nullptr;  // K1's hot-barcode table (HOT_SLOTS entries) + 256 u32 of scratch
-    MissRecords rec;
+    // the records of the last CR_REC_SETS pass-A calls (the libraries of a well are looked up one after the other, all of them
+    // before the first pass B): a set is dropped when pass B has used it, when a later pass A gets the same buffers, and with
+    // everything else that describes the caller's buffers (cr_invalidate)
+#define CR_REC_SETS 4
+    MissRecords recs[CR_REC_SETS];
+    uint32_t rec_next = 0;  // the set the next pass A overwrites when none is free
     KeyHistograms ghist;
     std::map<const void *, size_t> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this context's device (to how much)
     uint32_t n_xcc = 0;                    // XCDs that receive workgroups (probed by the first onesweep sort); 0 = unknown
@@ -310,7 +315,9 @@ void cr_set_thread_error(const char *msg);
 
 // workspace that only grows; returned pointer valid until the next cr_scratch call
 int cr_scratch(crgpu_ctx *ctx, uint64_t bytes, void **out);
-void cr_drop_miss_records(crgpu_ctx *ctx);
+void cr_invalidate_range(crgpu_ctx *ctx, const void *p, uint64_t bytes);
+void cr_drop_miss_records(crgpu_ctx *ctx);                  // all sets
+void cr_drop_miss_records(crgpu_ctx *ctx, MissRecords &r);  // one set
 // sort.hip: the plan radix_sort would use for 64-bit keys on bits [lo_bit, hi_bit); false = onesweep does not apply
 bool cr_sweep_plan(uint32_t lo_bit, uint32_t hi_bit, SweepPlan *plan, uint32_t *widths);
 // low bits of a molecule key of total_bits that the radix passes leave to the finishing pass (0: none)

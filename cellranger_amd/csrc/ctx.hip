@@ -229,6 +229,12 @@ extern "C" int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out) {
         case CRGPU_STAT_FEATURE_FAST_LAUNCHES:
             *value_out = ctx->feature_fast_launches;
             return CRGPU_OK;
+        case CRGPU_STAT_MISS_RECORD_SETS: {
+            uint64_t k = 0;
+            for (const MissRecords &r : ctx->recs) k += r.valid ? 1u : 0u;
+            *value_out = k;
+            return CRGPU_OK;
+        }
         case CRGPU_STAT_DISTINCT_KEYS:
             *value_out = ctx->last_distinct_keys;
             return CRGPU_OK;
@@ -247,6 +253,24 @@ void cr_invalidate(crgpu_ctx *ctx) {
     cr_drop_miss_records(ctx);
     cr_drop_feature_pending(ctx);
     ctx->ghist.valid = false;
+}
+// the same for a call that writes [p, p + bytes) of the caller's memory and nothing else: only the by-products that describe
+// (a buffer overlapping) that range go -- the feature extraction between pass A and pass B writes the feature indices, not the
+// barcodes pass A's miss records are about
+void cr_invalidate_range(crgpu_ctx *ctx, const void *p, uint64_t bytes) {
+    if (!p || !bytes) return;
+    const uintptr_t a = (uintptr_t)p, b = a + bytes;
+    auto hits = [&](const void *q, uint64_t len) { return q && (uintptr_t)q < b && (uintptr_t)q + len > a; };
+    for (MissRecords &r : ctx->recs)
+        if (r.valid && (hits(r.d_cb, r.n * 4) || hits(r.d_flags, r.n) || hits(r.d_idx, r.n * 4))) cr_drop_miss_records(ctx, r);
+    const FxPendingSet &f = ctx->fxp;
+    // (rows: at most stride bytes each; the outputs: 4 bytes per read and id / capture -- bounded generously)
+    if (f.valid && (hits(f.d_seq, f.n * (uint64_t)(f.stride ? f.stride : 1)) || hits(f.d_qual, f.n * (uint64_t)(f.stride ? f.stride : 1)) ||
+                    hits(f.d_len, f.n * 4) || hits(f.d_feature_out, f.n * 4) || hits(f.d_n_ids_out, f.n * 4) ||
+                    hits(f.d_capture_out, f.n * 4)))
+        cr_drop_feature_pending(ctx);
+    const KeyHistograms &g = ctx->ghist;
+    if (g.valid && hits(g.d_keys, g.n * 8)) ctx->ghist.valid = false;
 }
 void cr_dense_drop(crgpu_ctx *ctx) {
     if (!ctx->dense.valid) return;
@@ -367,7 +391,7 @@ extern "C" int crgpu_memcpy_h2d(crgpu_ctx *ctx, void *d_dst, const void *h_src, 
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     if (!bytes) return CRGPU_OK;
-    cr_invalidate(ctx);  // the destination may be a buffer a kept by-product describes
+    cr_invalidate_range(ctx, d_dst, bytes);  // the destination may be a buffer a kept by-product describes
     CR_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     CR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CRGPU_OK;
@@ -386,7 +410,7 @@ extern "C" int crgpu_memset(crgpu_ctx *ctx, void *d_dst, int value, uint64_t byt
     if (!ctx) return CRGPU_EINVAL;
     CR_ENTER(ctx);
     if (!bytes) return CRGPU_OK;
-    cr_invalidate(ctx);
+    cr_invalidate_range(ctx, d_dst, bytes);
     CR_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
     return CRGPU_OK;
 }

@@ -275,7 +275,7 @@ extern "C" int crgpu_match_features_dev(crgpu_ctx *ctx, int pattern, const uint3
                "feature pattern %d not set", pattern);
     if (n == 0) return CRGPU_OK;
     CR_REQUIRE(ctx, d_seq && d_qualn && d_feature_out, CRGPU_EINVAL, "crgpu_match_features: NULL buffer");
-    cr_invalidate(ctx);  // a caller buffer is written: by-products of earlier calls are not trusted any more
+    cr_invalidate_range(ctx, d_feature_out, n * sizeof(uint32_t));  // a caller buffer is written: by-products about it go
     const FeaturePattern &P = ctx->pat[pattern];
     // p_edit[qv] = 10^(-qv/10) for qv = 0..33, host libm as in feature_extraction.rs:45
     double pe[34];

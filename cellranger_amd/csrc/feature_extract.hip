@@ -971,7 +971,11 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
         void *p;
         ~ResumeGuard() { cr_pool_free(c, p); }
     } resume_guard{ctx, resume.d_recs};
-    cr_invalidate(ctx);  // caller buffers are written: by-products of earlier calls are not trusted any more
+    // caller buffers are written (4 bytes per read each): the by-products of earlier calls that describe them are not trusted
+    // any more (pass A's miss records describe the barcodes: they stay)
+    cr_invalidate_range(ctx, d_feature_out, n * sizeof(uint32_t));
+    cr_invalidate_range(ctx, d_n_ids_out, n * sizeof(uint32_t));
+    cr_invalidate_range(ctx, d_capture_out, n * sizeof(uint32_t));
     double pe[34];
     for (int q = 0; q < 34; q++) pe[q] = std::pow(10.0, -(double)q / 10.0);  // host libm as in :45
     double *d_pe = (double *)(ctx->d_scalars + 128);

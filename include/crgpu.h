@@ -126,6 +126,7 @@ int crgpu_invalidate(crgpu_ctx *ctx);
 #define CRGPU_STAT_COMM_BYTES_C3 7  /* bytes of triplets this rank sent to the root of gathers (C3) */
 #define CRGPU_STAT_DISTINCT_KEYS 9          /* distinct molecule keys of the last count call (on this rank) */
 #define CRGPU_STAT_LOW_SUPPORT_CANDIDATES 10 /* of those, the keys the low-support filter had to group by (barcode, UMI) */
+#define CRGPU_STAT_MISS_RECORD_SETS 11       /* pass-A calls whose miss records are still kept for their pass B (at most 4) */
 #define CRGPU_STAT_SORT_REFINISHED 1 /* sorts redone on all key bits because a run of equal top bits was too long for the finishing pass */
 int crgpu_get_stat(crgpu_ctx *ctx, int which, uint64_t *value_out);
 /* ctx may be NULL: returns the message of the last failed crgpu_create on this thread. */

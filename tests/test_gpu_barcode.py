@@ -555,3 +555,38 @@ def test_table_of_frequent_barcodes_on_a_translated_list(variant, monkeypatch):
     assert np.array_equal(c.get_counts(1, COUNTS_CORRECTED), G.hist_as_rank_counts(res.corrected_hist[1], 16, canon_sorted))
     assert (res.bc_state == 2).sum() > 5_000 and (res.bc_state == 1).sum() > 400_000
     c.close()
+
+
+def test_miss_records_are_kept_per_call_and_dropped_by_the_range_that_is_written(monkeypatch):
+    """Pass A of every library of a well runs before the first pass B: the records of up to four pass-A calls are kept, each
+    until its pass B has used it.  A write through the context drops exactly the sets that describe the written range (the
+    feature extraction between the passes writes feature indices, not barcodes)."""
+    import gpu_helpers as G
+    from cellranger_amd import synth as S
+
+    monkeypatch.setenv("CRGPU_HOT_MIN_READS", "1")
+    n = 300_000
+    w = S.Workload(n_total=2 * n, seed=S.SEED0 + 23, n_wl=20_000, n_cells=300, n_ambient=2000)
+    c = G.fresh_ctx()
+    c.set_whitelist(0, w.wl_packed, length=16)
+    sets = lambda: c.stat(11)   # CRGPU_STAT_MISS_RECORD_SETS
+    dev = []
+    for k in range(2):
+        r = w.host_reads(k * n, n)
+        d = dict(cb=c.upload(r["cb"]), cbq=c.upload(r["cb_qualn"]), fl=c.upload(r["flags"]), idx=c.empty(n, np.uint32), r=r)
+        dev.append(d)
+    other = c.empty(n, np.uint32)
+    for k, d in enumerate(dev):
+        c.match_and_count(d["cb"], d["fl"], n, d["idx"])
+        assert sets() == k + 1
+    other.upload(np.zeros(n, np.uint32))                       # an unrelated buffer: both sets stay
+    assert sets() == 2
+    c.correct(dev[0]["cb"], dev[0]["cbq"], dev[0]["fl"], n, dev[0]["idx"])   # pass B consumes its set
+    assert sets() == 1
+    dev[1]["cb"].upload(dev[1]["r"]["cb"])                     # the barcodes of the second call rewritten: its set goes
+    assert sets() == 0
+    c.match_and_count(dev[1]["cb"], dev[1]["fl"], n, dev[1]["idx"])
+    assert sets() == 1
+    c.match_and_count(dev[1]["cb"], dev[1]["fl"], n, dev[1]["idx"])          # the same buffers again: replaced, not added
+    assert sets() == 1
+    c.close()
