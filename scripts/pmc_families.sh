@@ -24,7 +24,8 @@ def family(k):
     if k.startswith("void k_radix_scatter<unsigned long") : return "sort_scatter"
     if "k_build_keys" in k: return "keys"
     if any(x in k for x in ("k_lookup_hot", "k_stage_idx", "k_hist_buckets", "k_match_binned", "k_hot_", "k_match<")): return "match"
-    if any(x in k for x in ("k_correct_records", "k_collect_miss", "k_correct<", "k_region_offsets")): return "correct"
+    if any(x in k for x in ("k_correct_records", "k_collect_miss", "k_correct<", "k_region_offsets", "k_correct_sorted", "k_compact_records",
+                            "k_flag_corrected")): return "correct"
     if any(x in k for x in ("k_csc", "SeenFlag")): return "matrix"
     if any(x in k for x in ("k_extract_", "k_feature_counts", "k_match_features")): return "feature"
     if any(x in k for x in ("k_find_descents", "k_repair_runs", "k_order_runs", "k_global_hist")): return "sort_hist"
