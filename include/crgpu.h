@@ -292,7 +292,13 @@ int crgpu_match_and_count_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_
  * Corrected counts accumulate in the context.
  * When the call follows crgpu_match_and_count_dev on the SAME d_cb / d_flags / d_idx buffers and n (their contents
  * unchanged in between), the misses are taken from compact records that pass A left in the context instead of being
- * found again by a scan of d_idx; any other call sequence scans.  The results are identical either way. */
+ * found again by a scan of d_idx (the records of the last four pass-A calls are kept: the libraries of a well are looked
+ * up one after the other before the first pass B); any other call sequence scans.  The results are identical either way.
+ * d_flags, when given, must carry CRGPU_FLAG_CB_HAS_N for exactly the reads whose quality bytes have bit 7 set (the pack
+ * kernels write both): as in pass A the flag byte says which reads have an N, and a read without one fetches its quality
+ * line only when two or more candidates have to be weighed (a single candidate wins whatever the qualities are, unless
+ * the expected-error veto of crgpu_set_posterior is on).  Whitelists of more than 2 M entries take the recorded misses in
+ * barcode order: one search of the two pigeonhole bins per run of equal sequences. */
 int crgpu_set_posterior(crgpu_ctx *ctx, double max_expected_barcode_errors, double bc_confidence_threshold);
 int crgpu_correct_dev(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t *d_qualn, const uint8_t *d_flags,
                       uint64_t n, uint32_t *d_idx_inout, uint8_t *d_corrected_out);
