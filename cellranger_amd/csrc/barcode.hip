@@ -1664,20 +1664,57 @@ __global__ __launch_bounds__(256) void k_correct_records(const WlViewSet vs, con
                                                          const uint32_t *__restrict__ rec_count, uint32_t rec_cap,
                                                          uint32_t rec_regions, const K2Params P,
                                                          const uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rank_out,
-                                                         uint32_t parts) {
+                                                         uint32_t parts, const bool n_aside) {
     if (rec_count[rec_regions] != 0u) return;
+    // A read with an N takes another path than the others (four exact lookups, its quality line, prior counts: a longer chain of
+    // dependent loads), and a tenth of the misses of the cfg3 model are such reads: with them inline every wave ran both paths
+    // one after the other.  They are set aside in a queue of the wave instead (LDS; a wave runs in lockstep and its LDS
+    // operations complete in order) and worked off 64 at a time, so either path runs with all its lanes busy.
+    __shared__ uint32_t s_q[256 / 64][3][128];  // per wave: read index, key, slot of the record (for the rank sink)
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const bool set_aside = n_aside && P.have_flags && P.qualn != nullptr;
+    auto drain = [&](uint32_t from, uint32_t n_take, uint32_t base) {
+        if (lane < n_take) {
+            const uint32_t slot = s_q[wv][2][from + lane];
+            uint32_t *sink = rank_out ? rank_out + base + slot : nullptr;
+            k2_correct_one<true>(vs, P, s_q[wv][0][from + lane], s_q[wv][1][from + lane], vs.ulib | CRGPU_FLAG_CB_HAS_N, sink);
+        }
+    };
     // work items = (region, part): `parts` workgroups share a region's records (gridDim.x is a multiple of parts)
     for (uint32_t w = blockIdx.x; w < rec_regions * parts; w += gridDim.x) {
         const uint32_t r = w / parts, part = w % parts;
         const uint32_t cnt = rec_count[r];
         const uint32_t base = rank_out ? rec_off[r] : 0u;
         const uint32_t p_lo = (uint32_t)((uint64_t)cnt * part / parts), p_hi = (uint32_t)((uint64_t)cnt * (part + 1u) / parts);
-        for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += 256) {
-            const uint64_t o = (uint64_t)r * rec_cap + p;
+        uint32_t qn = 0;  // wave-uniform
+        for (uint32_t p0 = p_lo; p0 < p_hi; p0 += 256) {  // uniform trip count: the queue bookkeeping is wave-wide
+            const uint32_t p = p0 + threadIdx.x;
+            const bool live = p < p_hi;
+            const uint64_t o = (uint64_t)r * rec_cap + (live ? p : p_lo);
+            const uint32_t i = CR_LOAD_STREAM(&rec_i[o]), key = CR_LOAD_STREAM(&rec_key[o]), fl = CR_LOAD_STREAM(&rec_fl[o]);
             uint32_t *sink = rank_out ? rank_out + base + p : nullptr;
-            if (sink) *sink = CRGPU_MISS;
-            k2_correct_one<true>(vs, P, CR_LOAD_STREAM(&rec_i[o]), CR_LOAD_STREAM(&rec_key[o]), CR_LOAD_STREAM(&rec_fl[o]), sink);
+            if (live && sink) *sink = CRGPU_MISS;
+            const bool aside = live && set_aside && (fl & CRGPU_FLAG_CB_HAS_N) && (fl & CRGPU_FLAG_LIB_MASK) == vs.ulib;
+            if (live && !aside) k2_correct_one<true>(vs, P, i, key, fl, sink);
+            const unsigned long long m = __ballot(aside);
+            if (m) {
+                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (aside) {
+                    s_q[wv][0][at] = i;
+                    s_q[wv][1][at] = key;
+                    s_q[wv][2][at] = p;
+                }
+                qn += (uint32_t)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64u) {
+                    drain(qn - 64u, 64u, base);
+                    qn -= 64u;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
+        drain(0u, qn, base);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -2091,7 +2128,7 @@ static int correct_dev_impl(crgpu_ctx *ctx, const uint32_t *d_cb, const uint8_t 
         if (const char *g = getenv("CRGPU_K2_GRID")) k2_grid = (uint32_t)atoi(g) / k2_parts * k2_parts;  // A/B
         if (k2_grid < k2_parts) k2_grid = k2_parts;
         hipLaunchKernelGGL(k_correct_records, dim3(k2_grid), dim3(256), 0, ctx->stream, vs, rec.d_i, rec.d_key, rec.d_fl, rec.d_count,
-                           rec.cap, rec.regions, P, d_off, d_rank, k2_parts);
+                           rec.cap, rec.regions, P, d_off, d_rank, k2_parts, getenv("CRGPU_K2_N_INLINE") == nullptr);  // (A/B switch)
         int rc = CRGPU_OK;
         if (hipGetLastError() != hipSuccess) rc = cr_fail(ctx, CRGPU_EHIP, "crgpu_correct: launch failed");
         uint32_t total = 0;
