@@ -54,7 +54,8 @@ KERNEL_BYTES = {
               "sorted key: 8 B in, once (outputs, a few per cent of it, not counted)"),
     "feature": ("k_extract_tethered_lds (+ k_feature_counts)", 30, "FB read per pass: 15 captured bases + 15 qualities (SURVEY 8d)"),
 }
-PMC_PROFILE = "r03_cfg3_1B_pmc_fetch_write.json"  # the committed PMC passes of THIS round's code (scripts/pmc_families.sh)
+# the committed PMC passes of THIS round's code (scripts/pmc_families.sh), per workload at its default size
+PMC_PROFILE = {"cfg3": "r03_cfg3_1B_pmc_fetch_write.json", "cfg4": "r03_cfg4_500M_pmc_fetch_write.json"}
 
 
 def parse_args():
@@ -587,9 +588,9 @@ def main():
             # PMC profile of this round is attached only when it was taken on this very path, workload and size (the keys-only
             # count of cfg3 at 1 B reads with the 737 K list: not --dupinfo, not another workload)
             traffic, traffic_src = None, None
-            prof = os.path.join(ROOT, "profiles", PMC_PROFILE)
-            if (workload == "cfg3" and dup_out is None and world == 1 and n == 1_000_000_000 and args.whitelist == 737280
-                    and os.path.exists(prof)):
+            prof = os.path.join(ROOT, "profiles", PMC_PROFILE.get(workload, "none"))
+            at_profiled_size = (workload == "cfg3" and dup_out is None and n == 1_000_000_000) or (workload == "cfg4" and n == 500_000_000)
+            if at_profiled_size and world == 1 and args.whitelist == 737280 and os.path.exists(prof):
                 try:
                     with open(prof) as f:
                         per_el = json.load(f)["derived"].get(name + "_hbm_bytes_per_element")
