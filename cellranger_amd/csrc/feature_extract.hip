@@ -28,6 +28,7 @@
 #include <string>
 
 #include "common.h"
+#include "wl_view.h"  // U32x4: 16-byte loads from 4-byte aligned addresses
 
 struct FxPat {
     uint32_t read, tethered, anchor5, anchor3, never;
@@ -315,6 +316,7 @@ struct FxtParams {
     uint32_t pre_dots, suf_dots;  // the prefix / suffix hold wildcards only: nothing to compare
     uint32_t win_lo, win_dw;      // first byte (multiple of 4) and dwords of the row window staged into LDS
     uint32_t lanes_per_row;       // power of two >= win_dw, <= 64
+    uint32_t quad_lanes;          // 16-byte loads: power of two >= ceil(win_dw / 4) lanes share a row (0: rows shorter than 16 bytes)
     uint32_t pitch;               // LDS dwords per row (odd)
     uint32_t slot_mask;
     uint32_t halves;              // 1: the sorted half-key tables of the features are staged in LDS (posterior by pigeonhole)
@@ -519,7 +521,31 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
         const uint64_t wrow = base + (tid & ~63u);  // the wave's first row
         // ---- stage the window of 64 rows --------------------------------------------------------------------------
         __builtin_amdgcn_wave_barrier();
-        {
+        if (P.quad_lanes) {
+            // 16 bytes per lane and load (the window of a row in one or two loads instead of one per dword: fewer, wider memory
+            // instructions in flight for the same sectors); a quad that would run past its row starts earlier and the dwords are
+            // put where they belong
+            const uint32_t rows_per = 64u / P.quad_lanes, col = lane & (P.quad_lanes - 1u), sub = lane / P.quad_lanes;
+            const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(R.seq);
+            const uint32_t stride_dw = R.stride >> 2, lo_dw = P.win_lo >> 2;
+            const uint32_t quads = (P.win_dw + 3u) >> 2;
+            const uint32_t qc = col < quads ? col : quads - 1u;
+            const uint32_t d0 = lo_dw + 4u * qc + 4u <= stride_dw ? lo_dw + 4u * qc : stride_dw - 4u;
+#pragma unroll 2
+            for (uint32_t it = 0; it < P.quad_lanes; it++) {
+                const uint32_t r = it * rows_per + sub;
+                const uint64_t row = wrow + r;
+                const uint64_t rc = row < n ? row : n - 1;  // clamped: no load behind a branch
+                const U32x4 q4 = *reinterpret_cast<const U32x4 *>(src + rc * stride_dw + d0);
+                if (col < quads) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t c = d0 + k - lo_dw;  // (unsigned: a dword in front of the window wraps to a large value)
+                        if (c < P.win_dw) s_rows[r * P.pitch + c] = q4.w[k];
+                    }
+                }
+            }
+        } else {
             const uint32_t rows_per = 64u / P.lanes_per_row, col = lane & (P.lanes_per_row - 1u), sub = lane / P.lanes_per_row;
             const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(R.seq);
             const uint64_t stride_dw = R.stride >> 2;
@@ -995,7 +1021,11 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
         const uint32_t need = X.t_pre_len + X.t_L + X.t_suf_len;
         const bool aligned = R.stride % 4 == 0 && (uintptr_t)R.seq % 4 == 0;
         uint32_t win_lo = 0, win_hi = R.stride;           // floating pattern (or per-row lengths with '$'): the whole row
-        if (X.t_anchor5) win_hi = std::min(R.stride, (need + 3u) & ~3u);
+        if (X.t_anchor5) {
+            win_hi = std::min(R.stride, (need + 3u) & ~3u);
+            // a prefix of wildcards only ("^N{10}(BC)") is never looked at: the window starts at the capture
+            if (X.t_pre_dots && !getenv("CRGPU_FXT_DWORD_LOADS")) win_lo = X.t_pre_len & ~3u;
+        }
         else if (X.t_anchor3 && !R.len && need <= R.stride) win_lo = (R.stride - need) & ~3u;
         const uint32_t win_dw = (win_hi - win_lo) / 4u;
         if (aligned && win_dw >= 1 && win_dw <= 64u && R.stride >= 4 && X.t_pre_len + X.t_suf_len <= 256u) {
@@ -1014,6 +1044,11 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
             P.lanes_per_row = 1;
             while (P.lanes_per_row < win_dw) P.lanes_per_row <<= 1;
             P.pitch = win_dw | 1u;
+            P.quad_lanes = 0;
+            if (R.stride >= 16 && !getenv("CRGPU_FXT_DWORD_LOADS")) {  // (A/B switch: one dword per lane and load, as before)
+                P.quad_lanes = 1;
+                while (P.quad_lanes < (win_dw + 3u) / 4u) P.quad_lanes <<= 1;
+            }
             uint32_t slots = 64;
             while (slots < 2u * X.t_n_feat) slots <<= 1;  // load factor <= 0.5
             P.slot_mask = slots - 1u;
