@@ -316,6 +316,7 @@ struct FxtParams {
     uint32_t pre_dots, suf_dots;  // the prefix / suffix hold wildcards only: nothing to compare
     uint32_t win_lo, win_dw;      // first byte (multiple of 4) and dwords of the row window staged into LDS
     uint32_t lanes_per_row;       // power of two >= win_dw, <= 64
+    uint32_t prefetch;            // the next batch's row loads are issued before this batch is worked on (quad_lanes 1 or 2)
     uint32_t quad_lanes;          // 16-byte loads: power of two >= ceil(win_dw / 4) lanes share a row (0: rows shorter than 16 bytes)
     uint32_t pitch;               // LDS dwords per row (odd)
     uint32_t slot_mask;
@@ -517,30 +518,58 @@ __global__ __launch_bounds__(THREADS) void k_extract_tethered_lds(const FxView v
         return;
     }
 
+    // 16-byte staging (P.quad_lanes != 0): one or two loads per row.  With at most two, the NEXT batch's loads are issued before
+    // this batch is worked on and land in registers meanwhile (the kernel waited for its row loads half of the time)
+    const uint32_t q_rows_per = P.quad_lanes ? 64u / P.quad_lanes : 64u, q_col = P.quad_lanes ? lane & (P.quad_lanes - 1u) : 0u,
+                   q_sub = P.quad_lanes ? lane / P.quad_lanes : 0u;
+    const uint32_t q_stride_dw = R.stride >> 2, q_lo_dw = P.win_lo >> 2, q_quads = (P.win_dw + 3u) >> 2;
+    const uint32_t q_qc = q_col < q_quads ? q_col : q_quads - 1u;
+    const uint32_t q_d0 = q_lo_dw + 4u * q_qc + 4u <= q_stride_dw ? q_lo_dw + 4u * q_qc : q_stride_dw - 4u;  // a quad that would run past its row starts earlier
+    const uint32_t *__restrict__ q_src = reinterpret_cast<const uint32_t *>(R.seq);
+    const bool prefetch = P.prefetch != 0u;
+    U32x4 pf[2];
+    auto q_issue = [&](uint64_t wrow_of, U32x4 *out) {
+#pragma unroll
+        for (uint32_t it = 0; it < 2; it++) {
+            if (it >= P.quad_lanes) break;
+            const uint64_t row = wrow_of + it * q_rows_per + q_sub;
+            const uint64_t rc = row < n ? row : n - 1;  // clamped: no load behind a branch
+            out[it] = *reinterpret_cast<const U32x4 *>(q_src + rc * q_stride_dw + q_d0);
+        }
+    };
+    auto q_commit = [&](const U32x4 *in) {
+#pragma unroll
+        for (uint32_t it = 0; it < 2; it++) {
+            if (it >= P.quad_lanes) break;
+            const uint32_t r = it * q_rows_per + q_sub;
+            if (q_col < q_quads) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t c = q_d0 + k - q_lo_dw;  // (unsigned: a dword in front of the window wraps to a large value)
+                    if (c < P.win_dw) s_rows[r * P.pitch + c] = in[it].w[k];
+                }
+            }
+        }
+    };
+    if (prefetch && (uint64_t)blockIdx.x * THREADS < n) q_issue((uint64_t)blockIdx.x * THREADS + (tid & ~63u), pf);
     for (uint64_t base = (uint64_t)blockIdx.x * THREADS; base < n; base += (uint64_t)gridDim.x * THREADS) {
         const uint64_t wrow = base + (tid & ~63u);  // the wave's first row
         // ---- stage the window of 64 rows --------------------------------------------------------------------------
         __builtin_amdgcn_wave_barrier();
-        if (P.quad_lanes) {
-            // 16 bytes per lane and load (the window of a row in one or two loads instead of one per dword: fewer, wider memory
-            // instructions in flight for the same sectors); a quad that would run past its row starts earlier and the dwords are
-            // put where they belong
-            const uint32_t rows_per = 64u / P.quad_lanes, col = lane & (P.quad_lanes - 1u), sub = lane / P.quad_lanes;
-            const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(R.seq);
-            const uint32_t stride_dw = R.stride >> 2, lo_dw = P.win_lo >> 2;
-            const uint32_t quads = (P.win_dw + 3u) >> 2;
-            const uint32_t qc = col < quads ? col : quads - 1u;
-            const uint32_t d0 = lo_dw + 4u * qc + 4u <= stride_dw ? lo_dw + 4u * qc : stride_dw - 4u;
-#pragma unroll 2
+        if (prefetch) {
+            q_commit(pf);
+            const uint64_t next = base + (uint64_t)gridDim.x * THREADS;
+            if (next < n) q_issue(next + (tid & ~63u), pf);
+        } else if (P.quad_lanes) {
             for (uint32_t it = 0; it < P.quad_lanes; it++) {
-                const uint32_t r = it * rows_per + sub;
+                const uint32_t r = it * q_rows_per + q_sub;
                 const uint64_t row = wrow + r;
-                const uint64_t rc = row < n ? row : n - 1;  // clamped: no load behind a branch
-                const U32x4 q4 = *reinterpret_cast<const U32x4 *>(src + rc * stride_dw + d0);
-                if (col < quads) {
+                const uint64_t rc = row < n ? row : n - 1;
+                const U32x4 q4 = *reinterpret_cast<const U32x4 *>(q_src + rc * q_stride_dw + q_d0);
+                if (q_col < q_quads) {
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) {
-                        const uint32_t c = d0 + k - lo_dw;  // (unsigned: a dword in front of the window wraps to a large value)
+                        const uint32_t c = q_d0 + k - q_lo_dw;
                         if (c < P.win_dw) s_rows[r * P.pitch + c] = q4.w[k];
                     }
                 }
@@ -1049,6 +1078,7 @@ extern "C" int crgpu_extract_features_dev(crgpu_ctx *ctx, int extractor, const u
                 P.quad_lanes = 1;
                 while (P.quad_lanes < (win_dw + 3u) / 4u) P.quad_lanes <<= 1;
             }
+            P.prefetch = (P.quad_lanes == 1u || P.quad_lanes == 2u) && !getenv("CRGPU_FXT_NO_PREFETCH");  // (A/B switch)
             uint32_t slots = 64;
             while (slots < 2u * X.t_n_feat) slots <<= 1;  // load factor <= 0.5
             P.slot_mask = slots - 1u;
