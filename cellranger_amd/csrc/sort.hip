@@ -57,7 +57,7 @@
 #endif
 #ifndef SORT_MAX_BLOCKS
 #define SORT_MAX_BLOCKS 1024
-#define OR_MAX_LOW_BITS 8u  // low key bits the finishing step may be left with (bucket arrays of or_run_through_memory)
+#define OR_MAX_LOW_BITS 16u  // low key bits the finishing step may be left with (two levels of bucket arrays in or_run_through_memory)
 #endif
 
 // ---- exclusive scan of a small u32 array (block counts of the compactions), single workgroup -----
@@ -768,17 +768,20 @@ uint32_t cr_sort_low_bits(uint32_t total_bits, uint32_t umi_bits) {
         const uint32_t low = total_bits - 9 * p;          // <= 16 by construction
         return p < full ? low : 0;
     }
-    // at most 8 low bits: or_run_through_memory orders a long run by an in-place permutation over 2^low <= 256 buckets held in
-    // registers / scratch (ten bits -- 64-bit keys in six passes -- overran those arrays and hung the repair kernel on the
-    // 6.8 M-entry list: measured once, reverted); at least 14 UMI bits stay above the cut
-    static_assert(OR_MAX_LOW_BITS == 8, "or_run_through_memory: cnt[] / nxt[] hold 256 buckets");
+    // at most OR_MAX_LOW_BITS low bits, and at least 14 UMI bits above the cut (sixteen low bits for the 61-bit layout -- five passes --
+    // make the runs whole groups of UMIs and the finishing step 24 ms: measured): runs of up to 12 keys are ordered in registers
+    // (k_repair_runs), up to 64 by a wave (k_repair_medium_runs), longer ones by a workgroup in LDS (k_repair_long_runs); what does
+    // not fit the lists or LDS is walked through memory by one lane (two levels of at most 256 buckets beyond eight bits)
+    static_assert(OR_MAX_LOW_BITS >= 8 && OR_MAX_LOW_BITS <= 16, "or_run_through_memory: two levels of at most 256 buckets");
     uint32_t best_low = 0, best_passes = full;
+    uint32_t umi_above = 14u;  // UMI bits that stay above the cut (CRGPU_SORT_UMI_ABOVE: A/B)
+    if (const char *ua = getenv("CRGPU_SORT_UMI_ABOVE")) umi_above = (uint32_t)atoi(ua);
     for (uint32_t low = 1; low <= OR_MAX_LOW_BITS && low < total_bits; low++) {
         const uint32_t top = total_bits - low;
         const uint32_t q8 = (top + 7) / 8, q9 = (top + 8) / 9;
         const uint32_t q = q9 < q8 ? q9 : q8;
         // bit 0 is the UmiType bit, the UMI sits right above it: low - 1 of its bits fall below the cut
-        if (q < best_passes && umi_bits >= 14u + (low - 1u)) {  // the fewest passes; among equals the fewest low bits
+        if (q < best_passes && umi_bits >= umi_above + (low - 1u)) {  // the fewest passes; among equals the fewest low bits
             best_passes = q;
             best_low = low;
         }
@@ -925,6 +928,42 @@ __global__ __launch_bounds__(256) void k_finish_runs(uint64_t *__restrict__ keys
 #define OR_CAP 32u      // runs up to this length: insertion sort
 #define OR_MAX 65536u   // longer runs than this are not scanned by one lane: the caller sorts on all bits
 // one lane puts the run [i, e) in order through memory: e found by scanning, nothing to do when it is already ordered
+// in-place bucket permutation (American flag sort) of keys[a, e) on the `bits` (<= 8) bits above `shift`; cnt / nxt hold 2^bits
+// entries; on return cnt[d] = end of bucket d (relative to a)
+template <bool HAS_VALS>
+__device__ void or_flag_permute(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t a, uint64_t e, uint32_t shift,
+                                uint32_t bits, uint32_t *cnt, uint32_t *nxt) {
+    const uint32_t nb = 1u << bits, dm = nb - 1u;
+    for (uint32_t d = 0; d < nb; d++) cnt[d] = 0;
+    for (uint64_t x = a; x < e; x++) cnt[(uint32_t)(keys[x] >> shift) & dm]++;
+    uint32_t acc = 0;
+    for (uint32_t d = 0; d < nb; d++) {
+        nxt[d] = acc;
+        acc += cnt[d];
+        cnt[d] = acc;  // end of bucket d
+    }
+    for (uint32_t d = 0; d < nb; d++) {
+        while (nxt[d] < cnt[d]) {
+            const uint64_t k = keys[a + nxt[d]];
+            const uint32_t kd = (uint32_t)(k >> shift) & dm;
+            if (kd == d) {
+                nxt[d]++;
+            } else {
+                const uint64_t t = a + nxt[kd];
+                const uint64_t o = keys[t];
+                keys[t] = k;
+                keys[a + nxt[d]] = o;
+                if (HAS_VALS) {
+                    const uint32_t va = vals[a + nxt[d]], vb = vals[t];
+                    vals[t] = va;
+                    vals[a + nxt[d]] = vb;
+                }
+                nxt[kd]++;
+            }
+        }
+    }
+}
+
 template <bool HAS_VALS>
 __device__ void or_run_through_memory(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low, uint64_t i,
                                       uint32_t *__restrict__ bad) {
@@ -962,40 +1001,26 @@ __device__ void or_run_through_memory(uint64_t *__restrict__ keys, uint32_t *__r
         return;
     }
     // a long run that mixes low bits (many reads of one UMI with both UmiTypes, ...): in-place bucket permutation on the
-    // low bits (American flag sort, at most 256 buckets)
+    // low bits (American flag sort).  Up to 8 low bits: one level of at most 256 buckets; 9 .. OR_MAX_LOW_BITS: first on the
+    // bits above the low eight (at most 8 buckets), then every such bucket on its low eight.  (The bucket arrays live in
+    // scratch, per lane: 256 entries each is what a kernel with 256-thread workgroups can afford.)
     uint32_t cnt[256], nxt[256];
     if (low > OR_MAX_LOW_BITS) {  // cannot happen (cr_sort_low_bits): never overrun the arrays, let the caller sort on all bits
         atomicOr(bad, 1u);
         return;
     }
-    const uint32_t nb = 1u << low, dm = nb - 1u;
-    for (uint32_t d = 0; d < nb; d++) cnt[d] = 0;
-    for (uint64_t a = i; a < e; a++) cnt[(uint32_t)keys[a] & dm]++;
-    uint32_t acc = 0;
-    for (uint32_t d = 0; d < nb; d++) {
-        nxt[d] = acc;
-        acc += cnt[d];
-        cnt[d] = acc;  // end of bucket d
+    if (low <= 8u) {
+        or_flag_permute<HAS_VALS>(keys, vals, i, e, 0u, low, cnt, nxt);
+        return;
     }
-    for (uint32_t d = 0; d < nb; d++) {
-        while (nxt[d] < cnt[d]) {
-            const uint64_t k = keys[i + nxt[d]];
-            const uint32_t kd = (uint32_t)k & dm;
-            if (kd == d) {
-                nxt[d]++;
-            } else {
-                const uint64_t t = i + nxt[kd];
-                const uint64_t o = keys[t];
-                keys[t] = k;
-                keys[i + nxt[d]] = o;
-                if (HAS_VALS) {
-                    const uint32_t va = vals[i + nxt[d]], vb = vals[t];
-                    vals[t] = va;
-                    vals[i + nxt[d]] = vb;
-                }
-                nxt[kd]++;
-            }
-        }
+    uint32_t ends[1u << (OR_MAX_LOW_BITS - 8u)];
+    const uint32_t hi_bits = low - 8u;
+    or_flag_permute<HAS_VALS>(keys, vals, i, e, 8u, hi_bits, cnt, nxt);
+    for (uint32_t d = 0; d < (1u << hi_bits); d++) ends[d] = cnt[d];
+    uint32_t from = 0;
+    for (uint32_t d = 0; d < (1u << hi_bits); d++) {
+        if (ends[d] - from > 1u) or_flag_permute<HAS_VALS>(keys, vals, i + from, i + ends[d], 0u, 8u, cnt, nxt);
+        from = ends[d];
     }
 }
 
@@ -1139,9 +1164,13 @@ __global__ __launch_bounds__(256) void k_find_descents(const uint64_t *__restric
 
 #define RR_SHORT 12u  // runs up to this many keys are ordered in registers
 // one descent: find the head of its run and, when it is the run's first descent, put the run in order
+// later_list (nullable) / later_n / later_cap: a run longer than RR_SHORT is not walked through memory by this lane but noted
+// (its head) in a device-wide list for k_repair_medium_runs
 template <bool HAS_VALS>
 __device__ __forceinline__ void repair_at(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low,
-                                          const unsigned long long *__restrict__ desc, uint64_t p, uint32_t *__restrict__ bad) {
+                                          const unsigned long long *__restrict__ desc, uint64_t p, uint32_t *__restrict__ bad,
+                                          unsigned long long *__restrict__ later_list = nullptr,
+                                          uint32_t *__restrict__ later_n = nullptr, uint32_t later_cap = 0u) {
     // keys[p] < keys[p - 1], same top bits.  Walk back to the head of the run.  An earlier descent on the way means another
     // lane owns the run.  Only things that no repair changes are looked at: the descent bits (read-only here) and the TOP
     // bits of the keys (a repair permutes keys inside one run, whose top bits are all equal) -- the owner may already be
@@ -1175,6 +1204,13 @@ __device__ __forceinline__ void repair_at(uint64_t *__restrict__ keys, uint32_t 
     if (len > RR_SHORT) {
         // is the key right behind the window still part of the run?
         if (h + RR_SHORT < n && (keys[h + RR_SHORT] >> low) == top) {
+            if (later_list) {
+                const uint32_t slot = atomicAdd(later_n, 1u);
+                if (slot < later_cap) {
+                    later_list[slot] = h;
+                    return;
+                }
+            }
             or_run_through_memory<HAS_VALS>(keys, vals, n, low, h, bad);
             return;
         }
@@ -1217,7 +1253,8 @@ __device__ __forceinline__ void repair_at(uint64_t *__restrict__ keys, uint32_t 
 template <bool HAS_VALS>
 __global__ __launch_bounds__(256) void k_repair_runs(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low,
                                                      const unsigned long long *__restrict__ desc, uint64_t n_words,
-                                                     uint32_t *__restrict__ bad) {
+                                                     uint32_t *__restrict__ bad, unsigned long long *__restrict__ med_list,
+                                                     uint32_t *__restrict__ n_med, uint32_t med_cap) {
     __shared__ uint32_t s_n;
     __shared__ uint32_t s_pos[RR_CAP];  // position inside the tile (RR_WORDS * 64 keys: 17 bits)
     const uint64_t n_tiles = (n_words + RR_WORDS - 1) / RR_WORDS;
@@ -1232,12 +1269,124 @@ __global__ __launch_bounds__(256) void k_repair_runs(uint64_t *__restrict__ keys
                 m &= m - 1ull;
                 const uint32_t slot = atomicAdd(&s_n, 1u);
                 if (slot < RR_CAP) s_pos[slot] = j * 64u + b;
-                else repair_at<HAS_VALS>(keys, vals, n, low, desc, (w0 + j) * 64 + b, bad);  // a tile full of descents: at once
+                else repair_at<HAS_VALS>(keys, vals, n, low, desc, (w0 + j) * 64 + b, bad, med_list, n_med, med_cap);  // a tile full of descents: at once
             }
         }
         __syncthreads();
         const uint32_t cnt = s_n < RR_CAP ? s_n : RR_CAP;
-        for (uint32_t t = threadIdx.x; t < cnt; t += 256) repair_at<HAS_VALS>(keys, vals, n, low, desc, w0 * 64 + s_pos[t], bad);
+        for (uint32_t t = threadIdx.x; t < cnt; t += 256)
+            repair_at<HAS_VALS>(keys, vals, n, low, desc, w0 * 64 + s_pos[t], bad, med_list, n_med, med_cap);
+        __syncthreads();
+        __syncthreads();
+    }
+}
+
+// Runs of RR_SHORT + 1 .. 64 keys with a descent (the reads of a larger molecule, some with a sequencing error in the low UMI
+// bases): one WAVE each -- a lane per key, the key's place = the number of keys of the run that go before it (by value, ties
+// by position: the stable order), found with one broadcast per member.  The heads come from a device-wide list, so the
+// waves share them evenly: inside k_repair_runs the tiles of a few hot barcodes held thousands of such runs each and
+// made the kernel's makespan (8.6 ms with ten low bits), as did one lane walking a run through memory (tens of us).
+// A run that goes on behind the wave's 64 keys is passed on to k_repair_long_runs.
+template <bool HAS_VALS>
+__global__ __launch_bounds__(256) void k_repair_medium_runs(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n,
+                                                            uint32_t low, const unsigned long long *__restrict__ med_list,
+                                                            const uint32_t *__restrict__ n_med, uint32_t med_cap,
+                                                            unsigned long long *__restrict__ long_list, uint32_t *__restrict__ n_long,
+                                                            uint32_t long_cap, uint32_t *__restrict__ bad) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cnt = *n_med < med_cap ? *n_med : med_cap;
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < cnt; t += n_waves) {  // wave-uniform
+        const uint64_t h = med_list[t];
+        const uint64_t at = h + lane < n ? h + lane : n - 1;
+        const uint64_t key = keys[at];
+        const uint32_t val = HAS_VALS ? vals[at] : 0u;
+        const uint64_t top = __shfl(key, 0) >> low;
+        const unsigned long long in = __ballot(h + lane < n && (key >> low) == top);
+        const uint32_t len = ~in ? (uint32_t)__ffsll((long long)~in) - 1u : 64u;  // the leading lanes that agree with the head
+        const bool goes_on = len == 64u && h + 64u < n && (keys[h + 64u] >> low) == top;
+        if (goes_on) {
+            if (lane == 0) {
+                const uint32_t slot = long_cap ? atomicAdd(n_long, 1u) : 0xFFFFFFFFu;
+                if (slot < long_cap) long_list[slot] = h;
+                else or_run_through_memory<HAS_VALS>(keys, vals, n, low, h, bad);
+            }
+            continue;
+        }
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < len; i++) {  // uniform
+            const uint64_t ki = __shfl(key, (int)i);
+            rank += (ki < key || (ki == key && i < lane)) ? 1u : 0u;
+        }
+        if (lane < len && rank != lane) {  // (every key of the run is in a register by now: the stores cannot hit a key not yet read)
+            keys[h + rank] = key;
+            if (HAS_VALS) vals[h + rank] = val;
+        }
+    }
+}
+
+// Runs of more than 64 keys with a descent (the reads of a large molecule, a few of them with a sequencing error in the low UMI
+// bases): one WORKGROUP each.  The keys of a run differ in their low bits only, so the run is sorted as 32-bit words
+// (low bits << 12 | position in the run) by a bitonic network in LDS -- the position makes the order the stable one -- and
+// written back from there.  One lane walking such a run through memory took milliseconds (3 us per key) and was the
+// kernel's whole makespan once ten low bits were left to the repair step.  Runs beyond RL_CAP keys: through memory.
+#define RL_CAP 4096u
+template <bool HAS_VALS>
+__global__ __launch_bounds__(256) void k_repair_long_runs(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint64_t n, uint32_t low,
+                                                          const unsigned long long *__restrict__ long_list,
+                                                          const uint32_t *__restrict__ n_long, uint32_t long_cap,
+                                                          uint32_t *__restrict__ bad) {
+    __shared__ uint32_t s_c[RL_CAP];
+    __shared__ uint32_t s_v[HAS_VALS ? RL_CAP : 1];
+    __shared__ uint32_t s_len;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cnt = *n_long < long_cap ? *n_long : long_cap;
+    const uint64_t lowmask = (1ull << low) - 1ull;
+    for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
+        const uint64_t h = long_list[it];
+        const uint64_t top = keys[h] >> low;
+        if (tid == 0) s_len = RL_CAP + 1u;
+        __syncthreads();
+        // the run's length: the first position behind h whose top bits differ (RL_CAP + 1: the run goes on behind the window)
+        for (uint32_t j = tid; j <= RL_CAP; j += 256) {
+            const bool out = h + j >= n || (keys[h + j] >> low) != top;
+            if (out) atomicMin(&s_len, j);
+        }
+        __syncthreads();
+        const uint32_t len = s_len;
+        if (len > RL_CAP) {  // uniform
+            if (tid == 0) or_run_through_memory<HAS_VALS>(keys, vals, n, low, h, bad);
+            __syncthreads();
+            continue;
+        }
+        uint32_t P = 128;
+        while (P < len) P <<= 1;
+        for (uint32_t j = tid; j < P; j += 256) {
+            s_c[j] = j < len ? ((uint32_t)(keys[h + j] & lowmask) << 12) | j : 0xFFFFFFFFu;
+            if (HAS_VALS && j < len) s_v[j] = vals[h + j];
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t x = tid; x < P / 2; x += 256) {
+                    const uint32_t a = 2u * x - (x & (j - 1u));  // lower index of the pair at distance j
+                    const uint32_t b = a + j;
+                    const bool up = (a & k) == 0u;
+                    const uint32_t ca = s_c[a], cb = s_c[b];
+                    if ((ca > cb) == up) {
+                        s_c[a] = cb;
+                        s_c[b] = ca;
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t j = tid; j < len; j += 256) {
+            const uint32_t c = s_c[j];
+            if ((c & 4095u) != j) {
+                keys[h + j] = (top << low) | (uint64_t)(c >> 12);
+                if (HAS_VALS) vals[h + j] = s_v[c & 4095u];
+            }
+        }
         __syncthreads();
     }
 }
@@ -1245,28 +1394,49 @@ __global__ __launch_bounds__(256) void k_repair_runs(uint64_t *__restrict__ keys
 int cr_repair_runs(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t low_bits, bool *fell_back) {
     *fell_back = false;
     if (n < 2 || low_bits == 0) return CRGPU_OK;
-    uint32_t *d_flag = ctx->d_scalars + 52, *d_set = ctx->d_scalars + 53;
+    uint32_t *d_flag = ctx->d_scalars + 52, *d_set = ctx->d_scalars + 53, *d_nlong = ctx->d_scalars + 54, *d_nmed = ctx->d_scalars + 55;
     const uint64_t n_words = (n + 63) / 64;
-    void *d_desc = nullptr;
+    void *d_desc = nullptr, *d_long = nullptr, *d_med = nullptr;
     CR_TRY(cr_pool_alloc(ctx, &d_desc, n_words * sizeof(unsigned long long)));
     struct Rel {
         crgpu_ctx *c;
-        void *p;
+        void *&p;
         ~Rel() { cr_pool_free(c, p); }
-    } rel{ctx, d_desc};
+    } rel{ctx, d_desc}, rel_long{ctx, d_long}, rel_med{ctx, d_med};
+    // heads of the runs of more than 64 keys that need work (a run has at least 65 keys: at most n / 65 of them; capped)
+    uint32_t long_cap = (uint32_t)std::min<uint64_t>(n / 65 + 1, 1u << 20);
+    if (cr_pool_alloc(ctx, &d_long, (uint64_t)long_cap * sizeof(unsigned long long)) != CRGPU_OK) {
+        d_long = nullptr;  // not fatal: such runs are walked through memory
+        long_cap = 0;
+    }
+    // ... and of the runs of 13 .. 64 keys (at most n / 13; capped: beyond it a lane walks the run through memory)
+    uint32_t med_cap = (uint32_t)std::min<uint64_t>(n / 13 + 1, 1u << 24);
+    if (cr_pool_alloc(ctx, &d_med, (uint64_t)med_cap * sizeof(unsigned long long)) != CRGPU_OK) {
+        d_med = nullptr;
+        med_cap = 0;
+    }
     {
         CrTimer t(ctx, CRGPU_T_SORT_HIST, n);  // booked beside the histogram slot: "sort, not a scatter pass"
-        CR_HIP(ctx, hipMemsetAsync(d_flag, 0, 2 * sizeof(uint32_t), ctx->stream));
+        CR_HIP(ctx, hipMemsetAsync(d_flag, 0, 4 * sizeof(uint32_t), ctx->stream));
         const uint64_t n_spans = (n + 64ull * FD_ITEMS - 1) / (64ull * FD_ITEMS);
         hipLaunchKernelGGL(k_find_descents, dim3(cr_grid(n_spans * 64u, 256, 256u * 8u)), dim3(256), 0, ctx->stream, d_keys, n, low_bits,
                            (unsigned long long *)d_desc, d_set);
         const dim3 grid(cr_grid((n_words + RR_WORDS - 1) / RR_WORDS, 1, 256u * 8u));
-        if (d_vals)
-            hipLaunchKernelGGL(k_repair_runs<true>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits,
-                               (const unsigned long long *)d_desc, n_words, d_flag);
-        else
-            hipLaunchKernelGGL(k_repair_runs<false>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits,
-                               (const unsigned long long *)d_desc, n_words, d_flag);
+#define CR_REPAIR_LAUNCH(HV)                                                                                                          \
+    hipLaunchKernelGGL(k_repair_runs<HV>, grid, dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits,                                   \
+                       (const unsigned long long *)d_desc, n_words, d_flag, (unsigned long long *)d_med, d_nmed, med_cap);                \
+    if (med_cap)                                                                                                                          \
+        hipLaunchKernelGGL(k_repair_medium_runs<HV>, dim3(256u * 8u), dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits,             \
+                           (const unsigned long long *)d_med, d_nmed, med_cap, (unsigned long long *)d_long, d_nlong, long_cap, d_flag); \
+    if (long_cap)                                                                                                                         \
+        hipLaunchKernelGGL(k_repair_long_runs<HV>, dim3(256u * 4u), dim3(256), 0, ctx->stream, d_keys, d_vals, n, low_bits,               \
+                           (const unsigned long long *)d_long, d_nlong, long_cap, d_flag)
+        if (d_vals) {
+            CR_REPAIR_LAUNCH(true);
+        } else {
+            CR_REPAIR_LAUNCH(false);
+        }
+#undef CR_REPAIR_LAUNCH
         CR_HIP(ctx, hipGetLastError());
     }
     uint32_t flag = 0;

@@ -331,8 +331,9 @@ def _needs_onesweep():
         pytest.skip("CRGPU_SORT=classic: the onesweep path under test is switched off")
 
 
-@pytest.mark.parametrize("big_run,finish", [(50_000, "0"), (50_000, "2"), (90_000, "2"), (50_000, "3"), (90_000, "3")])
-def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, monkeypatch):
+@pytest.mark.parametrize("big_run,finish,wide", [(50_000, "0", False), (50_000, "2", False), (90_000, "2", False), (50_000, "3", False),
+                                                 (90_000, "3", False), (50_000, "2", True), (90_000, "2", True)])
+def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, wide, monkeypatch):
     """UMIs that differ only in their last bases (three 8-base prefixes), UmiTypes mixed inside every UMI, and keys that
     agree in everything but the last 2.5 bases of the UMI in runs of 2..30, of 100 and of 50 000 reads: Hamming-1
     neighbourhoods are dense, counts tie, and one (barcode, feature) segment holds most of the reads.
@@ -340,7 +341,9 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, mo
     lowest key bits that save a pass to k_find_descents + k_repair_runs (only the runs of equal top bits that are out of order
     are touched: insertion up to 32 keys, in-place bucket permutation up to 65 536); "3" = round 2's k_order_runs (runs inside
     a wave by an odd-even transposition in registers).  A run of 90 000 keys makes either hand the job back to a sort on all
-    bits (CRGPU_STAT_SORT_REFINISHED)."""
+    bits (CRGPU_STAT_SORT_REFINISHED).  wide: a 6.8 M-entry whitelist and 36 601 features make the key 64 bits wide; the
+    passes then leave TEN low bits (six passes instead of seven): runs of 13 .. 64 keys are put in order by a wave (a lane per
+    key, place = number of keys that go before it), the long run by the two-level bucket permutation."""
     top_bits_sort = finish != "0"
     if top_bits_sort:
         _needs_onesweep()
@@ -351,8 +354,8 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, mo
     from cellranger_amd._lib import FLAG_NONTXOMIC
 
     n = 260_000
-    w = S.Workload(n_total=n, seed=31, n_wl=2000, n_cells=40, n_ambient=200, n_genes=40, umi_len=12, umi_err=0.0, cb_err=0.01,
-                   n_rate=0.001, no_feature_frac=0.05, reads_per_umi=1)
+    w = S.Workload(n_total=n, seed=31, n_wl=6_794_880 if wide else 2000, n_cells=40, n_ambient=200, n_genes=40, umi_len=12, umi_err=0.0,
+                   cb_err=0.01, n_rate=0.001, no_feature_frac=0.05, reads_per_umi=1)
     c = G.fresh_ctx(dense=False)   # the run lengths this test plants belong to the 42-bit whitelist-rank layout
     c.set_whitelist(0, w.wl_packed, length=16)
     r = w.host_reads(0, n)
@@ -371,7 +374,7 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, mo
         r["umi"][s:s + 100] = (r["umi"][s] & ~np.uint32(31)) | rng.integers(0, 32, 100, dtype=np.uint32)
     r["flags"][:big_run + 2_000] = r["flags"][0] & 0x0F     # the planted runs copy a barcode without N
     r["flags"] = (r["flags"] | np.where(rng.random(n) < 0.4, FLAG_NONTXOMIC, 0)).astype(np.uint8)
-    res, m = _compare_with_oracle(c, w, r, n, 40)
+    res, m = _compare_with_oracle(c, w, r, n, 36_601 if wide else 40)
     assert m.nnz > 1000
     assert (c.stat(1) > 0) == (top_bits_sort and big_run > 65_536)   # CRGPU_STAT_SORT_REFINISHED
     c.close()
