@@ -416,11 +416,16 @@ __global__ __launch_bounds__(EdgeCfg<SMALL>::THREADS) void k_correct_umis_edges(
 // best[k] = (count << 32) | index of the best key found so far for k (its own to start with).  Inside a segment
 // the index order is the UMI order, so the packed value orders exactly like (count, UMI) and atomicMax merges
 // the findings of the workgroups that probe different table chunks.
+#define GI_HALO 512u  // keys staged in front of and behind the chunk
 __global__ __launch_bounds__(UE_THREADS) void k_giant_init(const KL kl, const uint64_t *__restrict__ ukey,
                                                            const uint32_t *__restrict__ upos, uint64_t nd, uint64_t n_keys,
                                                            const GiantItem *__restrict__ items,
                                                            const uint32_t *__restrict__ n_items_ptr,
                                                            unsigned long long *__restrict__ best) {
+    // The runs of equal high halves around the chunk's keys are walked in LDS: the chunk and GI_HALO keys on either side are
+    // staged once, coalesced (UMI and read count); only a run that leaves the staged window goes on in global memory.  (Every
+    // step of the walk used to be two dependent global loads: 0.7 ms for a few million keys.)
+    __shared__ uint32_t s_u[UE_CAP + 2 * GI_HALO], s_c[UE_CAP + 2 * GI_HALO];
     const uint32_t n_items = *n_items_ptr;
     const uint64_t umi_mask = lowmask(kl.bits_umi);
     const UmiSplit sp = umi_split(kl.umi_len);
@@ -428,28 +433,63 @@ __global__ __launch_bounds__(UE_THREADS) void k_giant_init(const KL kl, const ui
         const GiantItem g = items[it];
         const uint64_t s = g.s, e = g.e;
         const uint64_t c1 = (uint64_t)g.c0 + UE_CAP < e ? (uint64_t)g.c0 + UE_CAP : e;
-        // same-high-half neighbours: the run around each key in the sorted global array
+        const uint64_t w0 = (uint64_t)g.c0 >= s + GI_HALO ? (uint64_t)g.c0 - GI_HALO : s;  // staged window [w0, w1) inside the segment
+        const uint64_t w1 = c1 + GI_HALO < e ? c1 + GI_HALO : e;
+        __syncthreads();
+        for (uint64_t k = w0 + threadIdx.x; k < w1; k += UE_THREADS) {
+            s_u[k - w0] = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
+            s_c[k - w0] = run_count(upos, nd, n_keys, k);
+        }
+        __syncthreads();
+        // same-high-half neighbours: the run around each key in the sorted array
         for (uint64_t k = g.c0 + threadIdx.x; k < c1; k += UE_THREADS) {
-            const uint32_t my_umi = (uint32_t)((ukey[k] >> kl.sh_umi) & umi_mask);
+            const uint32_t my_umi = s_u[k - w0];
             const uint32_t my_hi = my_umi >> sp.lo_bits, my_lo = my_umi & sp.lo_mask;
-            unsigned long long b = ((unsigned long long)run_count(upos, nd, n_keys, k) << 32) | (uint32_t)k;
-            for (uint64_t q = k; q > s;) {
+            unsigned long long b = ((unsigned long long)s_c[k - w0] << 32) | (uint32_t)k;
+            bool open = true;  // the run may go on in front of the window
+            for (uint64_t q = k; q > w0;) {
                 --q;
-                const uint32_t u = (uint32_t)((ukey[q] >> kl.sh_umi) & umi_mask);
-                if ((u >> sp.lo_bits) != my_hi) break;
+                const uint32_t u = s_u[q - w0];
+                if ((u >> sp.lo_bits) != my_hi) {
+                    open = false;
+                    break;
+                }
                 if (hd1(u & sp.lo_mask, my_lo)) {
-                    const unsigned long long c = ((unsigned long long)run_count(upos, nd, n_keys, q) << 32) | (uint32_t)q;
+                    const unsigned long long c = ((unsigned long long)s_c[q - w0] << 32) | (uint32_t)q;
                     b = c > b ? c : b;
                 }
             }
-            for (uint64_t q = k + 1; q < e; q++) {
-                const uint32_t u = (uint32_t)((ukey[q] >> kl.sh_umi) & umi_mask);
-                if ((u >> sp.lo_bits) != my_hi) break;
+            if (open)
+                for (uint64_t q = w0; q > s;) {
+                    --q;
+                    const uint32_t u = (uint32_t)((ukey[q] >> kl.sh_umi) & umi_mask);
+                    if ((u >> sp.lo_bits) != my_hi) break;
+                    if (hd1(u & sp.lo_mask, my_lo)) {
+                        const unsigned long long c = ((unsigned long long)run_count(upos, nd, n_keys, q) << 32) | (uint32_t)q;
+                        b = c > b ? c : b;
+                    }
+                }
+            open = true;
+            for (uint64_t q = k + 1; q < w1; q++) {
+                const uint32_t u = s_u[q - w0];
+                if ((u >> sp.lo_bits) != my_hi) {
+                    open = false;
+                    break;
+                }
                 if (hd1(u & sp.lo_mask, my_lo)) {
-                    const unsigned long long c = ((unsigned long long)run_count(upos, nd, n_keys, q) << 32) | (uint32_t)q;
+                    const unsigned long long c = ((unsigned long long)s_c[q - w0] << 32) | (uint32_t)q;
                     b = c > b ? c : b;
                 }
             }
+            if (open)
+                for (uint64_t q = w1; q < e; q++) {
+                    const uint32_t u = (uint32_t)((ukey[q] >> kl.sh_umi) & umi_mask);
+                    if ((u >> sp.lo_bits) != my_hi) break;
+                    if (hd1(u & sp.lo_mask, my_lo)) {
+                        const unsigned long long c = ((unsigned long long)run_count(upos, nd, n_keys, q) << 32) | (uint32_t)q;
+                        b = c > b ? c : b;
+                    }
+                }
             best[k] = b;
         }
     }
