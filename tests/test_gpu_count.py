@@ -417,7 +417,7 @@ def test_random_key_layouts_bit_exact(status64, monkeypatch):
     assert len(seen_bits) >= 8 and max(seen_bits) >= 58 and min(seen_bits) <= 30
 
 
-@pytest.mark.parametrize("bad_pass,finish,status64", [(0, "2", False), (2, "2", False), (4, "2", False), (5, "0", False),
+@pytest.mark.parametrize("bad_pass,finish,status64", [(0, "2", False), (2, "2", False), (3, "2", False), (5, "0", False),
                                                       (1, "2", True), (3, "0", True)])
 def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, finish, status64, monkeypatch):
     """The look-back chain of one onesweep pass is stalled on purpose (CRGPU_SORT_FORCE_ABORT: chunk 0 never publishes).
@@ -436,7 +436,8 @@ def test_onesweep_watchdog_falls_back_to_the_classic_passes(bad_pass, finish, st
     c = G.fresh_ctx()
     c.set_whitelist(0, w.wl_packed, length=16)
     # 16 + 9 + 24 + 1 = 50 bits: six passes (8+8+8+8+9+9) on all bits (finish "0"), five 9-bit passes on the top 45 bits +
-    # k_repair_runs on the low 5 (the default, "2")
+    # k_repair_runs on the low 5 (the default, "2"; with dense barcode keys -- CRGPU_TEST_DENSE=1, 47 bits -- four passes +
+    # eleven low bits: the stalled pass of a "2" case is one of the first four)
     c.set_key_layout(w.n_genes, w.umi_len, 1, 0)
     r = w.host_reads(0, n)
     _, _, _, dev = G.gpu_barcode_stage(c, r, n)
