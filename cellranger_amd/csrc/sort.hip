@@ -1122,8 +1122,11 @@ static int cr_order_runs_r02(crgpu_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals,
 //                     neighbour (same bits above `low`) and is SMALLER than it -- the run is out of order there.  One 64-bit
 //                     ballot word per 64 keys is written: 1.6 % of the bytes read.
 //   k_repair_runs     one lane per set bit; the lane whose bit is the FIRST descent of its run (no other one between the
-//                     run's head and it) puts the whole run in order through memory (or_run_through_memory: insertion sort,
-//                     bucket permutation for long runs, *bad for runs beyond OR_MAX -> the caller sorts on all bits).
+//                     run's head and it) owns the run: up to RR_SHORT keys are put in order in its registers; a longer run's
+//                     head goes to a device-wide list.
+//   k_repair_medium_runs / k_repair_long_runs   the listed runs: up to 64 keys by a wave, more by a workgroup in LDS, what
+//                     fits neither through memory by one lane (or_run_through_memory; *bad for runs beyond OR_MAX -> the
+//                     caller sorts on all bits).  The lists spread the runs of a few hot barcodes over the whole device.
 // Runs are disjoint, so the repairing lanes never touch each other's keys.
 #define FD_ITEMS 8
 __global__ __launch_bounds__(256) void k_find_descents(const uint64_t *__restrict__ keys, uint64_t n, uint32_t low,

@@ -339,7 +339,8 @@ def test_clustered_umis_and_long_runs_of_near_identical_keys(big_run, finish, wi
     neighbourhoods are dense, counts tie, and one (barcode, feature) segment holds most of the reads.
     finish (CRGPU_SORT_FINISH): "0" = radix passes on every key bit; "2" (the default since round 3) = the sort leaves the
     lowest key bits that save a pass to k_find_descents + k_repair_runs (only the runs of equal top bits that are out of order
-    are touched: insertion up to 32 keys, in-place bucket permutation up to 65 536); "3" = round 2's k_order_runs (runs inside
+    are touched: up to 12 keys in registers, up to 64 by a wave, longer ones by a workgroup in LDS, beyond 4096 keys an in-place
+    bucket permutation through memory up to 65 536); "3" = round 2's k_order_runs (runs inside
     a wave by an odd-even transposition in registers).  A run of 90 000 keys makes either hand the job back to a sort on all
     bits (CRGPU_STAT_SORT_REFINISHED).  wide: a 6.8 M-entry whitelist and 36 601 features make the key 64 bits wide; the
     passes then leave TEN low bits (six passes instead of seven): runs of 13 .. 64 keys are put in order by a wave (a lane per
