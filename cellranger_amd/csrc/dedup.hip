@@ -2274,15 +2274,23 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
         }
         CR_TRY(fork2.side(fork2.t0));
     }
+    // Beside the main stream these grid-stride kernels take 6 of the 8 workgroups a CU holds: with all 8 every wave slot was
+    // theirs for their whole run time, and the main stream's next (often tiny) kernel waited milliseconds for one to end
+    uint32_t side_wgs = fork2.on_side ? 256u * 6u : 256u * 8u;
+    if (const char *g = getenv("CRGPU_SIDE_WGS")) side_wgs = 256u * (uint32_t)atoi(g);  // (A/B switch)
+    if (side_wgs < 256u) side_wgs = 256u * 8u;
     if (vals) {
         CrTimer t(ctx, CRGPU_T_DEDUP);
         if (!want_probe)
-            hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
+            hipLaunchKernelGGL(k_rep_read, dim3(cr_grid(nd, 256, side_wgs)), dim3(256), 0, ctx->stream, keys, vals, upos, nd, n_keys,
                                rep_b.as<uint32_t>());
-        // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): zeros
+        // reads that never reach DupBuilder::observe get no DupInfo (mark_dups.rs:289-291): zeros.  The direct scatter into our
+        // own packed temporary is followed by k_unpack_dupinfo, which writes all three arrays for EVERY read (zeros where the
+        // temporary holds none): zeroing them first was 9 GB of fills per 1 B reads in front of the scatter.
+        const bool unpack_covers_all = !windowed && !pr.packed_out;
         if (pr.packed_out) {
             CR_HIP(ctx, hipMemsetAsync(pr.packed_out, 0, pr.n_reads * sizeof(DupRec), ctx->stream));
-        } else {
+        } else if (!unpack_covers_all) {
             if (pr.out_umi) CR_HIP(ctx, hipMemsetAsync(pr.out_umi, 0, pr.n_reads * sizeof(uint32_t), ctx->stream));
             if (pr.out_cnt) CR_HIP(ctx, hipMemsetAsync(pr.out_cnt, 0, pr.n_reads * sizeof(uint32_t), ctx->stream));
             if (pr.out_flags) CR_HIP(ctx, hipMemsetAsync(pr.out_flags, 0, pr.n_reads, ctx->stream));
@@ -2338,17 +2346,17 @@ static int count_keys_impl(crgpu_ctx *ctx, uint64_t *d_keys_inout, uint64_t n_ke
             }
             DupRec *packed = pr.packed_out ? pr.packed_out : packed_b.as<DupRec>();
             if (pack8)
-                hipLaunchKernelGGL(k_per_read<true>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
+                hipLaunchKernelGGL(k_per_read<true>, dim3(cr_grid(nd, 256, side_wgs)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
                                    corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
             else
-                hipLaunchKernelGGL(k_per_read<false>, dim3(cr_grid(nd, 256)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
+                hipLaunchKernelGGL(k_per_read<false>, dim3(cr_grid(nd, 256, side_wgs)), dim3(256), 0, ctx->stream, kl, ukey, vals, upos, nd, n_keys,
                                    corr, inc_all, st, minidx, rep_b.as<uint32_t>(), (void *)packed, tf);
             if (!pr.packed_out) {
                 if (pack8)
-                    hipLaunchKernelGGL(k_unpack_dupinfo<true>, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream,
+                    hipLaunchKernelGGL(k_unpack_dupinfo<true>, dim3(cr_grid(pr.n_reads, 256, side_wgs)), dim3(256), 0, ctx->stream,
                                        (const void *)packed, pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
                 else
-                    hipLaunchKernelGGL(k_unpack_dupinfo<false>, dim3(cr_grid(pr.n_reads, 256)), dim3(256), 0, ctx->stream,
+                    hipLaunchKernelGGL(k_unpack_dupinfo<false>, dim3(cr_grid(pr.n_reads, 256, side_wgs)), dim3(256), 0, ctx->stream,
                                        (const void *)packed, pr.n_reads, pr.out_umi, pr.out_cnt, pr.out_flags);
             }
             CR_HIP(ctx, hipGetLastError());
